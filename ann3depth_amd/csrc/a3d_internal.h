@@ -1,0 +1,48 @@
+// a3d_internal.h — shared between the translation units of liba3d.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/a3d.h"
+
+namespace a3d {
+
+int set_error(int code, const char* fmt, ...);
+
+#define A3D_CHECK_ARG(cond, ...)                                 \
+  do {                                                           \
+    if (!(cond)) return ::a3d::set_error(A3D_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(A3D_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return A3D_OK;
+}
+
+// ---- implicit-GEMM front end (igemm_host.hip) ----
+struct GemmPlan {
+  int cfg;           // index into the config table
+  int splitk;
+  int ktiles_per_split;
+  int tiles_m, tiles_n;
+  size_t ws_bytes;   // split-K slabs (0 if splitk == 1)
+};
+
+struct GemmProblem {
+  int mode;          // MODE_*
+  int M, N, K;
+  int avec, bvec;    // 1 or 4
+};
+
+GemmPlan plan_gemm(const GemmProblem& g);
+
+struct IgemmParams;
+int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st);
+
+// column sums of a [rows, ld] matrix (first n columns) -> out[n]; ws >= colsum_ws_bytes
+size_t colsum_ws_bytes(int rows, int n);
+int launch_colsum(const float* x, int rows, int n, int ld, float* out, void* ws, hipStream_t st);
+
+}  // namespace a3d

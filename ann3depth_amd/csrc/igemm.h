@@ -1,0 +1,458 @@
+// igemm.h — implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel template covers the three contractions a conv layer needs, each as C[M,N] = A[M,K] * B[K,N]:
+//   FWD   : M = n*ho*wo pixels, N = Cout,  K = r*s*Cin   A = im2col(x)        B = filter [K][N] as stored (HWIO)
+//   BWD_D : M = n*h*w  pixels, N = Cin,   K = r*s*Cout  A = im2col^T(dz)     B = filter read as [Cin][(rs,Cout)]
+//   BWD_F : M = r*s*Cin,       N = Cout,  K = n*ho*wo   A = im2col(x)^T      B = dz [K][N]
+// Dense layers are the 1x1 / 1-pixel special case.  fp32 MFMA is bit-for-bit an fmaf chain, so results carry
+// plain fp32 rounding (no reduced-precision inputs).
+//
+// Block = 256 threads = 4 waves; each wave owns TM x TN accumulators of 32x32.  The K loop runs in tiles of BK=32
+// with a register-prefetched, double-buffered LDS pipeline (global loads of tile t+1 are in flight while the MFMAs
+// of tile t run; one __syncthreads per tile).  Inside a tile K is consumed in chunks of 8: lane half h supplies
+// k = 8u+4h+j to MFMA j of the chunk, for both operands, so a K-contiguous operand is read with one ds_read_b128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace a3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FastDiv {
+  uint32_t mul, shr, d;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+  uint32_t l = 0;
+  while ((1u << l) < d) ++l;                  // l = ceil(log2 d), 1..31
+  uint64_t p = 31 + l;
+  f.mul = (uint32_t)((((uint64_t)1 << p) + d - 1) / d);
+  f.shr = l - 1;
+  return f;
+}
+// exact for n < 2^31
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+
+enum { MODE_FWD = 0, MODE_BWD_D = 1, MODE_BWD_F = 2 };
+enum { EPI_RELU = 1, EPI_SIGMOID = 2 };
+
+struct IgemmParams {
+  const float* A;       // im2col source tensor (x or dz)
+  const float* B;       // FWD: filter; BWD_D: filter; BWD_F: dz
+  float* C;             // output (or split-K slabs)
+  const float* bias;    // [N] or null            (FWD epilogue)
+  const float* mask;    // [M, ldc] or null        (BWD_D epilogue: *= mask>0)
+  const uint8_t* keep;  // [M, N] or null          (FWD epilogue: *= keep*mask_scale)
+  float mask_scale;
+  int M, N, K;
+  // geometry of the im2col operand
+  int npix;             // number of pixels on the pixel axis (FWD/BWD_D: M, BWD_F: K)
+  int nrsc;             // r*s*channels on the filter-window axis (FWD/BWD_D: K, BWD_F: M)
+  int H, W;             // spatial extent of the SOURCE tensor being gathered
+  int ld;               // elements per source pixel
+  int stride, lstride, pad_t, pad_l;
+  int S;                // filter width
+  int Cg;               // channels of the gathered tensor (Cin for FWD/BWD_F, Cout for BWD_D)
+  int Cn;               // BWD_D: Cin (row count of B); unused otherwise
+  FastDiv div_phw, div_pw, div_c, div_s;   // pixel grid (PH*PW, PW) and window decode (Cg, S)
+  int pHW;              // source pixels per image = H*W
+  int ldb;              // FWD: N of filter rows; BWD_F: elements per dz pixel
+  int ldc;              // elements per output row
+  int act;
+  int splitk, ktiles_per_split;
+  size_t slab;          // elements per split-K slab
+  int tiles_m, tiles_n;
+};
+
+template <int MODE, int BM, int BN, int WAVES_M, int AVEC, int BVEC>
+struct IgemmCfg {
+  static constexpr int BK = 32;
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM >= 1 && TN >= 1 && TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile");
+  // LDS images
+  // A: FWD/BWD_D [BM][BK+4] (K contiguous, b128 fragment reads); BWD_F [BK][BM+4] (M contiguous, b32 reads)
+  static constexpr int A_ROWS = (MODE == MODE_BWD_F) ? BK : BM;
+  static constexpr int A_COLS = (MODE == MODE_BWD_F) ? BM : BK;
+  static constexpr int A_LD = A_COLS + 4;
+  // B: FWD/BWD_F [BK][BN+4] (N contiguous, b32 reads); BWD_D [BN][BK+4] (K contiguous, b128 reads)
+  static constexpr int B_ROWS = (MODE == MODE_BWD_D) ? BN : BK;
+  static constexpr int B_COLS = (MODE == MODE_BWD_D) ? BK : BN;
+  static constexpr int B_LD = B_COLS + 4;
+  static constexpr int A_ELEMS = A_ROWS * A_LD, B_ELEMS = B_ROWS * B_LD;
+  static constexpr int PIX = A_ROWS;   // pixel-table entries (rows of the im2col tile)
+  static constexpr size_t LDS_BYTES = (size_t)(2 * (A_ELEMS + B_ELEMS)) * 4 + (size_t)2 * PIX * 16;
+};
+
+// ---- pixel table: one int4 per row of the im2col tile: {image base in pixels, y0, x0, valid} ----
+template <bool TRANSPOSED>
+__device__ __forceinline__ int4 make_pix(const IgemmParams& p, int pixel) {
+  int4 e;
+  bool valid = pixel < p.npix;
+  uint32_t m = valid ? (uint32_t)pixel : 0u;
+  uint32_t n = fdiv(m, p.div_phw);
+  uint32_t rem = m - n * p.div_phw.d;
+  uint32_t po = fdiv(rem, p.div_pw);
+  uint32_t qo = rem - po * p.div_pw.d;
+  e.x = (int)(n * (uint32_t)p.pHW);
+  if (TRANSPOSED) {
+    e.y = (int)po + p.pad_t;
+    e.z = (int)qo + p.pad_l;
+  } else {
+    e.y = (int)po * p.stride - p.pad_t;
+    e.z = (int)qo * p.stride - p.pad_l;
+  }
+  e.w = valid ? 1 : 0;
+  return e;
+}
+
+struct ColDec {
+  int r, s, c;
+  bool valid;
+};
+__device__ __forceinline__ ColDec decode_col(const IgemmParams& p, int kcol) {
+  ColDec d;
+  d.valid = kcol < p.nrsc;
+  uint32_t k = d.valid ? (uint32_t)kcol : 0u;
+  uint32_t q = fdiv(k, p.div_c);
+  d.c = (int)(k - q * p.div_c.d);
+  uint32_t r = fdiv(q, p.div_s);
+  d.r = (int)r;
+  d.s = (int)(q - r * p.div_s.d);
+  return d;
+}
+
+// Gather ROWS x COLS (pixels x window elements) into registers. Thread t owns column chunk t % CPR and rows
+// t / CPR + j * RPP.
+template <int ROWS, int COLS, int VEC, bool TRANSPOSED>
+struct Im2colTile {
+  static constexpr int CPR = COLS / VEC;
+  static_assert(256 % CPR == 0, "cpr");
+  static constexpr int RPP = 256 / CPR;
+  static constexpr int NL = (ROWS + RPP - 1) / RPP;
+  static_assert(ROWS % RPP == 0, "rows");
+
+  __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const IgemmParams& p, const int4* pixtab,
+                                              const ColDec& cd, int tid) {
+    const int r0 = tid / CPR;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int4 pt = pixtab[r0 + j * RPP];
+      int y = TRANSPOSED ? pt.y - cd.r : pt.y + cd.r;
+      int x = TRANSPOSED ? pt.z - cd.s : pt.z + cd.s;
+      bool ok = cd.valid && pt.w;
+      if (TRANSPOSED) {
+        ok = ok && (((y | x) & (p.stride - 1)) == 0) && y >= 0 && x >= 0;
+        y >>= p.lstride;
+        x >>= p.lstride;
+      }
+      ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      long off = ((long)pt.x + (long)y * p.W + x) * (long)p.ld + cd.c;
+      if (VEC == 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.A + off);
+        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
+      } else {
+        regs[j][0] = ok ? p.A[off] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
+    const int r0 = tid / CPR, cq = tid % CPR;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
+      if (VEC == 4) {
+        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        dst[0] = regs[j][0];
+      }
+    }
+  }
+};
+
+// Plain 2-D tile: src[(row0+r)*ld + col0+c], zero outside [0,rmax) x [0,cmax).
+template <int ROWS, int COLS, int VEC>
+struct PlainTile {
+  static constexpr int CPR = COLS / VEC;
+  static constexpr int TOTAL = ROWS * CPR;
+  static constexpr int NL = (TOTAL + 255) / 256;
+
+  __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const float* src, int ld, int row0, int col0,
+                                              int rmax, int cmax, int tid) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int idx = tid + j * 256;
+      int r = idx / CPR, cq = idx % CPR;
+      int gr = row0 + r, gc = col0 + cq * VEC;
+      bool ok = (TOTAL % 256 == 0 || idx < TOTAL) && gr < rmax && gc < cmax;   // VEC=4 requires cmax % 4 == 0
+      long off = (long)gr * ld + gc;
+      if (VEC == 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(src + off);
+        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
+      } else {
+        regs[j][0] = ok ? src[off] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int idx = tid + j * 256;
+      if (TOTAL % 256 != 0 && idx >= TOTAL) continue;
+      int r = idx / CPR, cq = idx % CPR;
+      float* dst = lds + r * ld + cq * VEC;
+      if (VEC == 4) {
+        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        dst[0] = regs[j][0];
+      }
+    }
+  }
+};
+
+// BWD_D filter tile: rows = Cin (GEMM N), cols = (rs, Cout) (GEMM K): W[rs][cin][cout].
+template <int ROWS, int COLS, int VEC>
+struct FilterTTile {
+  static constexpr int CPR = COLS / VEC;
+  static constexpr int RPP = 256 / CPR;
+  static constexpr int NL = ROWS / RPP;
+  static_assert(ROWS % RPP == 0, "rows");
+  __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const IgemmParams& p, int n0, int kcol,
+                                              int tid) {
+    const int r0 = tid / CPR;
+    bool kvalid = kcol < p.K;
+    uint32_t k = kvalid ? (uint32_t)kcol : 0u;
+    uint32_t rs = fdiv(k, p.div_c);              // div_c.d == Cout here
+    int ko = (int)(k - rs * p.div_c.d);
+    long base = (long)rs * p.Cn * p.Cg + ko;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int cin = n0 + r0 + j * RPP;
+      bool ok = kvalid && cin < p.N;
+      long off = base + (long)cin * p.Cg;
+      if (VEC == 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p.B + off);
+        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
+      } else {
+        regs[j][0] = ok ? p.B[off] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
+    const int r0 = tid / CPR, cq = tid % CPR;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
+      if (VEC == 4) {
+        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        dst[0] = regs[j][0];
+      }
+    }
+  }
+};
+
+template <int MODE, int BM, int BN, int WAVES_M, int AVEC, int BVEC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, AVEC, BVEC>;
+  constexpr int BK = Cfg::BK;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
+  using ATile = Im2colTile<Cfg::A_ROWS, Cfg::A_COLS, AVEC, TRANSPOSED>;
+  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<Cfg::B_ROWS, Cfg::B_COLS, BVEC>,
+                                          PlainTile<Cfg::B_ROWS, Cfg::B_COLS, BVEC>>::type;
+  constexpr int BNL = BTile::NL;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);
+  float* Bs = As + 2 * Cfg::A_ELEMS;
+  int4* pixtab = reinterpret_cast<int4*>(Bs + 2 * Cfg::B_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- block -> (tile_m, tile_n, split): XCD-aware bijective remap of the linear id, tile_n fastest so the
+  //      blocks that re-read one im2col panel share an XCD's L2 ----
+  const uint32_t nwg = gridDim.x;
+  uint32_t bid = blockIdx.x;
+  {
+    uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_mn = p.tiles_m * p.tiles_n;
+  const int split = bid / tiles_mn;
+  const int tmn = bid - split * tiles_mn;
+  const int tile_m = tmn / p.tiles_n, tile_n = tmn - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+  const int nkt = kt_end - kt_begin;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  float ra[ATile::NL][AVEC];
+  float rb[BNL][BVEC];
+
+  const int a_cq = tid % ATile::CPR;
+  const int b_cq = tid % BTile::CPR;   // BWD_D only
+
+  // ---- prologue ----
+  if (MODE == MODE_BWD_F) {
+    // pixel axis is K: tables for tiles kt_begin and kt_begin+1
+    if (tid < 2 * Cfg::PIX) {
+      int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
+      pixtab[which * Cfg::PIX + e] = make_pix<false>(p, (kt_begin + which) * BK + e);
+    }
+  } else {
+    if (tid < Cfg::PIX) pixtab[tid] = make_pix<TRANSPOSED>(p, m0 + tid);
+  }
+  __syncthreads();
+
+  ColDec cdec;
+  if (MODE == MODE_BWD_F) cdec = decode_col(p, m0 + a_cq * AVEC);
+
+  auto load_tiles = [&](int kt, int pbuf) {
+    if constexpr (MODE == MODE_BWD_F) {
+      ATile::load(ra, p, pixtab + pbuf * Cfg::PIX, cdec, tid);
+      BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+    } else {
+      ColDec cd = decode_col(p, kt * BK + a_cq * AVEC);
+      ATile::load(ra, p, pixtab, cd, tid);
+      if constexpr (MODE == MODE_FWD)
+        BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+      else
+        BTile::load(rb, p, n0, kt * BK + b_cq * BVEC, tid);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    ATile::store(ra, As + buf * Cfg::A_ELEMS, Cfg::A_LD, tid);
+    BTile::store(rb, Bs + buf * Cfg::B_ELEMS, Cfg::B_LD, tid);
+  };
+
+  if (nkt > 0) {
+    load_tiles(kt_begin, 0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int it = 0; it < nkt; ++it) {
+    const int kt = kt_begin + it;
+    const bool more = it + 1 < nkt;
+    if (more) load_tiles(kt + 1, (it + 1) & 1);
+    if (MODE == MODE_BWD_F) {
+      // table for tile kt+2 goes into the buffer tile kt used (all its loads were issued before the last barrier)
+      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
+    }
+    const float* Ac = As + cur * Cfg::A_ELEMS;
+    const float* Bc = Bs + cur * Cfg::B_ELEMS;
+#pragma unroll
+    for (int u = 0; u < BK / 8; ++u) {
+      f32x4 af[TM], bf[TN];
+      const int kk = 8 * u + 4 * lh;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = wm * Cfg::WM + a * 32 + li;
+        if (MODE == MODE_BWD_F) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[a][j] = Ac[(kk + j) * Cfg::A_LD + row];
+        } else {
+          af[a] = *reinterpret_cast<const f32x4*>(Ac + row * Cfg::A_LD + kk);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = wn * Cfg::WN + b * 32 + li;
+        if (MODE == MODE_BWD_D) {
+          bf[b] = *reinterpret_cast<const f32x4*>(Bc + col * Cfg::B_LD + kk);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[b][j] = Bc[(kk + j) * Cfg::B_LD + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ----
+  float* Cout = p.C;
+  int ldc = p.ldc;
+  const bool partial = p.splitk > 1;
+  if (partial) {
+    Cout = p.C + (size_t)split * p.slab;
+    ldc = p.N;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn * Cfg::WN + b * 32 + li;
+      if (col >= p.N) continue;
+      float bias = 0.f;
+      if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        float val = acc[a][b][v];
+        const size_t o = (size_t)row * ldc + col;
+        if (!partial) {
+          if (MODE == MODE_FWD) {
+            val += bias;
+            if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
+            else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
+            if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
+          } else if (MODE == MODE_BWD_D) {
+            if (p.mask) val = p.mask[o] > 0.f ? val * p.mask_scale : 0.f;
+          }
+        }
+        Cout[o] = val;
+      }
+    }
+  }
+}
+
+// split-K slab reduction + the same epilogue
+struct ReduceParams {
+  const float* ws; float* C; const float* bias; const float* mask; const uint8_t* keep; float mask_scale;
+  int M, N, ldc, splitk, act, mode; size_t slab;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
+
+}  // namespace a3d

@@ -1,0 +1,434 @@
+// igemm_host.hip — tile/split-K planning, dispatch, split-K reduction, bias-gradient column sums, and the
+// conv2d / dense entry points of include/a3d.h.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "a3d_internal.h"
+#include "igemm.h"
+
+namespace a3d {
+
+int launch_igemm_mode0(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_igemm_mode1(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
+
+struct TileCfg {
+  int bm, bn;
+  float eff;   // relative MFMA efficiency of the tile shape (bigger tiles amortise LDS traffic better)
+};
+static const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 96, 0.92f}, {128, 64, 0.85f}, {128, 32, 0.55f},
+                                {64, 64, 0.65f},   {32, 128, 0.60f}, {64, 128, 0.85f}};
+static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+static const int kSlots = 512;               // 256 CUs x 2 resident blocks
+static const size_t kMaxSlabBytes = (size_t)192 << 20;
+
+// ---- opt-in launch timing (a3d_timing_*) ----
+struct TimingSlot {
+  hipEvent_t start, stop;
+  a3d_timing_record rec;
+};
+static std::mutex g_timing_mu;
+static bool g_timing_on = false;
+static std::vector<TimingSlot> g_timing;
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1};
+
+GemmPlan plan_gemm(const GemmProblem& g) {
+  GemmPlan best{};
+  double best_t = 1e300;
+  const int nk = (g.K + 31) / 32;
+  for (int c = 0; c < kNumCfgs; ++c) {
+    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
+    const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
+    const long tiles = (long)tm * tn;
+    int max_split = std::max(1, nk / 4);
+    max_split = std::min(max_split, 512);
+    long want = (kSlots + tiles - 1) / tiles;
+    int splitk = (int)std::min<long>(std::max<long>(want, 1), max_split);
+    while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
+    int kps = (nk + splitk - 1) / splitk;
+    splitk = (nk + kps - 1) / kps;
+    const long blocks = tiles * splitk;
+    const long rounds = (blocks + kSlots - 1) / kSlots;
+    // under-filled chip: a block alone on a CU runs ~1.6x faster than two sharing it
+    double fill = std::min(1.0, (double)blocks / kSlots);
+    double t_block = (double)bm * bn * kps * 32.0 / kCfgs[c].eff * (0.6 + 0.4 * fill);
+    double t = rounds * t_block;
+    if (splitk > 1) t += (double)g.M * g.N * (splitk + 1) * 24.0;   // slab write+read, in the same pseudo-units
+    if (t < best_t) {
+      best_t = t;
+      best.cfg = c;
+      best.splitk = splitk;
+      best.ktiles_per_split = kps;
+      best.tiles_m = tm;
+      best.tiles_n = tn;
+      best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+    }
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
+  const size_t total = (size_t)p.M * p.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * p.slab + i];
+    const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
+    const size_t o = (size_t)row * p.ldc + col;
+    if (p.mode == MODE_FWD) {
+      if (p.bias) s += p.bias[col];
+      if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
+      else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
+      if (p.keep) s = p.keep[i] ? s * p.mask_scale : 0.f;
+    } else if (p.mode == MODE_BWD_D) {
+      if (p.mask) s = p.mask[o] > 0.f ? s * p.mask_scale : 0.f;
+    }
+    p.C[o] = s;
+  }
+}
+
+int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st) {
+  p.splitk = plan.splitk;
+  p.ktiles_per_split = plan.ktiles_per_split;
+  p.tiles_m = plan.tiles_m;
+  p.tiles_n = plan.tiles_n;
+  p.slab = (size_t)p.M * p.N;
+  float* final_c = p.C;
+  if (plan.splitk > 1) {
+    if (!ws) return set_error(A3D_EWORKSPACE, "igemm: split-K needs a workspace");
+    p.C = static_cast<float*>(ws);
+  }
+  const unsigned grid = (unsigned)((long)plan.tiles_m * plan.tiles_n * plan.splitk);
+  int rc;
+  TimingSlot slot{};
+  bool timed = false;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    timed = g_timing_on;
+  }
+  if (timed) {
+    if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
+      return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
+    hipEventRecord(slot.start, st);
+  }
+  if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
+  else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
+  else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
+  if (timed) {
+    hipEventRecord(slot.stop, st);
+    a3d_timing_record& r = slot.rec;
+    r.mode = mode; r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
+    r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
+    r.flops = 2.0 * p.M * p.N * p.K;
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timing.push_back(slot);
+  }
+  if (rc != A3D_OK) return rc;
+  if (plan.splitk > 1) {
+    ReduceParams r;
+    r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
+    r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
+    r.mode = mode; r.slab = p.slab;
+    size_t total = (size_t)p.M * p.N;
+    unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
+    rc = check_launch("splitk_reduce");
+  }
+  return rc;
+}
+
+// ---- column sums (BiasAddGrad) ----
+static const int kColsumRowSplits = 128;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int rows, int n, int ld, float* part,
+                                                             int rows_per_split) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r_begin = blockIdx.y * rows_per_split;
+  const int r_end = min(rows, r_begin + rows_per_split);
+  float s = 0.f;
+  if (col < n)
+    for (int r = r_begin + rl; r < r_end; r += 4) s += x[(size_t)r * ld + col];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < n) part[(size_t)blockIdx.y * n + col] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                                red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+size_t colsum_ws_bytes(int rows, int n) {
+  (void)rows;
+  return (size_t)kColsumRowSplits * n * 4;
+}
+
+int launch_colsum(const float* x, int rows, int n, int ld, float* out, void* ws, hipStream_t st) {
+  int splits = std::min(kColsumRowSplits, std::max(1, rows / 16));
+  int rps = (rows + splits - 1) / splits;
+  splits = (rows + rps - 1) / rps;
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, splits), dim3(256), 0, st, x, rows, n, ld, part, rps);
+  int rc = check_launch("colsum_partial");
+  if (rc != A3D_OK) return rc;
+  ReduceParams r{};
+  r.ws = part; r.C = out; r.M = 1; r.N = n; r.ldc = n; r.splitk = splits; r.mode = MODE_BWD_F; r.slab = (size_t)n;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, r);
+  return check_launch("colsum_reduce");
+}
+
+// ---- descriptor checks / parameter assembly ----
+static int ilog2_exact(int v) {
+  for (int l = 0; l < 8; ++l)
+    if ((1 << l) == v) return l;
+  return -1;
+}
+
+static int check_desc(const a3d_conv_desc* d) {
+  A3D_CHECK_ARG(d != nullptr, "conv: null descriptor");
+  A3D_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->c > 0 && d->k > 0 && d->r > 0 && d->s > 0, "conv: bad dims");
+  A3D_CHECK_ARG(ilog2_exact(d->stride) >= 0 && d->stride <= 4, "conv: stride %d unsupported (1, 2 or 4)", d->stride);
+  A3D_CHECK_ARG(d->pad_t >= 0 && d->pad_l >= 0 && d->pad_t < d->r && d->pad_l < d->s, "conv: bad padding");
+  A3D_CHECK_ARG(d->ho > 0 && d->wo > 0, "conv: bad output size");
+  A3D_CHECK_ARG((d->ho - 1) * d->stride - d->pad_t < d->h && (d->wo - 1) * d->stride - d->pad_l < d->w,
+                "conv: output size inconsistent with input");
+  A3D_CHECK_ARG(d->ldx >= d->c && d->ldy >= d->k, "conv: pixel strides smaller than channel counts");
+  const double lim = 2147483647.0;
+  A3D_CHECK_ARG((double)d->n * d->h * d->w * d->ldx < lim && (double)d->n * d->ho * d->wo * d->ldy < lim &&
+                    (double)d->r * d->s * d->c * d->k < lim,
+                "conv: tensor too large for 31-bit indexing");
+  return A3D_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct ConvProblem {
+  GemmProblem g;
+};
+
+static GemmProblem fwd_problem(const a3d_conv_desc* d) {
+  GemmProblem g;
+  g.mode = MODE_FWD;
+  g.M = d->n * d->ho * d->wo; g.N = d->k; g.K = d->r * d->s * d->c;
+  g.avec = (d->c % 4 == 0 && d->ldx % 4 == 0) ? 4 : 1;
+  g.bvec = (d->k % 4 == 0) ? 4 : 1;
+  return g;
+}
+static GemmProblem bwd_d_problem(const a3d_conv_desc* d) {
+  GemmProblem g;
+  g.mode = MODE_BWD_D;
+  g.M = d->n * d->h * d->w; g.N = d->c; g.K = d->r * d->s * d->k;
+  g.avec = (d->k % 4 == 0 && d->ldy % 4 == 0) ? 4 : 1;
+  g.bvec = (d->k % 4 == 0) ? 4 : 1;
+  return g;
+}
+static GemmProblem bwd_f_problem(const a3d_conv_desc* d) {
+  GemmProblem g;
+  g.mode = MODE_BWD_F;
+  g.M = d->r * d->s * d->c; g.N = d->k; g.K = d->n * d->ho * d->wo;
+  g.avec = (d->c % 4 == 0 && d->ldx % 4 == 0) ? 4 : 1;
+  g.bvec = (d->k % 4 == 0 && d->ldy % 4 == 0) ? 4 : 1;
+  return g;
+}
+
+static void fill_common(IgemmParams& p, const GemmProblem& g) {
+  p = IgemmParams{};
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.mask_scale = 1.f;
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" {
+
+int a3d_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing_on = on != 0;
+  return A3D_OK;
+}
+
+int a3d_timing_collect(a3d_timing_record* out, int cap) {
+  std::vector<TimingSlot> slots;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    slots.swap(g_timing);
+  }
+  int n = 0;
+  for (TimingSlot& s : slots) {
+    hipEventSynchronize(s.stop);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, s.start, s.stop);
+    s.rec.ms = ms;
+    if (out && n < cap) out[n++] = s.rec;
+    hipEventDestroy(s.start);
+    hipEventDestroy(s.stop);
+  }
+  return n;
+}
+
+size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
+  if (check_desc(d) != A3D_OK) return 0;
+  return plan_gemm(fwd_problem(d)).ws_bytes;
+}
+
+int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                   void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
+  A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
+  GemmProblem g = fwd_problem(d);
+  if (!aligned16(x)) g.avec = 1;
+  if (!aligned16(w)) g.bvec = 1;
+  GemmPlan plan = plan_gemm(fwd_problem(d));
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", plan.ws_bytes);
+  IgemmParams p;
+  fill_common(p, g);
+  p.A = x; p.B = w; p.C = y; p.bias = bias; p.act = act;
+  p.npix = g.M; p.nrsc = g.K;
+  p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
+  p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.S = d->s; p.Cg = d->c;
+  p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
+  p.div_c = make_fastdiv(d->c); p.div_s = make_fastdiv(d->s);
+  p.ldb = d->k; p.ldc = d->ldy;
+  return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+}
+
+size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
+  if (check_desc(d) != A3D_OK) return 0;
+  return plan_gemm(bwd_d_problem(d)).ws_bytes;
+}
+
+int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w, float* dx, const float* relu_mask,
+                        void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(dz && w && dx, "conv2d_bwd_data: null tensor");
+  GemmProblem g = bwd_d_problem(d);
+  if (!aligned16(dz)) g.avec = 1;
+  if (!aligned16(w)) g.bvec = 1;
+  GemmPlan plan = plan_gemm(bwd_d_problem(d));
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
+  IgemmParams p;
+  fill_common(p, g);
+  p.A = dz; p.B = w; p.C = dx; p.mask = relu_mask;
+  p.npix = g.M; p.nrsc = g.K;
+  p.H = d->ho; p.W = d->wo; p.ld = d->ldy; p.pHW = d->ho * d->wo;
+  p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.S = d->s; p.Cg = d->k; p.Cn = d->c;
+  p.div_phw = make_fastdiv(d->h * d->w); p.div_pw = make_fastdiv(d->w);
+  p.div_c = make_fastdiv(d->k); p.div_s = make_fastdiv(d->s);
+  p.ldb = 0; p.ldc = d->ldx;
+  return launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+}
+
+size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
+  if (check_desc(d) != A3D_OK) return 0;
+  size_t slabs = plan_gemm(bwd_f_problem(d)).ws_bytes;
+  return std::max(slabs, colsum_ws_bytes(d->n * d->ho * d->wo, d->k));
+}
+
+int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
+                          size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(x && dz && dw, "conv2d_bwd_filter: null tensor");
+  GemmProblem g = bwd_f_problem(d);
+  if (!aligned16(x)) g.avec = 1;
+  if (!aligned16(dz)) g.bvec = 1;
+  GemmPlan plan = plan_gemm(bwd_f_problem(d));
+  size_t need = std::max(plan.ws_bytes, db ? colsum_ws_bytes(g.K, g.N) : (size_t)0);
+  if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (db) {   // BiasAddGrad first: it shares the workspace with the slabs, stream order keeps them apart
+    rc = launch_colsum(dz, g.K, g.N, d->ldy, db, ws, st);
+    if (rc != A3D_OK) return rc;
+  }
+  IgemmParams p;
+  fill_common(p, g);
+  p.A = x; p.B = dz; p.C = dw;
+  p.npix = g.K; p.nrsc = g.M;
+  p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
+  p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.S = d->s; p.Cg = d->c;
+  p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
+  p.div_c = make_fastdiv(d->c); p.div_s = make_fastdiv(d->s);
+  p.ldb = d->ldy; p.ldc = d->k;
+  return launch_igemm(MODE_BWD_F, plan, g.avec, g.bvec, p, ws, st);
+}
+
+// ---- dense = 1x1 conv over a 1x1 image ----
+static a3d_conv_desc dense_desc(int m, int k, int n) {
+  a3d_conv_desc d{};
+  d.n = m; d.h = 1; d.w = 1; d.c = k; d.k = n; d.r = 1; d.s = 1; d.stride = 1; d.ho = 1; d.wo = 1;
+  d.ldx = k; d.ldy = n;
+  return d;
+}
+
+size_t a3d_dense_fwd_ws_bytes(int m, int k, int n) {
+  a3d_conv_desc d = dense_desc(m, k, n);
+  return a3d_conv2d_fwd_ws_bytes(&d);
+}
+
+int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
+                  const uint8_t* drop_keep, void* ws, size_t ws_bytes, void* stream) {
+  A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_fwd: bad dims");
+  a3d_conv_desc d = dense_desc(m, k, n);
+  int rc = check_desc(&d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
+  GemmProblem g = fwd_problem(&d);
+  if (!aligned16(x)) g.avec = 1;
+  if (!aligned16(w)) g.bvec = 1;
+  GemmPlan plan = plan_gemm(fwd_problem(&d));
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_fwd: need %zu workspace bytes", plan.ws_bytes);
+  IgemmParams p;
+  fill_common(p, g);
+  p.A = x; p.B = w; p.C = y; p.bias = bias; p.act = act; p.keep = drop_keep; p.mask_scale = 2.f;
+  p.npix = m; p.nrsc = k; p.H = 1; p.W = 1; p.ld = k; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1; p.Cg = k;
+  p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(k); p.div_s = make_fastdiv(1);
+  p.ldb = n; p.ldc = n;
+  return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+}
+
+size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n) {
+  a3d_conv_desc d = dense_desc(m, k, n);
+  return a3d_conv2d_bwd_data_ws_bytes(&d);
+}
+
+int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
+                       float scale, void* ws, size_t ws_bytes, void* stream) {
+  A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_data: bad dims");
+  a3d_conv_desc d = dense_desc(m, k, n);
+  int rc = check_desc(&d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(dz && w && dx, "dense_bwd_data: null tensor");
+  GemmProblem g = bwd_d_problem(&d);
+  if (!aligned16(dz)) g.avec = 1;
+  if (!aligned16(w)) g.bvec = 1;
+  GemmPlan plan = plan_gemm(bwd_d_problem(&d));
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: need %zu workspace bytes", plan.ws_bytes);
+  IgemmParams p;
+  fill_common(p, g);
+  p.A = dz; p.B = w; p.C = dx; p.mask = mask; p.mask_scale = scale;
+  p.npix = m; p.nrsc = n; p.H = 1; p.W = 1; p.ld = n; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1;
+  p.Cg = n; p.Cn = k;
+  p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(n); p.div_s = make_fastdiv(1);
+  p.ldc = k;
+  return launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+}
+
+size_t a3d_dense_bwd_filter_ws_bytes(int m, int k, int n) {
+  a3d_conv_desc d = dense_desc(m, k, n);
+  return a3d_conv2d_bwd_filter_ws_bytes(&d);
+}
+
+int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, void* ws,
+                         size_t ws_bytes, void* stream) {
+  A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_filter: bad dims");
+  a3d_conv_desc d = dense_desc(m, k, n);
+  return a3d_conv2d_bwd_filter(&d, x, dz, dw, db, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

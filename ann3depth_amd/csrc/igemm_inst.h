@@ -1,0 +1,47 @@
+// igemm_inst.h — instantiates every (tile config x vector width) of one MODE; included by igemm_{fwd,bwd_d,bwd_f}.hip
+// with A3D_MODE defined, so the three modes compile in parallel.
+#include "a3d_internal.h"
+#include "igemm.h"
+
+namespace a3d {
+
+#define A3D_CFGS(X) X(0, 128, 128, 2) X(1, 128, 96, 4) X(2, 128, 64, 4) X(3, 128, 32, 4) X(4, 64, 64, 2) \
+                    X(5, 32, 128, 1) X(6, 64, 128, 1)
+
+template <int BM, int BN, int WAVES_M, int AVEC, int BVEC>
+static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
+  using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, AVEC, BVEC>;
+  auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, AVEC, BVEC>;
+  static bool attr_done = false;   // idempotent attribute, benign if set twice
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, p);
+  return check_launch("igemm");
+}
+
+template <int BM, int BN, int WAVES_M>
+static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
+  if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, 4, 4>(p, grid, st);
+  if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, 4, 1>(p, grid, st);
+  if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, 1, 4>(p, grid, st);
+  return launch_one<BM, BN, WAVES_M, 1, 1>(p, grid, st);
+}
+
+#define A3D_CAT_(a, b) a##b
+#define A3D_CAT(a, b) A3D_CAT_(a, b)
+
+int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
+  switch (cfg) {
+#define X(i, bm, bn, wm) \
+  case i: return launch_vec<bm, bn, wm>(avec, bvec, p, grid, st);
+    A3D_CFGS(X)
+#undef X
+  }
+  return set_error(A3D_EINVAL, "igemm: unknown config %d", cfg);
+}
+
+}  // namespace a3d

@@ -1,0 +1,312 @@
+// pointwise.hip — the HBM-bound kernels of the path: max-pool (+concat) and its gradient (+ReluGrad), legacy
+// bilinear resize, patch extraction, scale-invariant log loss (wavefront-shuffle reductions) and TF-1.3 ApplyAdam.
+// This file is compiled with -ffp-contract=off (see Makefile): the oracle does these computations as separate
+// fp32 operations, and without FMA contraction the kernels are bit-exact against the numpy restatement (HIP's
+// __f*_rn intrinsics are plain operators on ROCm 7.2 and do not prevent contraction by themselves).
+#include <algorithm>
+
+#include "a3d_internal.h"
+
+namespace a3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline unsigned grid_for(size_t total, int per_block = 256, unsigned cap = 8192) {
+  size_t g = (total + per_block - 1) / per_block;
+  return (unsigned)std::min<size_t>(std::max<size_t>(g, 1), cap);
+}
+
+// ------------------------------------------------------------------ max pool 2x2/2 VALID
+// one thread per output element; channel index fastest -> coalesced along NHWC's C.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ extra, int n, int h, int w, int c,
+                                                          int ho, int wo, int ldy) {
+  const int cout = c + (extra ? 1 : 0);
+  const size_t total = (size_t)n * ho * wo * cout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cout);
+    const size_t pix = i / cout;
+    float v;
+    if (ch < c) {
+      const int q = (int)(pix % wo);
+      const size_t t = pix / wo;
+      const int p = (int)(t % ho);
+      const int b = (int)(t / ho);
+      const float* s = x + (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+      v = fmaxf(fmaxf(s[0], s[c]), fmaxf(s[(size_t)w * c], s[(size_t)w * c + c]));
+    } else {
+      v = extra[pix];
+    }
+    y[pix * ldy + ch] = v;
+  }
+}
+
+// one thread per 2x2 cell of the INPUT grid (ceil(h/2) x ceil(w/2)); cells cut by VALID flooring write zeros.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                          int wo, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const size_t total = (size_t)n * hc * wc * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int q = (int)(t % wc);
+    t /= wc;
+    const int p = (int)(t % hc);
+    const int b = (int)(t / hc);
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+    const bool full = p < ho && q < wo;
+    if (full) {
+      const float v0 = x[base], v1 = x[base + c], v2 = x[base + (size_t)w * c], v3 = x[base + (size_t)w * c + c];
+      int arg = 0;
+      float best = v0;
+      if (v1 > best) { best = v1; arg = 1; }
+      if (v2 > best) { best = v2; arg = 2; }
+      if (v3 > best) { best = v3; arg = 3; }
+      float g = dy[(((size_t)b * ho + p) * wo + q) * lddy + ch];
+      if (relu_mask && !(best > 0.f)) g = 0.f;
+      dx[base] = arg == 0 ? g : 0.f;
+      dx[base + c] = arg == 1 ? g : 0.f;
+      dx[base + (size_t)w * c] = arg == 2 ? g : 0.f;
+      dx[base + (size_t)w * c + c] = arg == 3 ? g : 0.f;
+    } else {
+      const bool has_r = 2 * p + 1 < h, has_c = 2 * q + 1 < w;
+      dx[base] = 0.f;
+      if (has_c) dx[base + c] = 0.f;
+      if (has_r) dx[base + (size_t)w * c] = 0.f;
+      if (has_r && has_c) dx[base + (size_t)w * c + c] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ResizeBilinear (legacy, align_corners=False)
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
+                                                     int w, int c, int oh, int ow, float sy, float sx) {
+  const size_t total = (size_t)n * oh * ow * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    const float fy = __fmul_rn((float)oy, sy), fx = __fmul_rn((float)ox, sx);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
+    const float* img = x + (size_t)b * h * w * c + ch;
+    const float tl = img[((size_t)y0 * w + x0) * c], tr = img[((size_t)y0 * w + x1) * c];
+    const float bl = img[((size_t)y1 * w + x0) * c], br = img[((size_t)y1 * w + x1) * c];
+    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), lx));
+    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), lx));
+    y[i] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ly));
+  }
+}
+
+// ------------------------------------------------------------------ extract_image_patches (SAME, zero fill)
+__global__ __launch_bounds__(256) void patches_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
+                                                      int w, int c, int k, int stride, int ph, int pw, int pad_t,
+                                                      int pad_l) {
+  const size_t total = (size_t)n * ph * pw * k * k * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int j = (int)(t % k);
+    t /= k;
+    const int ii = (int)(t % k);
+    t /= k;
+    const int pc = (int)(t % pw);
+    t /= pw;
+    const int pr = (int)(t % ph);
+    const int b = (int)(t / ph);
+    const int sy = pr * stride - pad_t + ii, sx = pc * stride - pad_l + j;
+    float v = 0.f;
+    if ((unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)w) v = x[(((size_t)b * h + sy) * w + sx) * c + ch];
+    y[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ scale-invariant log loss
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float masked_log(float v) {
+  float l = logf(__fadd_rn(v, 1e-8f));
+  return isnan(l) ? 0.f : l;     // tf.where(tf.is_nan(log), 0, log): -inf is kept
+}
+
+// one block per sample: ws[2b] = sum d^2, ws[2b+1] = sum d
+__global__ __launch_bounds__(256) void silog_sums_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                         float* __restrict__ ws, int npix) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x;
+  const float* o = out + (size_t)b * npix;
+  const float* t = tgt + (size_t)b * npix;
+  float s2 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < npix; i += 256) {
+    const float d = __fsub_rn(masked_log(o[i]), masked_log(t[i]));
+    s2 += d * d;
+    s1 += d;
+  }
+  s2 = wave_sum(s2);
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s2;
+    red[1][threadIdx.x >> 6] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[2 * b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ws[2 * b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ __launch_bounds__(64) void silog_final_kernel(const float* __restrict__ ws, float* __restrict__ loss, int b,
+                                                         float c) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < b; i += 64) {
+    const float s1 = ws[2 * i + 1];
+    s += ws[2 * i] - c * (s1 * s1);
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = s / (float)b;
+}
+
+__global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                        const float* __restrict__ ws, float* __restrict__ dout, int b,
+                                                        int npix, float c, float inv_b) {
+  const size_t total = (size_t)b * npix;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int smp = (int)(i / npix);
+    const float o = out[i];
+    const float arg = __fadd_rn(o, 1e-8f);
+    const float lo = logf(arg);
+    float g = 0.f;
+    if (!isnan(lo)) {
+      const float d = __fsub_rn(lo, masked_log(tgt[i]));
+      const float sd = ws[2 * smp + 1];
+      g = __fdiv_rn(__fmul_rn(__fsub_rn(__fmul_rn(2.f, d), __fmul_rn(__fmul_rn(2.f, c), sd)), inv_b), arg);
+    }
+    dout[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ ApplyAdam (TF 1.3 formula)
+__device__ __forceinline__ void adam_one(float& var, float& m, float& v, float g, float omb1, float omb2, float alpha,
+                                         float eps) {
+  m = __fadd_rn(m, __fmul_rn(__fsub_rn(g, m), omb1));
+  v = __fadd_rn(v, __fmul_rn(__fsub_rn(__fmul_rn(g, g), v), omb2));
+  var = __fsub_rn(var, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(__fsqrt_rn(v), eps)));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ g, size_t count,
+                                                   float omb1, float omb2, float alpha, float eps, float gscale) {
+  const size_t nvec = count / 4;
+  const bool use_scale = gscale != 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    f32x4 w4 = reinterpret_cast<f32x4*>(var)[i], m4 = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 v4 = reinterpret_cast<f32x4*>(v)[i], g4 = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
+      float wj = w4[j], mj = m4[j], vj = v4[j];
+      adam_one(wj, mj, vj, gj, omb1, omb2, alpha, eps);
+      w4[j] = wj; m4[j] = mj; v4[j] = vj;
+    }
+    reinterpret_cast<f32x4*>(var)[i] = w4;
+    reinterpret_cast<f32x4*>(m)[i] = m4;
+    reinterpret_cast<f32x4*>(v)[i] = v4;
+  }
+  if (blockIdx.x == 0) {
+    const size_t i = nvec * 4 + threadIdx.x;
+    if (i < count) {
+      float gj = use_scale ? __fmul_rn(g[i], gscale) : g[i];
+      adam_one(var[i], m[i], v[i], gj, omb1, omb2, alpha, eps);
+    }
+  }
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" {
+
+int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int ldy, const float* extra,
+                       void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && x && y, "maxpool_fwd: bad arguments");
+  A3D_CHECK_ARG(ldy >= c + (extra ? 1 : 0), "maxpool_fwd: ldy %d too small", ldy);
+  const int ho = h / 2, wo = w / 2;
+  const size_t total = (size_t)n * ho * wo * (c + (extra ? 1 : 0));
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
+                     extra, n, h, w, c, ho, wo, ldy);
+  return check_launch("maxpool_fwd");
+}
+
+int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* dy, int lddy, float* dx,
+                       int relu_mask, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && x && dy && dx && lddy >= c, "maxpool_bwd: bad arguments");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy,
+                     dx, n, h, w, c, h / 2, w / 2, lddy, relu_mask);
+  return check_launch("maxpool_bwd");
+}
+
+int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, int ow, float* y, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && x && y, "resize: bad arguments");
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  const size_t total = (size_t)n * oh * ow * c;
+  hipLaunchKernelGGL(resize_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, h,
+                     w, c, oh, ow, sy, sx);
+  return check_launch("resize");
+}
+
+int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0 && x && y, "patches: bad arguments");
+  const int ph = (h + stride - 1) / stride, pw = (w + stride - 1) / stride;
+  const int pad_h = std::max((ph - 1) * stride + k - h, 0), pad_w = std::max((pw - 1) * stride + k - w, 0);
+  const size_t total = (size_t)n * ph * pw * k * k * c;
+  hipLaunchKernelGGL(patches_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, n, h, w, c, k, stride, ph, pw, pad_h / 2, pad_w / 2);
+  return check_launch("patches");
+}
+
+static const float kSilogC = (float)(0.5 / (74 * 55));   // src/models.py:269, folded constant
+
+int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, float* loss, float* ws, void* stream) {
+  A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && loss && ws, "silog_fwd: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(silog_sums_kernel, dim3(b), dim3(256), 0, st, out, tgt, ws, npix);
+  int rc = check_launch("silog_sums");
+  if (rc != A3D_OK) return rc;
+  hipLaunchKernelGGL(silog_final_kernel, dim3(1), dim3(64), 0, st, ws, loss, b, kSilogC);
+  return check_launch("silog_final");
+}
+
+int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,
+                       void* stream) {
+  A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && ws && dout, "silog_bwd: bad arguments");
+  const size_t total = (size_t)b * npix;
+  hipLaunchKernelGGL(silog_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), out, tgt,
+                     ws, dout, b, npix, kSilogC, 1.0f / (float)b);
+  return check_launch("silog_bwd");
+}
+
+int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
+                       float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
+                       void* stream) {
+  A3D_CHECK_ARG(count > 0 && var && m && v && g, "adam: bad arguments");
+  A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                  reinterpret_cast<uintptr_t>(g)) & 15) == 0, "adam: buffers must be 16-byte aligned");
+  const float alpha = lr * sqrtf(1.f - beta2_power) / (1.f - beta1_power);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,
+                     grad_scale);
+  return check_launch("adam");
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+"""Synchronous data parallelism: one process per GPU, gradient buckets all-reduced with RCCL over xGMI.
+
+Replaces the only data-parallel strategy of the reference, asynchronous between-graph replication through TF
+parameter servers over gRPC (src/ann3depth.py:77-92).  Each optimizer group's gradients live in one
+flat buffer (models.ParamGroup), so a bucket is one `all_reduce(sum)`; the 1/world mean is folded into the Adam
+kernel's grad_scale.  `start()` is asynchronous: the process group's own stream waits for the kernels already
+enqueued on the compute stream, so the dense-layer bucket (268 MB, produced first in backward) is reduced while
+the conv backward kernels still run; `finish()` makes the compute stream wait for all pending buckets.
+On CPU (tests) the same code runs over the gloo backend.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.pending = []
+
+    def start(self, flat_grad):
+        self.pending.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def broadcast(self, tensor, src=0):
+        dist.broadcast(tensor, src, group=self.group)
+
+
+def init_from_env(backend=None):
+    """Process-group setup from the launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables.
+    Returns (rank, local_rank, world_size); world_size 1 needs no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'    # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world

@@ -1,0 +1,175 @@
+"""Operator layer: the TF ops ann3depth's model functions instantiate, as calls into liba3d.so on torch tensors.
+
+PyTorch only owns memory and streams here.  Every function enqueues HIP kernels on the current stream through the
+C ABI (include/a3d.h) and returns without synchronising.  Layouts are TensorFlow's (NHWC / HWIO / [in,out]).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+ACT = {None: 0, 'relu': 1, 'sigmoid': 2}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f'{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} '
+                         f'contiguous={t.is_contiguous()}')
+
+
+class Workspace:
+    """Scratch for split-K slabs and partial reductions.  One per device; grows on demand (never inside a graph
+    capture: call reserve() with the largest need first)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def reserve(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f'workspace of {nbytes} bytes must be reserved before graph capture')
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return self.buf
+
+    def get(self, nbytes, device):
+        buf = self.reserve(nbytes, device)
+        return ctypes.c_void_p(buf.data_ptr()), buf.numel()
+
+
+_WS = Workspace()
+
+
+def same_pad(in_size, k, stride):
+    out = -(-in_size // stride)
+    pad = max((out - 1) * stride + k - in_size, 0)
+    return out, pad // 2
+
+
+def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None):
+    """Descriptor of tf.layers.conv2d(x[n,h,w,c], k, (r,s), (stride,stride), padding)."""
+    padding = padding.upper()
+    if padding == 'SAME':
+        ho, pt = same_pad(h, r, stride)
+        wo, pl = same_pad(w, s, stride)
+    elif padding == 'VALID':
+        ho, pt = (h - r) // stride + 1, 0
+        wo, pl = (w - s) // stride + 1, 0
+    else:
+        raise ValueError(padding)
+    return ConvDesc(n=n, h=h, w=w, c=c, k=k, r=r, s=s, stride=stride, pad_t=pt, pad_l=pl, ho=ho, wo=wo,
+                    ldx=ldx or c, ldy=ldy or k)
+
+
+def conv2d_fwd(d, x, w, bias, y, act=None):
+    lib = _lib.load()
+    ws, n = _WS.get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
+    check(lib.a3d_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], ws, n, _stream()),
+          'a3d_conv2d_fwd')
+    return y
+
+
+def conv2d_bwd_data(d, dz, w, dx, relu_mask=None):
+    lib = _lib.load()
+    ws, n = _WS.get(lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)), dz.device)
+    check(lib.a3d_conv2d_bwd_data(ctypes.byref(d), _ptr(dz), _ptr(w), _ptr(dx), _ptr(relu_mask), ws, n, _stream()),
+          'a3d_conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_filter(d, x, dz, dw, db=None):
+    lib = _lib.load()
+    ws, n = _WS.get(lib.a3d_conv2d_bwd_filter_ws_bytes(ctypes.byref(d)), x.device)
+    check(lib.a3d_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), ws, n, _stream()),
+          'a3d_conv2d_bwd_filter')
+    return dw, db
+
+
+def dense_fwd(x, w, bias, y, act=None, drop_keep=None):
+    m, k = x.shape
+    n = w.shape[1]
+    lib = _lib.load()
+    ws, nb = _WS.get(lib.a3d_dense_fwd_ws_bytes(m, k, n), x.device)
+    check(lib.a3d_dense_fwd(m, k, n, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], _ptr(drop_keep), ws, nb,
+                            _stream()), 'a3d_dense_fwd')
+    return y
+
+
+def dense_bwd_data(dz, w, dx, mask=None, scale=1.0):
+    m, n = dz.shape
+    k = w.shape[0]
+    lib = _lib.load()
+    ws, nb = _WS.get(lib.a3d_dense_bwd_data_ws_bytes(m, k, n), dz.device)
+    check(lib.a3d_dense_bwd_data(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), scale, ws, nb, _stream()),
+          'a3d_dense_bwd_data')
+    return dx
+
+
+def dense_bwd_filter(x, dz, dw, db=None):
+    m, k = x.shape
+    n = dz.shape[1]
+    lib = _lib.load()
+    ws, nb = _WS.get(lib.a3d_dense_bwd_filter_ws_bytes(m, k, n), x.device)
+    check(lib.a3d_dense_bwd_filter(m, k, n, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), ws, nb, _stream()),
+          'a3d_dense_bwd_filter')
+    return dw, db
+
+
+def maxpool2x2_fwd(x, y, extra=None):
+    """y[..., :c] = max_pool(x); if extra is given, y[..., c] = extra (fused concat).  y's last dim is its pixel
+    stride."""
+    n, h, w, c = x.shape
+    check(_lib.load().a3d_maxpool2x2_fwd(n, h, w, c, _ptr(x), _ptr(y), y.shape[-1], _ptr(extra), _stream()),
+          'a3d_maxpool2x2_fwd')
+    return y
+
+
+def maxpool2x2_bwd(x, dy, dx, relu_mask=True):
+    """dy's last dim is its pixel stride (>= c): only its first c channels are read."""
+    n, h, w, c = x.shape
+    check(_lib.load().a3d_maxpool2x2_bwd(n, h, w, c, _ptr(x), _ptr(dy), dy.shape[-1], _ptr(dx), int(relu_mask),
+                                         _stream()), 'a3d_maxpool2x2_bwd')
+    return dx
+
+
+def resize_bilinear_tf1(x, y):
+    n, h, w, c = x.shape
+    check(_lib.load().a3d_resize_bilinear_tf1(n, h, w, c, _ptr(x), y.shape[1], y.shape[2], _ptr(y), _stream()),
+          'a3d_resize_bilinear_tf1')
+    return y
+
+
+def extract_patches(x, k, stride, y):
+    n, h, w, c = x.shape
+    check(_lib.load().a3d_extract_patches(n, h, w, c, _ptr(x), k, stride, _ptr(y), _stream()), 'a3d_extract_patches')
+    return y
+
+
+def silog_loss_fwd(out, tgt, loss, ws):
+    b = out.shape[0]
+    npix = out.numel() // b
+    check(_lib.load().a3d_silog_loss_fwd(b, npix, _ptr(out), _ptr(tgt), _ptr(loss), _ptr(ws), _stream()),
+          'a3d_silog_loss_fwd')
+    return loss
+
+
+def silog_loss_bwd(out, tgt, ws, dout):
+    b = out.shape[0]
+    npix = out.numel() // b
+    check(_lib.load().a3d_silog_loss_bwd(b, npix, _ptr(out), _ptr(tgt), _ptr(ws), _ptr(dout), _stream()),
+          'a3d_silog_loss_bwd')
+    return dout
+
+
+def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale=1.0):
+    check(_lib.load().a3d_adam_apply_tf1(var.numel(), _ptr(var), _ptr(m), _ptr(v), _ptr(g), lr, beta1, beta2, eps,
+                                         beta1_power, beta2_power, grad_scale, _stream()), 'a3d_adam_apply_tf1')

@@ -1,0 +1,189 @@
+"""bench.py — images/sec of the MSDN train step (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU; gradients are all-reduced with
+RCCL).  Prints ONE JSON line on rank 0: whole-job images/s with inputs resident in HBM, the roofline of the dominant
+kernel (HIP-event timed inside the timed region) and the CPU baseline (the numpy oracle on the host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak = fp32 vector peak
+METRIC = 'images/sec (640x480->55x74 MSDN train step)'
+
+
+def synth_batch(B, rank, device):
+    """BASELINE.md synthetic inputs: u8 images /255 (seed 1000+rank); per-image min-max 8-bit depth /255
+    (seed 2000+rank), stored-size 480x640."""
+    rng = np.random.default_rng(1000 + rank)
+    img = (rng.integers(0, 256, (B, 480, 640, 3), dtype=np.uint8).astype(np.float32) / np.float32(255))
+    rng = np.random.default_rng(2000 + rank)
+    ys, xs = np.mgrid[0:480, 0:640].astype(np.float32)
+    dep = np.empty((B, 480, 640, 1), np.float32)
+    for b in range(B):
+        a, c, p = rng.uniform(0.002, 0.02, 3)
+        f = np.sin(a * xs + p) + np.cos(c * ys) + 0.002 * ys
+        f = (f - f.min()) / (f.max() - f.min())
+        dep[b, :, :, 0] = np.round(f * 255).astype(np.uint8).astype(np.float32) / np.float32(255)
+    return torch.from_numpy(img).to(device), torch.from_numpy(dep).to(device)
+
+
+def keep_masks(B, n, rank, device):
+    out = []
+    for step in range(n):
+        rng = np.random.default_rng(4000 + step + 100000 * rank)
+        out.append(torch.from_numpy((rng.random((B, 4096)) >= 0.5).astype(np.uint8)).to(device))
+    return out
+
+
+def collect_timing(lib):
+    from ann3depth_amd._lib import TimingRecord
+    cap = 1 << 16
+    arr = (TimingRecord * cap)()
+    n = lib.a3d_timing_collect(arr, cap)
+    return [arr[i] for i in range(n)]
+
+
+def kernel_name(r):
+    return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.avec}, {r.bvec}>'
+
+
+def run_phase(net, img, dep, masks, steps, warmup, global_step, lib, world, timed_kernels):
+    import torch.distributed as dist
+    net.global_step = global_step
+    for i in range(warmup):
+        net.step(img, dep, masks[i % len(masks)])
+    if timed_kernels:
+        lib.a3d_timing_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        net.step(img, dep, masks[(warmup + i) % len(masks)])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.a3d_timing_enable(0)
+    recs = collect_timing(lib) if timed_kernels else []
+    if world > 1:
+        t = torch.tensor([dt], device=img.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, recs
+
+
+def roofline_from(recs):
+    groups = {}
+    for r in recs:
+        g = groups.setdefault(kernel_name(r), {'ms': 0.0, 'flops': 0.0, 'calls': 0})
+        g['ms'] += r.ms
+        g['flops'] += r.flops
+        g['calls'] += 1
+    if not groups:
+        return None, {}
+    name, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
+    achieved = g['flops'] / (g['ms'] * 1e-3) / 1e12
+    table = {k: {'calls': v['calls'], 'avg_us': round(1e3 * v['ms'] / v['calls'], 2),
+                 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
+    roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'calls': g['calls'], 'avg_launch_us': round(1e3 * g['ms'] / g['calls'], 2),
+            'flops_per_launch': g['flops'] / g['calls']}
+    return roof, table
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (numpy + OpenBLAS, 'port') on this box's host cores: coarse-phase train steps at B=8 on the same
+    synthetic data shape; bounded to ~seconds_budget of CPU work."""
+    from oracle import msdn as O
+    B = 8
+    rng = np.random.default_rng(1000)
+    img = (rng.integers(0, 256, (B, 480, 640, 3)) / 255).astype(np.float32)
+    dep = (rng.integers(0, 256, (B, 480, 640, 1)) / 255).astype(np.float32)
+    keep = rng.random((B, 4096)) >= 0.5
+    tr = O.Trainer(O.init_params(3000), B)
+    t0 = time.perf_counter()
+    tr.step(img, dep, keep)                       # warm-up (BLAS threads, page faults)
+    first = time.perf_counter() - t0
+    n = max(1, min(8, int(seconds_budget / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(img, dep, keep)
+    dt = time.perf_counter() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'{n} coarse-phase train steps at batch {B} (480x640 stored -> 228x304 net), numpy oracle + '
+                      f'OpenBLAS threads on all host cores; CPU restatement, not TF-1.3 Eigen'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 2/3: 32)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
+    args = ap.parse_args()
+
+    from ann3depth_amd import _lib, dp, models
+    lib = _lib.load()
+    rank, local_rank, world = dp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run',
+                  file=sys.stderr)
+        sys.exit(2)
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    B = args.batch
+    reducer = dp.GradReducer() if world > 1 else None
+    net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer)
+    img, dep = synth_batch(B, rank, device)
+    masks = keep_masks(B, 8, rank, device)
+
+    # headline: coarse-phase train step (what `make train` executes from global_step 0; the heaviest real phase)
+    dt, recs = run_phase(net, img, dep, masks, args.steps, args.warmup, 0, lib, world, timed_kernels=True)
+    value = world * B * args.steps / dt
+    roof, table = roofline_from(recs)
+    extra = {}
+    if not args.no_fine:
+        dtf, _ = run_phase(net, img, dep, masks, args.steps, min(args.warmup, 2), models.SAMPLES_COARSE // B, lib,
+                           world, timed_kernels=False)
+        extra['fine_phase'] = {'value': round(world * B * args.steps / dtf, 1), 'ms_per_step': round(1e3 * dtf / args.steps, 3)}
+    if rank == 0:
+        line = {
+            'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'MSDN coarse+fine, batch 32 per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
+                                   'coarse-phase train step (global_step 0): both forwards + both losses, backward of '
+                                   'coarse/*, 2x ApplyAdam(beta2=1)',
+                       'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': f'dp{world}' + (' (RCCL all-reduce of 283 MB grads/step)' if world > 1 else '')},
+            'roofline': roof,
+            'igemm_kernels': table,
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

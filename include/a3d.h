@@ -1,0 +1,158 @@
+/* a3d.h — C ABI of liba3d.so: the MI355X (gfx950) kernels behind ann3depth's depth-regression training path.
+ *
+ * The reference (shoeffner/ann3depth) has no FFI of its own: its arithmetic is whatever TensorFlow-1.3 ops the
+ * model functions in src/models.py instantiate.  Each entry point below replaces the TF op (or op group) created
+ * by the cited reference call site; the Python host (ann3depth_amd/) is the only caller.
+ *
+ * Conventions
+ *   - Layouts are TensorFlow's: activations NHWC, conv filters HWIO ([R][S][Cin][Cout]), dense kernels [in][out].
+ *   - All tensors are float32 device pointers owned by the caller (PyTorch is only the allocator).  The library
+ *     allocates nothing, keeps no global state, and never synchronises: every call only enqueues work on the
+ *     caller's hipStream_t (passed as void*), so it is stream-ordered and graph-capturable.
+ *   - `ws` is caller-provided scratch of at least the size the matching *_ws_bytes() query returns.
+ *   - Return value: 0 (A3D_OK) or a negative A3D_E* code; a3d_last_error() gives a thread-local message.
+ *     Nothing throws across the ABI and nothing calls exit().
+ */
+#ifndef A3D_H_
+#define A3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3D_OK 0
+#define A3D_EINVAL (-1)   /* bad argument / unsupported shape */
+#define A3D_EWORKSPACE (-2) /* workspace too small */
+#define A3D_ELAUNCH (-3)  /* hipLaunchKernel failed */
+#define A3D_EFORMAT (-4)  /* corrupt TFRecord / Example */
+#define A3D_EIO (-5)
+
+#define A3D_ACT_NONE 0
+#define A3D_ACT_RELU 1
+#define A3D_ACT_SIGMOID 2
+
+/* Geometry of one tf.layers.conv2d call (src/models.py:64-72,211-223,241-251).
+ * pad_t/pad_l are TF's "before" paddings (SAME: pad_total//2; VALID: 0); ho/wo the output extent. */
+typedef struct a3d_conv_desc {
+  int32_t n, h, w, c;        /* input  [n,h,w,c]  */
+  int32_t k, r, s;           /* filter [r,s,c,k]  */
+  int32_t stride;            /* same for both axes; must be 1, 2 or 4 */
+  int32_t pad_t, pad_l;
+  int32_t ho, wo;            /* output [n,ho,wo,k] */
+  int32_t ldx;               /* elements between consecutive input pixels  (>= c; c if dense-packed) */
+  int32_t ldy;               /* elements between consecutive output pixels (>= k) */
+} a3d_conv_desc;
+
+const char* a3d_version(void);
+int a3d_last_error(char* buf, size_t len);
+
+/* Conv2D + BiasAdd (+ Relu)  — tf.layers.conv2d forward.  bias may be NULL. */
+size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                   int act, void* ws, size_t ws_bytes, void* stream);
+
+/* Conv2DBackpropInput.  dz = gradient wrt the pre-activation output [n,ho,wo,k] (pixel stride ldy).
+ * If relu_mask != NULL (same shape/stride as dx) the result is multiplied by (relu_mask > 0): this fuses the
+ * ReluGrad of the PREVIOUS layer, whose output is this layer's input. */
+size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w, float* dx,
+                        const float* relu_mask, void* ws, size_t ws_bytes, void* stream);
+
+/* Conv2DBackpropFilter + BiasAddGrad.  dw [r,s,c,k]; db [k] may be NULL. */
+size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* tf.layers.dense (src/models.py:80-82,228,231): y[m,n] = act(x[m,:] @ w[:,n] + b[n]).
+ * If drop_keep != NULL (uint8 [m,n]) the tf.layers.dropout(rate=.5, training=True) of src/models.py:230 is fused:
+ * y *= 2 * keep. */
+size_t a3d_dense_fwd_ws_bytes(int m, int k, int n);
+int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
+                  const uint8_t* drop_keep, void* ws, size_t ws_bytes, void* stream);
+/* dx[m,k] = dz[m,:] @ w[k,:]^T, optionally * scale * (mask[m,k] > 0)  (mask = the dropped-out activations fuses
+ * dropout-grad and ReluGrad of the layer below). */
+size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n);
+int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
+                       float scale, void* ws, size_t ws_bytes, void* stream);
+/* dw[k,n] = x^T @ dz ; db[n] = sum_m dz  (db may be NULL) */
+size_t a3d_dense_bwd_filter_ws_bytes(int m, int k, int n);
+int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, float* dw, float* db,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* tf.layers.max_pooling2d(x, 2, 2) VALID (src/models.py:65,68,73,213,216,243).
+ * y has pixel stride ldy >= c.  If extra != NULL, y channel c is filled from extra[n,ho,wo] (fuses the
+ * tf.concat([pooled, coarse], -1) of src/models.py:246; requires ldy >= c+1). */
+int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int ldy, const float* extra,
+                       void* stream);
+/* MaxPoolGrad (first maximum in scan order) fused with the ReluGrad of the conv that produced x:
+ * dx = (argmax ? dy : 0) * (x > 0 if relu_mask else 1).  dy has pixel stride lddy. */
+int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* dy, int lddy, float* dx,
+                       int relu_mask, void* stream);
+
+/* tf.image.resize_images = ResizeBilinear(align_corners=False), legacy src = dst*in/out mapping
+ * (src/models.py:180-181,282-283). */
+int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, int ow, float* y, void* stream);
+
+/* tf.extract_image_patches(k x k, stride, SAME) + reshape (src/models.py:53-59): y [n*ph*pw, k, k, c]. */
+int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream);
+
+/* Scale-invariant log loss (src/models.py:255-275).  out/tgt [b, npix]; loss: 1 float. ws: b*2 floats. */
+int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, float* loss, float* ws, void* stream);
+/* d loss / d out, using the per-sample sums left in ws by the forward call. */
+int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,
+                       void* stream);
+
+/* tf.train.AdamOptimizer ApplyAdam (src/models.py:309): alpha = lr*sqrt(1-b2p)/(1-b1p);
+ * m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= m*alpha/(sqrt(v)+eps).  grad_scale multiplies g first
+ * (1/world_size after an all-reduce sum). */
+int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
+                       float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
+                       void* stream);
+
+/* ---- opt-in kernel timing for bench.py's roofline line (the only process-global state in the library) ----
+ * While enabled, every implicit-GEMM launch (conv / dense, any direction) is bracketed by a hipEvent pair recorded
+ * on the launch stream.  a3d_timing_collect() synchronises those events, returns up to `cap` records (oldest first),
+ * and clears the list.  Not for use inside graph capture. */
+typedef struct a3d_timing_record {
+  int32_t mode;        /* 0 fwd, 1 bwd-data, 2 bwd-filter */
+  int32_t bm, bn, waves_m, avec, bvec;   /* template arguments of igemm_kernel<mode,bm,bn,waves_m,avec,bvec> */
+  int32_t splitk;
+  int32_t m, n, k;     /* GEMM extents of the launch */
+  float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */
+  double flops;        /* algorithmic 2*m*n*k */
+} a3d_timing_record;
+int a3d_timing_enable(int on);
+int a3d_timing_collect(a3d_timing_record* out, int cap);
+
+/* ---- host side of the dataset plugin: TFRecord container + tf.train.Example (src/data.py:62-86,
+ *      tools/data_tf_converter.py:27-53) ---- */
+uint32_t a3d_crc32c(const void* data, size_t len);
+uint32_t a3d_masked_crc32c(const void* data, size_t len);
+
+typedef struct a3d_example_view {
+  int64_t image_height, image_width, image_channels;
+  int64_t depth_height, depth_width, depth_channels;
+  const uint8_t* image; size_t image_bytes;   /* point into the record payload */
+  const uint8_t* depth; size_t depth_bytes;
+} a3d_example_view;
+
+/* Frame at buf[0..len): returns payload offset/length; A3D_EFORMAT on CRC mismatch or truncation.
+ * *consumed = bytes of the whole frame. verify_crc=0 skips the payload CRC. */
+int a3d_tfrecord_next(const uint8_t* buf, size_t len, int verify_crc, size_t* payload_off, size_t* payload_len,
+                      size_t* consumed);
+/* Parse the 8-feature Example of tools/data_tf_converter.py:41-51. */
+int a3d_example_parse(const uint8_t* payload, size_t len, a3d_example_view* out);
+/* data._convert_img_depth (src/data.py:82-85): dst[i] = src_le_f32[i] + 0.5 */
+int a3d_decode_raw_plus_half(const uint8_t* src, size_t bytes, float* dst);
+/* Serialise one framed record (writer side).  Returns bytes written, or the needed size if cap is too small
+ * (nothing written then), or a negative error. */
+int64_t a3d_example_write(const float* image, int ih, int iw, int ic, const float* depth, int dh, int dw, int dc,
+                          uint8_t* dst, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A3D_H_ */

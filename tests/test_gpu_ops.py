@@ -1,0 +1,244 @@
+"""Parity of every HIP op (through the C ABI) against the numpy oracle on the same seeded inputs.
+Bit-exact where the kernel mirrors the oracle's fp32 operation order (pool, resize, patches, Adam); rel-L2 <= 1e-5
+against the float64 oracle for fp32-accumulating contractions (conv / dense / loss)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf13_ops as T
+
+pytestmark = pytest.mark.gpu
+
+RTOL_F32 = 1e-5     # fp32 MFMA accumulation vs float64 truth, K up to a few thousand
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ann3depth_amd import ops
+    return ops
+
+
+CONV_CASES = [
+    # n, h, w, c, k, ksize, stride, padding            (edge cases of SURVEY 8c golden plan + every MSDN/DCNF layer kind)
+    (2, 35, 47, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind: Cin=3 scalar gather, N=96 tile
+    (2, 27, 37, 96, 256, 5, 1, 'SAME'),      # conv2d_1 at full spatial size
+    (3, 13, 18, 256, 384, 3, 1, 'SAME'),     # conv2d_2
+    (2, 13, 18, 384, 256, 3, 2, 'VALID'),    # conv2d_4: stride-2 VALID 13x18 -> 6x8
+    (2, 40, 52, 3, 63, 9, 2, 'VALID'),       # fine/first: Cout=63
+    (2, 21, 30, 64, 64, 5, 1, 'SAME'),       # fine/second
+    (2, 21, 30, 64, 1, 5, 1, 'SAME'),        # fine/third: Cout=1
+    (1, 10, 11, 8, 12, 4, 2, 'SAME'),        # asymmetric SAME padding, stride 2
+    (1, 9, 9, 5, 7, 3, 1, 'SAME'),           # Cin, Cout not multiples of 4
+    (5, 24, 24, 64, 256, 5, 1, 'VALID'),     # dcnf conv2d_1 kind
+    (1, 1, 1, 16, 8, 1, 1, 'VALID'),         # degenerate 1x1
+]
+
+
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', CONV_CASES)
+def test_conv2d_fwd_bwd(ops, n, h, w, c, k, ks, st, pad):
+    rng = np.random.default_rng(100 + h * w + c + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    b = rng.standard_normal(k).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    x64, w64, b64 = x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)
+    y_ref = T.conv2d_fwd(x64, w64, b64, st, pad, relu=False)
+    assert (d.ho, d.wo) == y_ref.shape[1:3]
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda')
+    ops.conv2d_fwd(d, xd, wd, bd, y, None)
+    assert rel_l2(y.cpu().numpy(), y_ref) < RTOL_F32
+    ops.conv2d_fwd(d, xd, wd, bd, y, 'relu')
+    yr = y.cpu().numpy()
+    assert rel_l2(yr, np.maximum(y_ref, 0)) < RTOL_F32
+    ops.conv2d_fwd(d, xd, wd, None, y, None)
+    assert rel_l2(y.cpu().numpy(), y_ref - b64) < RTOL_F32
+
+    dz = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dw_ref, db_ref = T.conv2d_bwd_filter(x64, dz.astype(np.float64), wt.shape, st, pad)
+    dx_ref = T.conv2d_bwd_data(dz.astype(np.float64), w64, x.shape, st, pad)
+    dzd = dev(dz)
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    ops.conv2d_bwd_filter(d, xd, dzd, dw, db)
+    assert rel_l2(dw.cpu().numpy(), dw_ref) < RTOL_F32
+    assert rel_l2(db.cpu().numpy(), db_ref) < RTOL_F32
+    dx = torch.full_like(xd, float('nan'))
+    ops.conv2d_bwd_data(d, dzd, wd, dx)
+    assert rel_l2(dx.cpu().numpy(), dx_ref) < RTOL_F32
+    # fused ReluGrad of the previous layer: mask = this layer's input
+    ops.conv2d_bwd_data(d, dzd, wd, dx, relu_mask=xd)
+    assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < RTOL_F32
+
+
+def test_conv2d_strided_pixels(ops):
+    """ldx / ldy pixel strides: the fine/second layer reads the 64-channel concat buffer and bwd-data writes it."""
+    rng = np.random.default_rng(5)
+    n, h, w, c, k = 2, 11, 14, 8, 12
+    xbuf = rng.standard_normal((n, h, w, 16)).astype(np.float32)
+    wt = rng.standard_normal((3, 3, c, k)).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, 3, 3, 1, 'SAME', ldx=16, ldy=20)
+    ybuf = torch.full((n, h, w, 20), 7.0, device='cuda')
+    ops.conv2d_fwd(d, dev(xbuf), dev(wt), None, ybuf, None)
+    y_ref = T.conv2d_fwd(xbuf[..., :c].astype(np.float64), wt.astype(np.float64), None, 1, 'SAME')
+    got = ybuf.cpu().numpy()
+    assert rel_l2(got[..., :k], y_ref) < RTOL_F32
+    assert (got[..., k:] == 7.0).all()
+
+
+DENSE_CASES = [(32, 12288, 4096), (4, 512, 4070), (32, 4096, 4070), (7, 130, 66), (48, 12544, 128), (48, 128, 16),
+               (48, 16, 1)]
+
+
+@pytest.mark.parametrize('m,k,n', DENSE_CASES)
+def test_dense_fwd_bwd(ops, m, k, n):
+    rng = np.random.default_rng(m + k + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    keep = rng.random((m, n)) >= 0.5
+    x64, w64, b64 = x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty((m, n), device='cuda')
+    ops.dense_fwd(xd, wd, bd, y, 'relu')
+    y_ref = T.dense_fwd(x64, w64, b64, 'relu')
+    assert rel_l2(y.cpu().numpy(), y_ref) < RTOL_F32
+    ops.dense_fwd(xd, wd, bd, y, 'relu', drop_keep=dev(keep, torch.uint8))
+    assert rel_l2(y.cpu().numpy(), T.dropout_fwd(y_ref, keep)) < RTOL_F32
+    ops.dense_fwd(xd, wd, bd, y, 'sigmoid')
+    assert rel_l2(y.cpu().numpy(), T.dense_fwd(x64, w64, b64, 'sigmoid')) < RTOL_F32
+    dz = rng.standard_normal((m, n)).astype(np.float32)
+    dx_ref, dw_ref, db_ref = T.dense_bwd(x64, w64, dz.astype(np.float64))
+    dzd = dev(dz)
+    dx = torch.empty_like(xd)
+    ops.dense_bwd_data(dzd, wd, dx)
+    assert rel_l2(dx.cpu().numpy(), dx_ref) < RTOL_F32
+    ops.dense_bwd_data(dzd, wd, dx, mask=xd, scale=2.0)
+    assert rel_l2(dx.cpu().numpy(), 2 * dx_ref * (x > 0)) < RTOL_F32
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    ops.dense_bwd_filter(xd, dzd, dw, db)
+    assert rel_l2(dw.cpu().numpy(), dw_ref) < RTOL_F32
+    assert rel_l2(db.cpu().numpy(), db_ref) < RTOL_F32
+
+
+@pytest.mark.parametrize('n,h,w,c', [(2, 55, 74, 96), (2, 27, 37, 256), (1, 110, 148, 63), (3, 4, 5, 3), (2, 14, 14, 256)])
+def test_maxpool_fwd_bwd_bitexact(ops, n, h, w, c):
+    rng = np.random.default_rng(h * w + c)
+    x = np.maximum(rng.standard_normal((n, h, w, c)), 0).astype(np.float32)      # post-ReLU: many exact ties at 0
+    xd = dev(x)
+    y = torch.empty((n, h // 2, w // 2, c), device='cuda')
+    ops.maxpool2x2_fwd(xd, y)
+    y_ref = T.maxpool2x2_fwd(x)
+    np.testing.assert_array_equal(y.cpu().numpy(), y_ref)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx = torch.full_like(xd, float('nan'))
+    ops.maxpool2x2_bwd(xd, dev(dy), dx, relu_mask=False)
+    np.testing.assert_array_equal(dx.cpu().numpy(), T.maxpool2x2_bwd(x, dy))
+    ops.maxpool2x2_bwd(xd, dev(dy), dx, relu_mask=True)
+    np.testing.assert_array_equal(dx.cpu().numpy(), T.relu_grad(T.maxpool2x2_bwd(x, dy), x))
+
+
+def test_maxpool_concat_and_strided_grad(ops):
+    """fine/first pool writes channels 0..62 of the 64-channel buffer, coarse goes to channel 63 (src/models.py:246);
+    the gradient reads the first 63 channels of a 64-channel pixel stride."""
+    rng = np.random.default_rng(9)
+    x = np.maximum(rng.standard_normal((2, 22, 30, 63)), 0).astype(np.float32)
+    coarse = rng.standard_normal((2, 11, 15, 1)).astype(np.float32)
+    cat = torch.empty((2, 11, 15, 64), device='cuda')
+    ops.maxpool2x2_fwd(dev(x), cat, extra=dev(coarse))
+    ref = np.concatenate([T.maxpool2x2_fwd(x), coarse], axis=-1)
+    np.testing.assert_array_equal(cat.cpu().numpy(), ref)
+    dcat = rng.standard_normal((2, 11, 15, 64)).astype(np.float32)
+    dx = torch.empty((2, 22, 30, 63), device='cuda')
+    ops.maxpool2x2_bwd(dev(x), dev(dcat), dx, relu_mask=True)
+    np.testing.assert_array_equal(dx.cpu().numpy(), T.relu_grad(T.maxpool2x2_bwd(x, dcat[..., :63]), x))
+
+
+@pytest.mark.parametrize('n,h,w,c,oh,ow', [(2, 480, 640, 3, 228, 304), (2, 480, 640, 1, 55, 74), (1, 48, 64, 3, 228, 304),
+                                           (1, 6, 8, 1, 55, 74), (2, 480, 640, 3, 240, 320), (1, 7, 5, 2, 7, 5)])
+def test_resize_bitexact(ops, n, h, w, c, oh, ow):
+    rng = np.random.default_rng(h + w + oh)
+    x = (rng.integers(0, 256, (n, h, w, c)) / 255).astype(np.float32)
+    y = torch.empty((n, oh, ow, c), device='cuda')
+    ops.resize_bilinear_tf1(dev(x), y)
+    np.testing.assert_array_equal(y.cpu().numpy(), T.resize_bilinear_tf1(x, oh, ow))
+
+
+def test_extract_patches_bitexact(ops):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 240, 320, 3)).astype(np.float32)
+    ref = T.extract_patches(x, 100, 40, 'SAME')
+    y = torch.empty((2 * 48, 100, 100, 3), device='cuda')
+    ops.extract_patches(dev(x), 100, 40, y)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref.reshape(96, 100, 100, 3))
+
+
+def test_silog_loss(ops):
+    rng = np.random.default_rng(11)
+    b, npix = 32, 4070
+    o = (rng.standard_normal((b, npix)) * 0.05).astype(np.float32)          # about half negative -> NaN-masked logs
+    t = (rng.integers(0, 256, (b, npix)) / 255).astype(np.float32)          # contains exact zeros
+    o[0, 0] = -1e-8                                                          # log(0) = -inf stays: non-finite loss
+    od, td = dev(o), dev(t)
+    loss = torch.empty(1, device='cuda')
+    ws = torch.empty(2 * b, device='cuda')
+    dout = torch.empty_like(od)
+    ops.silog_loss_fwd(od, td, loss, ws)
+    assert not np.isfinite(loss.item())
+    with np.errstate(invalid='ignore', divide='ignore'):
+        assert not np.isfinite(T.silog_loss_fwd(o, t))
+    o[0, 0] = 0.3
+    od = dev(o)
+    ops.silog_loss_fwd(od, td, loss, ws)
+    ref = T.silog_loss_fwd(o.astype(np.float64), t.astype(np.float64))
+    assert abs(loss.item() - ref) < 2e-6 * abs(ref)
+    ops.silog_loss_bwd(od, td, ws, dout)
+    g_ref = T.silog_loss_bwd(o.astype(np.float64), t.astype(np.float64))
+    g = dout.cpu().numpy()
+    assert rel_l2(g, g_ref) < 1e-5
+    assert (g[o < -1e-8] == 0).all()
+
+
+@pytest.mark.parametrize('beta2', [1.0, 0.999])
+def test_adam_bitexact(ops, beta2):
+    rng = np.random.default_rng(17)
+    count = 4 * 1000 + 3          # vector body + scalar tail
+    var = rng.standard_normal(count).astype(np.float32)
+    opt = T.AdamTF1(0.1, 0.9, beta2)
+    vd = dev(var)
+    md = torch.zeros_like(vd)
+    sd = torch.zeros_like(vd)
+    ref = {'w': var.copy()}
+    b1p, b2p = np.float32(0.9), np.float32(beta2)
+    for step in range(3):
+        g = rng.standard_normal(count).astype(np.float32)
+        opt.apply(ref, {'w': g})
+        ops.adam_apply_tf1(vd, md, sd, dev(g), 0.1, 0.9, beta2, 1e-8, float(b1p), float(b2p))
+        b1p, b2p = b1p * np.float32(0.9), b2p * np.float32(beta2)
+        np.testing.assert_array_equal(md.cpu().numpy(), opt.m['w'])
+        np.testing.assert_array_equal(sd.cpu().numpy(), opt.v['w'])
+        np.testing.assert_array_equal(vd.cpu().numpy(), ref['w'])
+    if beta2 == 1.0:
+        np.testing.assert_array_equal(ref['w'], var)       # the reference's optimizer never moves the weights
+
+
+def test_bad_arguments_fail_loudly(ops):
+    from ann3depth_amd._lib import A3dError
+    x = torch.zeros((1, 8, 8, 4), device='cuda')
+    w = torch.zeros((3, 3, 4, 4), device='cuda')
+    y = torch.zeros((1, 8, 8, 4), device='cuda')
+    d = ops.conv_desc(1, 8, 8, 4, 4, 3, 3, 1, 'SAME')
+    d.stride = 3
+    with pytest.raises(A3dError, match='stride'):
+        ops.conv2d_fwd(d, x, w, None, y)
