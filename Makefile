@@ -1,0 +1,60 @@
+# Drop-in for the training part of the reference Makefile (variables and `train` target of
+# /root/reference/Makefile:36-59,83-85).  `make build` compiles the gfx950 kernels first.
+
+DATA_DIR ?= ./data
+
+ifdef CLUSTER_SPEC
+	CLUSTER_PARAM1 = --cluster-spec=${CLUSTER_SPEC}
+else
+	CLUSTER_PARAM1 :=
+endif
+ifdef JOB_TYPE
+	CLUSTER_PARAM2 = --job-name=${JOB_TYPE}
+else
+	CLUSTER_PARAM2 :=
+endif
+ifdef TASK_INDEX
+	CLUSTER_PARAM3 = --task-index=${TASK_INDEX}
+else
+	CLUSTER_PARAM3 :=
+endif
+CLUSTER_PARAMS ?= ${CLUSTER_PARAM1} ${CLUSTER_PARAM2} ${CLUSTER_PARAM3}
+
+# Default training parameters
+MODEL ?= msdn
+RUNID ?= ''
+STEPS ?= 10000000
+BATCHSIZE ?= 32
+DATASET ?= nyu
+SUM_FREQ ?= 100
+CKPT_FREQ ?= 900
+CKPT_DIR ?= checkpoints
+TIMEOUT ?= 4200
+# data-parallel replicas on this node (replaces PS_NODES / WORKERS of `make distributed`)
+GPUS ?= 1
+
+SCRIPT_PARAMETERS := --ckptdir=${CKPT_DIR} --datadir=${DATA_DIR} --model=${MODEL} --id=${RUNID} \
+					 --steps=${STEPS} --batchsize=${BATCHSIZE} --ckptfreq=${CKPT_FREQ} \
+					 --sumfreq=${SUM_FREQ} --timeout=${TIMEOUT} ${CLUSTER_PARAMS}
+
+ifeq (${GPUS},1)
+SCRIPT := python3 -O -m ann3depth_amd.ann3depth
+else
+SCRIPT := python3 -O -m torch.distributed.run --nnodes=1 --nproc-per-node ${GPUS} --master-addr 127.0.0.1 \
+		  -m ann3depth_amd.ann3depth
+endif
+
+.PHONY: train
+train: ${DATA_DIR}
+	${SCRIPT} ${SCRIPT_PARAMETERS} ${DATASET}
+
+.PHONY: help
+help:
+	${SCRIPT} --help
+
+.PHONY: build
+build:
+	$(MAKE) -C ann3depth_amd/csrc
+
+${DATA_DIR}:
+	mkdir -p ${DATA_DIR}

@@ -45,7 +45,7 @@ SIGNATURES = {
     'a3d_dense_fwd_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'a3d_dense_fwd': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     'a3d_dense_bwd_data_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
-    'a3d_dense_bwd_data': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    'a3d_dense_bwd_data': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, c_size_t, _P]),
     'a3d_dense_bwd_filter_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'a3d_dense_bwd_filter': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     'a3d_maxpool2x2_fwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
@@ -54,6 +54,7 @@ SIGNATURES = {
     'a3d_extract_patches': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     'a3d_silog_loss_fwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),
     'a3d_silog_loss_bwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),
+    'a3d_dropout_keep_mask': (c_int, [c_size_t, ctypes.c_uint64, ctypes.c_uint64, c_float, _P, _P]),
     'a3d_adam_apply_tf1': (c_int, [c_size_t, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                    c_float, _P]),
     'a3d_timing_enable': (c_int, [c_int]),

@@ -1,0 +1,231 @@
+"""Driver — the surface of the reference's ``src/ann3depth.py``: same flags (src/ann3depth.py:221-254), same
+checkpoint directory convention, same stop conditions, same exit code, same one-line hot loop
+``while not should_stop: run(train_op)`` (src/ann3depth.py:126-127).
+
+TensorFlow's session machinery is not reproduced: `Session` below is the minimal stand-in for
+`MonitoredTrainingSession` + the reference's hooks (StopAtStepHook, StopAtSignalHook, summary saver,
+checkpoint saver/restorer, TraceHook).  The parameter-server path (`--job-name ps`, src/ann3depth.py:62-67) is
+replaced by synchronous RCCL data parallelism: launch one process per GPU with
+``python -m torch.distributed.run --nproc-per-node N -m ann3depth_amd.ann3depth ...``; the old cluster flags are
+accepted and ignored.
+"""
+import argparse
+import json
+import logging
+import logging.config
+import os
+import signal
+import sys
+import time
+
+import torch
+
+from . import data, dp, models
+
+
+def main(argv=None):
+    ini = 'logging.ini' if os.path.exists('logging.ini') else os.path.join(os.path.dirname(__file__), 'logging.ini')
+    logging.config.fileConfig(ini, disable_existing_loggers=False)
+    logger = logging.getLogger('ann3depth')
+
+    args = parse_args(argv)
+    logger.debug(args)
+    logger.info(f'This is a {args.job_name} with index {args.task_index}')
+    if args.cluster_spec:
+        logger.info(f'Ignoring cluster spec {args.cluster_spec}: replicas are RCCL ranks, not TF servers.')
+    else:
+        logger.info('Using default local cluster spec.')
+
+    if args.job_name == 'ps':
+        logger.info('Parameter servers do not exist in this build (gradients are all-reduced over xGMI).')
+        return 0
+    if args.job_name not in ('worker', 'local'):
+        logger.warning(f'No suitable job description found! {args.job_name}')
+        return 0
+
+    rank, local_rank, world = dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError('ann3depth_amd needs an MI355X: the training path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    chief = rank == 0
+    logger.info(f'Task: {rank} of {world} -- Chief? {chief}')
+
+    run_id = args.model + ('' if not args.id else f'_{args.id}')
+    ckptdir = str(os.path.join(args.ckptdir, run_id))                    # src/ann3depth.py:73-75
+    logger.info(f'Checkpoint dir is {ckptdir}.')
+
+    logger.info(f'Loading model {args.model}.')
+    model_op = setup_model(args, rank, world)
+
+    size_train = sum(g.count for g in model_op.replica.groups.values()) * 4 / 1024 / 1024
+    logger.debug(f'Trainable variables have about {size_train:.1f} MB')
+
+    logger.info('Setting up hooks.')
+    stop_at_signal = StopAtSignal()
+    if args.job_name != 'local':
+        logger.info(f'Starting alarm: {args.timeout} s timeout.')
+        signal.alarm(args.timeout)                                       # src/ann3depth.py:108-110
+
+    logger.info('Starting session.')
+    with Session(model_op, ckptdir if chief else None, last_step=args.steps, stop_at_signal=stop_at_signal,
+                 save_checkpoint_secs=args.ckptfreq, save_summaries_steps=args.sumfreq,
+                 trace_every=args.trace_every, logger=logger, world=world) as session:
+        while not session.should_stop():
+            session.run(model_op)
+    logger.info('Session stopped.')
+    return stop_at_signal.signal_received                                # src/ann3depth.py:129
+
+
+def setup_model(args, rank=0, world=1):
+    """src/ann3depth.py:134-145."""
+    model = getattr(models, args.model)
+    if world > 1:
+        model.reducer = dp.GradReducer()
+    if args.beta2 is not None:
+        model.beta2 = args.beta2
+    inputs, targets = data.inputs(args.datadir, args.dataset, args.batchsize, rank=rank, world=world,
+                                  seed=args.seed + rank)
+    return model(inputs, targets)
+
+
+class StopAtSignal:
+    """tfhelper.StopAtSignalHook (src/tfhelper.py:160-189): remember the signal, stop after the current step."""
+
+    def __init__(self, signals=None):
+        self.signal_received = 0
+        if signals is None:
+            signals = [signal.SIGUSR1, signal.SIGUSR2, signal.SIGALRM, signal.SIGINT, signal.SIGTERM]
+        for s in signals:
+            signal.signal(s, self._handler)
+
+    def _handler(self, signum, frame):
+        self.signal_received = signum
+
+
+class Session:
+    """Stand-in for tf.train.MonitoredTrainingSession as the reference configures it (src/ann3depth.py:113-125):
+    restore the newest checkpoint of `checkpoint_dir`, save every `save_checkpoint_secs` and on exit, write loss
+    scalars every `save_summaries_steps` steps, log steps/sec, stop at `last_step`, on a signal, or when the input
+    pipeline runs dry."""
+
+    def __init__(self, train_op, checkpoint_dir, last_step, stop_at_signal, save_checkpoint_secs, save_summaries_steps,
+                 trace_every, logger, world=1):
+        self.op, self.dir, self.last_step, self.sig = train_op, checkpoint_dir, last_step, stop_at_signal
+        self.ckpt_secs, self.sum_steps, self.trace_every = save_checkpoint_secs, save_summaries_steps, trace_every
+        self.log, self.world = logger, world
+        self.stop = False
+        self.t_last_ckpt = time.time()
+        self.t_last_sum, self.step_last_sum = time.time(), None
+        self.summaries = None
+
+    def __enter__(self):
+        rep = self.op.replica
+        latest = latest_checkpoint(self.dir) if self.dir else None
+        if latest:
+            self.log.info(f'Restoring {latest}')
+            rep.load_state_dict(torch.load(latest, map_location=rep.device))
+        if self.world > 1:                                    # non-chief replicas take the chief's state
+            import torch.distributed as dist
+            for g in rep.groups.values():
+                for buf in (g.var, g.m, g.v):
+                    dist.broadcast(buf, 0)
+            st = torch.tensor([rep.global_step] + [float(x) for g in rep.groups.values()
+                                                    for x in (g.beta1_power, g.beta2_power)],
+                              dtype=torch.float64, device=rep.device)
+            dist.broadcast(st, 0)
+            rep.global_step = int(st[0].item())
+        if self.dir:
+            os.makedirs(self.dir, exist_ok=True)
+            self.summaries = open(os.path.join(self.dir, 'summaries.jsonl'), 'a')
+        self.step_last_sum = rep.global_step
+        return self
+
+    def should_stop(self):
+        return self.stop or self.op.replica.global_step >= self.last_step
+
+    def run(self, train_op):
+        rep = train_op.replica
+        try:
+            out = train_op.run()
+        except data.OutOfRangeError as e:
+            self.log.info(f'Input pipeline exhausted: {e}')
+            self.stop = True
+            return None
+        step = rep.global_step
+        if self.sig.signal_received:                                     # StopAtSignalHook.after_run
+            self.stop = True
+        if self.sum_steps and step % self.sum_steps == 0:
+            now = time.time()
+            rate = (step - self.step_last_sum) / max(now - self.t_last_sum, 1e-9)
+            rec = {'global_step': step, 'coarse/coarse_loss': float(out['coarse_loss']),
+                   'fine/fine_loss': float(out['fine_loss']), 'Phase': out['phase'],
+                   'global_step/sec': rate, 'images/sec': rate * rep.B * self.world}
+            self.log.info('global_step/sec: %.4g  %s', rate, json.dumps(rec))
+            if self.summaries:
+                self.summaries.write(json.dumps(rec) + '\n')
+                self.summaries.flush()
+            self.t_last_sum, self.step_last_sum = now, step
+        if self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs:
+            self.save()
+        return out
+
+    def save(self):
+        rep = self.op.replica
+        torch.cuda.synchronize()
+        path = os.path.join(self.dir, f'model.ckpt-{rep.global_step}.pt')
+        tmp = path + '.tmp'
+        torch.save({k: v.detach().cpu() for k, v in rep.state_dict().items()}, tmp)
+        os.replace(tmp, path)
+        with open(os.path.join(self.dir, 'checkpoint'), 'w') as f:
+            f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
+        self.t_last_ckpt = time.time()
+        self.log.info(f'Saved checkpoint {path}')
+
+    def __exit__(self, exc_type, exc, tb):
+        self.op.pipeline.close()
+        if self.dir and exc_type is None:
+            self.save()                                                  # session close saves a final checkpoint
+        if self.summaries:
+            self.summaries.close()
+        return False
+
+
+def latest_checkpoint(ckptdir):
+    index = os.path.join(ckptdir, 'checkpoint')
+    if not os.path.exists(index):
+        return None
+    with open(index) as f:
+        line = f.readline()
+    name = line.split('"')[1] if '"' in line else ''
+    path = os.path.join(ckptdir, name)
+    return path if name and os.path.exists(path) else None
+
+
+def parse_args(argv=None):
+    """The reference's flags verbatim (src/ann3depth.py:221-254), plus --beta2 / --seed / --trace-every."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument('dataset', default='nyu', type=str, help='The dataset to use.')
+    parser.add_argument('--model', '-m', default='', type=str, help='Enter a model name.')
+    parser.add_argument('--steps', '-s', default=1000000, type=int, help='Total steps')
+    parser.add_argument('--batchsize', '-b', default=32, type=int, help='Batchsize')
+    parser.add_argument('--ckptdir', '-p', default='checkpoints', help='Checkpoint directory')
+    parser.add_argument('--id', default='', type=str, help='Checkpoint path suffix.')
+    parser.add_argument('--ckptfreq', '-f', default=900, type=int, help='Create a checkpoint every N seconds.')
+    parser.add_argument('--sumfreq', '-r', default=100, type=int, help='Create a summary every N steps.')
+    parser.add_argument('--datadir', '-d', default='data', type=str,
+                        help='The data directory containing the datasets.')
+    parser.add_argument('--timeout', '-k', default=4200, type=int, help='The time after which the process dies.')
+    parser.add_argument('--cluster-spec', default='', type=str,
+                        help='(ignored) The path to the cluster specification json.')
+    parser.add_argument('--job-name', default='local', type=str, help='"worker" or "local"; "ps" exits at once.')
+    parser.add_argument('--task-index', default=0, type=int, help='(ignored) rank comes from the launcher.')
+    parser.add_argument('--beta2', default=None, type=float,
+                        help='NON-REFERENCE: Adam beta2 (the reference hard-codes 1, which freezes the weights).')
+    parser.add_argument('--seed', default=0, type=int, help='Shuffle-queue seed.')
+    parser.add_argument('--trace-every', default=5000, type=int,
+                        help='TraceHook period (src/ann3depth.py:105); traces are taken with rocprofv3 externally.')
+    return parser.parse_args(argv)
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -15,6 +15,10 @@ int set_error(int code, const char* fmt, ...);
     if (!(cond)) return ::a3d::set_error(A3D_EINVAL, __VA_ARGS__); \
   } while (0)
 
+// hipGetLastError() is sticky across unrelated runtime calls made by the process (PyTorch probes devices, etc.):
+// clear it before launching so check_launch() reports only this launch.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(A3D_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -53,6 +53,7 @@ struct IgemmParams {
   const float* mask;    // [M, ldc] or null        (BWD_D epilogue: *= mask>0)
   const uint8_t* keep;  // [M, N] or null          (FWD epilogue: *= keep*mask_scale)
   float mask_scale;
+  int mask_act;         // EPI_RELU: *= (mask > 0);  EPI_SIGMOID: *= mask * (1 - mask)
   int M, N, K;
   // geometry of the im2col operand
   int npix;             // number of pixels on the pixel axis (FWD/BWD_D: M, BWD_F: K)
@@ -114,6 +115,11 @@ __device__ __forceinline__ int4 make_pix(const IgemmParams& p, int pixel) {
   }
   e.w = valid ? 1 : 0;
   return e;
+}
+
+__device__ __forceinline__ float apply_act_grad(float g, float y, int act, float scale) {
+  if (act == EPI_SIGMOID) return g * scale * (y * (1.f - y));
+  return y > 0.f ? g * scale : 0.f;
 }
 
 struct ColDec {
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
             if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
           } else if (MODE == MODE_BWD_D) {
-            if (p.mask) val = p.mask[o] > 0.f ? val * p.mask_scale : 0.f;
+            if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
           }
         }
         Cout[o] = val;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 // split-K slab reduction + the same epilogue
 struct ReduceParams {
   const float* ws; float* C; const float* bias; const float* mask; const uint8_t* keep; float mask_scale;
-  int M, N, ldc, splitk, act, mode; size_t slab;
+  int M, N, ldc, splitk, act, mode, mask_act; size_t slab;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
 

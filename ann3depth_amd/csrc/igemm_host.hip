@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
       else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
       if (p.keep) s = p.keep[i] ? s * p.mask_scale : 0.f;
     } else if (p.mode == MODE_BWD_D) {
-      if (p.mask) s = p.mask[o] > 0.f ? s * p.mask_scale : 0.f;
+      if (p.mask) s = apply_act_grad(s, p.mask[o], p.mask_act, p.mask_scale);
     }
     p.C[o] = s;
   }
@@ -129,9 +129,10 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     ReduceParams r;
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
-    r.mode = mode; r.slab = p.slab;
+    r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act;
     size_t total = (size_t)p.M * p.N;
     unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 2048);
+    clear_stale_error();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
     rc = check_launch("splitk_reduce");
   }
@@ -166,11 +167,13 @@ int launch_colsum(const float* x, int rows, int n, int ld, float* out, void* ws,
   int rps = (rows + splits - 1) / splits;
   splits = (rows + rps - 1) / rps;
   float* part = static_cast<float*>(ws);
+  clear_stale_error();
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, splits), dim3(256), 0, st, x, rows, n, ld, part, rps);
   int rc = check_launch("colsum_partial");
   if (rc != A3D_OK) return rc;
   ReduceParams r{};
   r.ws = part; r.C = out; r.M = 1; r.N = n; r.ldc = n; r.splitk = splits; r.mode = MODE_BWD_F; r.slab = (size_t)n;
+  clear_stale_error();
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, r);
   return check_launch("colsum_reduce");
 }
@@ -233,6 +236,7 @@ static void fill_common(IgemmParams& p, const GemmProblem& g) {
   p = IgemmParams{};
   p.M = g.M; p.N = g.N; p.K = g.K;
   p.mask_scale = 1.f;
+  p.mask_act = EPI_RELU;
 }
 
 }  // namespace a3d
@@ -398,8 +402,9 @@ size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n) {
 }
 
 int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
-                       float scale, void* ws, size_t ws_bytes, void* stream) {
+                       int mask_act, float scale, void* ws, size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_data: bad dims");
+  A3D_CHECK_ARG(!mask || mask_act == A3D_ACT_RELU || mask_act == A3D_ACT_SIGMOID, "dense_bwd_data: bad mask_act");
   a3d_conv_desc d = dense_desc(m, k, n);
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
@@ -411,7 +416,7 @@ int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, flo
   if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: need %zu workspace bytes", plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
-  p.A = dz; p.B = w; p.C = dx; p.mask = mask; p.mask_scale = scale;
+  p.A = dz; p.B = w; p.C = dx; p.mask = mask; p.mask_scale = scale; p.mask_act = mask_act;
   p.npix = m; p.nrsc = n; p.H = 1; p.W = 1; p.ld = n; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1;
   p.Cg = n; p.Cn = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(n); p.div_s = make_fastdiv(1);

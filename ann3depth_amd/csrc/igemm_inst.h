@@ -19,6 +19,7 @@ static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
     if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
+  clear_stale_error();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, p);
   return check_launch("igemm");
 }

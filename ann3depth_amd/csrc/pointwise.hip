@@ -230,6 +230,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
   }
 }
 
+// ------------------------------------------------------------------ dropout keep mask (Philox4x32-10)
+// TF draws U[0,1) from its own Philox stream, which is not reproducible outside TF; this is the same generator
+// family keyed by (seed, step), one counter per 4 mask bytes.  keep = floor(keep_prob + u)  (nn.dropout, TF 1.3).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+  c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ keep, size_t count, uint32_t seed_lo,
+                                                           uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi,
+                                                           float keep_prob) {
+  const size_t nquad = (count + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (size_t)gridDim.x * 256) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), step_lo, step_hi};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t i = q * 4 + j;
+      if (i < count) {
+        const float u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);      // 24 random bits -> [0,1)
+        keep[i] = (uint8_t)floorf(keep_prob + u);
+      }
+    }
+  }
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -242,6 +276,7 @@ int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int
   A3D_CHECK_ARG(ldy >= c + (extra ? 1 : 0), "maxpool_fwd: ldy %d too small", ldy);
   const int ho = h / 2, wo = w / 2;
   const size_t total = (size_t)n * ho * wo * (c + (extra ? 1 : 0));
+  clear_stale_error();
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y,
                      extra, n, h, w, c, ho, wo, ldy);
   return check_launch("maxpool_fwd");
@@ -251,6 +286,7 @@ int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* 
                        int relu_mask, void* stream) {
   A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && x && dy && dx && lddy >= c, "maxpool_bwd: bad arguments");
   const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  clear_stale_error();
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy,
                      dx, n, h, w, c, h / 2, w / 2, lddy, relu_mask);
   return check_launch("maxpool_bwd");
@@ -260,6 +296,7 @@ int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, 
   A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && x && y, "resize: bad arguments");
   const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
   const size_t total = (size_t)n * oh * ow * c;
+  clear_stale_error();
   hipLaunchKernelGGL(resize_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, h,
                      w, c, oh, ow, sy, sx);
   return check_launch("resize");
@@ -270,6 +307,7 @@ int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int s
   const int ph = (h + stride - 1) / stride, pw = (w + stride - 1) / stride;
   const int pad_h = std::max((ph - 1) * stride + k - h, 0), pad_w = std::max((pw - 1) * stride + k - w, 0);
   const size_t total = (size_t)n * ph * pw * k * k * c;
+  clear_stale_error();
   hipLaunchKernelGGL(patches_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, y, n, h, w, c, k, stride, ph, pw, pad_h / 2, pad_w / 2);
   return check_launch("patches");
@@ -280,9 +318,11 @@ static const float kSilogC = (float)(0.5 / (74 * 55));   // src/models.py:269, f
 int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, float* loss, float* ws, void* stream) {
   A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && loss && ws, "silog_fwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  clear_stale_error();
   hipLaunchKernelGGL(silog_sums_kernel, dim3(b), dim3(256), 0, st, out, tgt, ws, npix);
   int rc = check_launch("silog_sums");
   if (rc != A3D_OK) return rc;
+  clear_stale_error();
   hipLaunchKernelGGL(silog_final_kernel, dim3(1), dim3(64), 0, st, ws, loss, b, kSilogC);
   return check_launch("silog_final");
 }
@@ -291,9 +331,19 @@ int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, cons
                        void* stream) {
   A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && ws && dout, "silog_bwd: bad arguments");
   const size_t total = (size_t)b * npix;
+  clear_stale_error();
   hipLaunchKernelGGL(silog_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), out, tgt,
                      ws, dout, b, npix, kSilogC, 1.0f / (float)b);
   return check_launch("silog_bwd");
+}
+
+int a3d_dropout_keep_mask(size_t count, uint64_t seed, uint64_t step, float rate, uint8_t* keep, void* stream) {
+  A3D_CHECK_ARG(count > 0 && keep && rate >= 0.f && rate < 1.f, "dropout_keep_mask: bad arguments");
+  clear_stale_error();
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((count + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), keep, count, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     (uint32_t)step, (uint32_t)(step >> 32), 1.0f - rate);
+  return check_launch("dropout_mask");
 }
 
 int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
@@ -303,6 +353,7 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
   A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
                   reinterpret_cast<uintptr_t>(g)) & 15) == 0, "adam: buffers must be 16-byte aligned");
   const float alpha = lr * sqrtf(1.f - beta2_power) / (1.f - beta1_power);
+  clear_stale_error();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,
                      grad_scale);

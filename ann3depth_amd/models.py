@@ -314,3 +314,189 @@ class MSDNReplica:
             gb.apply(scale)
         self.global_step += 1
         return {'coarse_loss': self.loss_coarse, 'fine_loss': self.loss_fine, 'phase': phase}
+
+
+# =====================================================================================================
+# DCNF unary stack ("DCNF-lite", Liu et al. 2015) — src/models.py:14-18,50-89,179-183
+# =====================================================================================================
+DCNF_IMG_H, DCNF_IMG_W = 240, 320      # src/models.py:180
+DCNF_PATCH, DCNF_SP = 100, 40          # src/models.py:15-16
+DCNF_PREFIX = 'unary/unary_layers/'
+DCNF_CONVS = [('conv2d', 3, 64, 11), ('conv2d_1', 64, 256, 5), ('conv2d_2', 256, 256, 3),
+              ('conv2d_3', 256, 256, 3), ('conv2d_4', 256, 256, 3)]        # all VALID, stride 1, ReLU (:64-72)
+DCNF_POOL_AFTER = ('conv2d', 'conv2d_1', 'conv2d_4')                       # :65,68,73
+DCNF_DENSES = [('dense', 12544, 128, 'relu'), ('dense_1', 128, 16, 'sigmoid'), ('dense_2', 16, 1, None)]  # :80-82
+
+
+class DCNFUnary:
+    """The shared-weight unary conv stack over all patches of a batch at once (the reference maps it over the
+    batch with tf.map_fn, src/models.py:89): images [B,H,W,3] -> z [B,48,1].  backward() takes a synthetic
+    upstream gradient dz (the CRF loss that would produce it is outside the north-star path)."""
+
+    def __init__(self, batchsize, device='cuda', params=None, seed=3000):
+        self.B = batchsize
+        self.device = dev = torch.device(device)
+        self.rows, _ = ops.same_pad(DCNF_IMG_H, DCNF_PATCH, DCNF_SP)
+        self.cols, _ = ops.same_pad(DCNF_IMG_W, DCNF_PATCH, DCNF_SP)
+        self.P = P = batchsize * self.rows * self.cols
+        shapes = collections.OrderedDict()
+        for n, ci, co, k in DCNF_CONVS:
+            shapes[DCNF_PREFIX + n + '/kernel'] = (k, k, ci, co)
+            shapes[DCNF_PREFIX + n + '/bias'] = (co,)
+        for n, i, o, _ in DCNF_DENSES:
+            shapes[DCNF_PREFIX + n + '/kernel'] = (i, o)
+            shapes[DCNF_PREFIX + n + '/bias'] = (o,)
+        self.shapes = shapes
+        self.group = ParamGroup('unary', 0.1, shapes, dev)      # GradientDescentOptimizer(0.1), src/models.py:198
+        if params is None:
+            rng = np.random.default_rng(seed)
+            params = {n: (glorot_uniform(rng, s) if n.endswith('/kernel') else np.zeros(s, np.float32))
+                      for n, s in shapes.items()}
+        for n, s in shapes.items():
+            self.group.view(self.group.var, n).copy_(torch.from_numpy(np.ascontiguousarray(params[n], np.float32)))
+
+        def buf(*shape):
+            return torch.empty(shape, device=dev)
+        self.resized = buf(batchsize, DCNF_IMG_H, DCNF_IMG_W, 3)
+        self.act = collections.OrderedDict()
+        self.dact = {}
+        self.desc = {}
+        self.act['x'] = buf(P, DCNF_PATCH, DCNF_PATCH, 3)
+        h = DCNF_PATCH
+        for n, ci, co, k in DCNF_CONVS:
+            self.desc[n] = ops.conv_desc(P, h, h, ci, co, k, k, 1, 'VALID')
+            h = h - k + 1
+            self.act[n] = buf(P, h, h, co)
+            if n in DCNF_POOL_AFTER:
+                h //= 2
+                self.act[n + '/pool'] = buf(P, h, h, co)
+        for n, i, o, _ in DCNF_DENSES:
+            self.act[n] = buf(P, o)
+        self.z = self.act['dense_2']
+
+    def var(self, name):
+        return self.group.view(self.group.var, DCNF_PREFIX + name)
+
+    def grad(self, name):
+        return self.group.view(self.group.grad, DCNF_PREFIX + name)
+
+    def forward(self, images):
+        ops.resize_bilinear_tf1(images, self.resized)                           # src/models.py:180
+        ops.extract_patches(self.resized, DCNF_PATCH, DCNF_SP, self.act['x'])   # :50-59
+        t = self.act['x']
+        for n, _, _, _ in DCNF_CONVS:
+            ops.conv2d_fwd(self.desc[n], t, self.var(n + '/kernel'), self.var(n + '/bias'), self.act[n], 'relu')
+            t = self.act[n]
+            if n in DCNF_POOL_AFTER:
+                ops.maxpool2x2_fwd(t, self.act[n + '/pool'])
+                t = self.act[n + '/pool']
+        t = t.view(self.P, -1)
+        for n, _, _, act in DCNF_DENSES:
+            ops.dense_fwd(t, self.var(n + '/kernel'), self.var(n + '/bias'), self.act[n], act)
+            t = self.act[n]
+        return self.z.view(self.B, self.rows * self.cols, 1)
+
+    def _dbuf(self, key, like):
+        if key not in self.dact:
+            self.dact[key] = torch.empty_like(like)
+        return self.dact[key]
+
+    def backward(self, dz):
+        """Gradients of sum(z * dz) wrt every unary variable, into the flat gradient buffer."""
+        P = self.P
+        a = self.act
+        flat = a['conv2d_4/pool'].view(P, -1)
+        d2 = dz.reshape(P, 1).contiguous()
+        # dense_2 (linear)
+        ops.dense_bwd_filter(a['dense_1'], d2, self.grad('dense_2/kernel'), self.grad('dense_2/bias'))
+        d1 = self._dbuf('dense_1', a['dense_1'])
+        ops.dense_bwd_data(d2, self.var('dense_2/kernel'), d1, mask=a['dense_1'], mask_act='sigmoid')  # y(1-y) fused
+        ops.dense_bwd_filter(a['dense'], d1, self.grad('dense_1/kernel'), self.grad('dense_1/bias'))
+        d0 = self._dbuf('dense', a['dense'])
+        ops.dense_bwd_data(d1, self.var('dense_1/kernel'), d0, mask=a['dense'], scale=1.0)     # ReluGrad fused
+        ops.dense_bwd_filter(flat, d0, self.grad('dense/kernel'), self.grad('dense/bias'))
+        dflat = self._dbuf('flat', a['conv2d_4/pool'])
+        ops.dense_bwd_data(d0, self.var('dense/kernel'), dflat.view(P, -1))
+        d = dflat
+        inputs = {'conv2d': 'x', 'conv2d_1': 'conv2d/pool', 'conv2d_2': 'conv2d_1/pool', 'conv2d_3': 'conv2d_2',
+                  'conv2d_4': 'conv2d_3'}
+        for n, _, _, _ in reversed(DCNF_CONVS):
+            if n in DCNF_POOL_AFTER:
+                dzc = self._dbuf(n, a[n])
+                ops.maxpool2x2_bwd(a[n], d, dzc, relu_mask=True)
+            else:
+                dzc = d      # the producer (bwd-data of the next conv) already applied this layer's ReluGrad
+            x = a[inputs[n]]
+            ops.conv2d_bwd_filter(self.desc[n], x, dzc, self.grad(n + '/kernel'), self.grad(n + '/bias'))
+            if n != 'conv2d':
+                dx = self._dbuf('in:' + n, x)
+                prev_is_plain_relu = inputs[n] in ('conv2d_2', 'conv2d_3')     # no pool between: fuse its ReluGrad
+                ops.conv2d_bwd_data(self.desc[n], dzc, self.var(n + '/kernel'), dx,
+                                    relu_mask=x if prev_is_plain_relu else None)
+                d = dx
+
+
+# =====================================================================================================
+# plugin surface: models.msdn / models.dcnf  (src/models.py:370-371)
+# =====================================================================================================
+class TrainOp:
+    """What `model(inputs, targets)` returns: run() is one `session.run(train_op)` — dequeue a batch, copy it to
+    HBM, draw the dropout mask, run the replica's step."""
+
+    def __init__(self, replica, pipeline, seed=0):
+        self.replica, self.pipeline, self.seed = replica, pipeline, seed
+        self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=replica.device)
+        self.host = None
+        self.dev = None
+        self.last = None
+
+    def run(self):
+        r = self.replica
+        if self.host is None:
+            img, dep = self.pipeline.next_batch()
+            self.host = (torch.from_numpy(img).pin_memory(), torch.from_numpy(dep).pin_memory())
+            self.dev = (torch.empty(img.shape, device=r.device), torch.empty(dep.shape, device=r.device))
+        else:
+            torch.cuda.current_stream().synchronize()      # previous H2D finished reading the pinned buffers
+            self.pipeline.next_batch(self.host[0].numpy(), self.host[1].numpy())
+        self.dev[0].copy_(self.host[0], non_blocking=True)
+        self.dev[1].copy_(self.host[1], non_blocking=True)
+        ops.dropout_keep_mask(self.keep, self.seed, r.global_step)
+        self.last = r.step(self.dev[0], self.dev[1], self.keep)
+        return self.last
+
+    @property
+    def global_step(self):
+        return self.replica.global_step
+
+
+class _MultiScaleDeepNetwork:
+    """Eigen et al. (2014) coarse+fine network — plugin wrapper around MSDNReplica (src/models.py:203-367)."""
+    beta2 = 1.0          # the reference's AdamOptimizer(rate, momentum, 1): alpha == 0, weights never move
+    reducer = None       # set by the driver when world_size > 1
+    seed = 3000
+
+    def __call__(self, images, depths, train=True):
+        assert images.pipeline is depths.pipeline, 'inputs and targets must come from the same data.inputs() call'
+        self.train = train
+        replica = MSDNReplica(images.pipeline.B, device=torch.device('cuda', torch.cuda.current_device()),
+                              seed=self.seed, beta2=self.beta2, reducer=self.reducer)
+        if self.reducer is not None:                         # replicas start from rank 0's weights
+            for g in replica.groups.values():
+                self.reducer.broadcast(g.var)
+        return TrainOp(replica, images.pipeline, seed=self.seed + 1000 * (self.reducer.rank if self.reducer else 0))
+
+
+class _DistributedConvolutionalNeuralFields:
+    """Liu et al. (2015).  Only the unary conv stack (src/models.py:50-89) is on this build's path; the pairwise
+    part and the CRF negative log-likelihood (src/models.py:91-177) are not implemented, so the plugin cannot be
+    trained with `make train` yet (the reference's own version cannot either: it pins layers to
+    /job:worker/task:{1,2,3}, src/models.py:63-79)."""
+
+    def __call__(self, images, depths, train=True):
+        raise NotImplementedError('dcnf: only the unary stack (models.DCNFUnary) is implemented; the CRF loss of '
+                                  'src/models.py:129-177 is outside this build\'s hot path')
+
+
+dcnf = _DistributedConvolutionalNeuralFields()
+msdn = _MultiScaleDeepNetwork()

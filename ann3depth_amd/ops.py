@@ -21,12 +21,6 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _chk(t, name):
-    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
-        raise ValueError(f'{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} '
-                         f'contiguous={t.is_contiguous()}')
-
-
 class Workspace:
     """Scratch for split-K slabs and partial reductions.  One per device; grows on demand (never inside a graph
     capture: call reserve() with the largest need first)."""
@@ -104,12 +98,14 @@ def dense_fwd(x, w, bias, y, act=None, drop_keep=None):
     return y
 
 
-def dense_bwd_data(dz, w, dx, mask=None, scale=1.0):
+def dense_bwd_data(dz, w, dx, mask=None, scale=1.0, mask_act='relu'):
+    """dx = dz @ w^T, optionally times the activation gradient of the layer below given its output `mask`."""
     m, n = dz.shape
     k = w.shape[0]
     lib = _lib.load()
     ws, nb = _WS.get(lib.a3d_dense_bwd_data_ws_bytes(m, k, n), dz.device)
-    check(lib.a3d_dense_bwd_data(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), scale, ws, nb, _stream()),
+    check(lib.a3d_dense_bwd_data(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), ACT[mask_act], scale, ws, nb,
+                                 _stream()),
           'a3d_dense_bwd_data')
     return dx
 
@@ -173,3 +169,10 @@ def silog_loss_bwd(out, tgt, ws, dout):
 def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale=1.0):
     check(_lib.load().a3d_adam_apply_tf1(var.numel(), _ptr(var), _ptr(m), _ptr(v), _ptr(g), lr, beta1, beta2, eps,
                                          beta1_power, beta2_power, grad_scale, _stream()), 'a3d_adam_apply_tf1')
+
+
+def dropout_keep_mask(keep, seed, step, rate=0.5):
+    """Fill the uint8 tensor `keep` with the Bernoulli(1-rate) keep mask of training step `step`."""
+    check(_lib.load().a3d_dropout_keep_mask(keep.numel(), seed, step, rate, _ptr(keep), _stream()),
+          'a3d_dropout_keep_mask')
+    return keep

@@ -1,0 +1,102 @@
+"""TF-free TFRecord reader/writer for the 8-feature float32 layout ann3depth uses
+(writer side: tools/data_tf_converter.py:27-53; reader side: src/data.py:62-86).
+
+Framing, CRC32C and the protobuf wire format are handled by liba3d.so (csrc/tfrecord.cc); this module only maps
+files and moves numpy buffers.
+"""
+import ctypes
+import mmap
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import ExampleView, check
+
+
+class TFRecordWriter:
+    """Context manager mirroring tf.python_io.TFRecordWriter for (image, depth) pairs."""
+
+    def __init__(self, path):
+        self.path = path
+        self.f = None
+        self.buf = None
+
+    def __enter__(self):
+        os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
+        self.f = open(self.path, 'wb')
+        return self
+
+    def __exit__(self, *exc):
+        self.f.close()
+
+    def write_example(self, image, depth):
+        """image [H,W,C], depth [H,W] or [H,W,1] in STORED form: float32 `png/255 - 0.5`
+        (tools/data_tf_converter.py:36-40)."""
+        lib = _lib.load()
+        image = np.ascontiguousarray(image, dtype='<f4')
+        depth = np.ascontiguousarray(depth, dtype='<f4')
+        if depth.ndim < 3:
+            depth = depth[..., None]
+        need = 16 + image.nbytes + depth.nbytes + 512
+        if self.buf is None or len(self.buf) < need:
+            self.buf = ctypes.create_string_buffer(need)
+        n = lib.a3d_example_write(image.ctypes.data, *image.shape, depth.ctypes.data, *depth.shape, self.buf, need)
+        if n < 0 or n > need:
+            check(int(min(n, -1)), 'a3d_example_write')
+        self.f.write(self.buf.raw[:n] if n < len(self.buf) else self.buf.raw)
+
+
+class RecordFile:
+    """A memory-mapped .tfrecords file; iterating yields (offset, length) of each payload after CRC checks."""
+
+    def __init__(self, path, verify_crc=True):
+        self.path = path
+        self.verify = int(verify_crc)
+        self.f = open(path, 'rb')
+        self.size = os.fstat(self.f.fileno()).st_size
+        self.mm = mmap.mmap(self.f.fileno(), 0, access=mmap.ACCESS_READ) if self.size else None
+        self.base = (ctypes.addressof(ctypes.c_char.from_buffer_copy(b'\0')) if self.mm is None else
+                     np.frombuffer(self.mm, np.uint8).ctypes.data)
+
+    def close(self):
+        if self.mm is not None:
+            self.mm.close()
+        self.f.close()
+
+    def __iter__(self):
+        lib = _lib.load()
+        pos = 0
+        off, ln, used = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        while pos < self.size:
+            check(lib.a3d_tfrecord_next(self.base + pos, self.size - pos, self.verify, ctypes.byref(off),
+                                        ctypes.byref(ln), ctypes.byref(used)), f'a3d_tfrecord_next({self.path}@{pos})')
+            yield pos + off.value, ln.value
+            pos += used.value
+
+    def parse(self, offset, length):
+        """data._convert_img_depth (src/data.py:70-86): -> (image [H,W,C], depth [H,W,C']) float32 with '+ 0.5'.
+        Sizes come from the record's own size features (the reference hard-codes 480x640)."""
+        lib = _lib.load()
+        ev = ExampleView()
+        check(lib.a3d_example_parse(self.base + offset, length, ctypes.byref(ev)), 'a3d_example_parse')
+        ishape = (ev.image_height, ev.image_width, ev.image_channels)
+        dshape = (ev.depth_height, ev.depth_width, ev.depth_channels)
+        if ev.image_bytes != 4 * int(np.prod(ishape)) or ev.depth_bytes != 4 * int(np.prod(dshape)):
+            raise _lib.A3dError(f'{self.path}: feature byte counts do not match the size features '
+                                f'({ev.image_bytes} vs {ishape}, {ev.depth_bytes} vs {dshape})')
+        image = np.empty(ishape, np.float32)
+        depth = np.empty(dshape, np.float32)
+        check(lib.a3d_decode_raw_plus_half(ev.image, ev.image_bytes, image.ctypes.data), 'a3d_decode_raw_plus_half')
+        check(lib.a3d_decode_raw_plus_half(ev.depth, ev.depth_bytes, depth.ctypes.data), 'a3d_decode_raw_plus_half')
+        return image, depth
+
+
+def crc32c(data):
+    data = bytes(data)
+    return _lib.load().a3d_crc32c(data, len(data))
+
+
+def masked_crc32c(data):
+    data = bytes(data)
+    return _lib.load().a3d_masked_crc32c(data, len(data))

@@ -72,11 +72,12 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
 size_t a3d_dense_fwd_ws_bytes(int m, int k, int n);
 int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                   const uint8_t* drop_keep, void* ws, size_t ws_bytes, void* stream);
-/* dx[m,k] = dz[m,:] @ w[k,:]^T, optionally * scale * (mask[m,k] > 0)  (mask = the dropped-out activations fuses
- * dropout-grad and ReluGrad of the layer below). */
+/* dx[m,k] = dz[m,:] @ w[k,:]^T, optionally fused with the activation gradient of the layer below, whose OUTPUT is
+ * `mask` [m,k]:  mask_act = A3D_ACT_RELU: dx *= scale * (mask > 0)  (with mask = the dropped-out activations this is
+ * dropout-grad and ReluGrad in one);  A3D_ACT_SIGMOID: dx *= scale * mask * (1 - mask). */
 size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n);
 int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
-                       float scale, void* ws, size_t ws_bytes, void* stream);
+                       int mask_act, float scale, void* ws, size_t ws_bytes, void* stream);
 /* dw[k,n] = x^T @ dz ; db[n] = sum_m dz  (db may be NULL) */
 size_t a3d_dense_bwd_filter_ws_bytes(int m, int k, int n);
 int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, float* dw, float* db,
@@ -104,6 +105,11 @@ int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, floa
 /* d loss / d out, using the per-sample sums left in ws by the forward call. */
 int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,
                        void* stream);
+
+/* Keep mask of tf.layers.dropout(rate, training=True) (src/models.py:230): keep[i] = floor((1-rate) + u_i),
+ * u from Philox4x32-10 keyed by (seed, step).  TF's own random stream is not reproducible, so parity tests pass
+ * the mask in; the training driver draws it with this kernel. */
+int a3d_dropout_keep_mask(size_t count, uint64_t seed, uint64_t step, float rate, uint8_t* keep, void* stream);
 
 /* tf.train.AdamOptimizer ApplyAdam (src/models.py:309): alpha = lr*sqrt(1-b2p)/(1-b1p);
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= m*alpha/(sqrt(v)+eps).  grad_scale multiplies g first

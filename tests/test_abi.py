@@ -1,0 +1,47 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/a3d.h declares (no compute calls here)."""
+import os
+import re
+import subprocess
+
+from ann3depth_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'a3d.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return set(re.findall(r'\b(a3d_[a-z0-9_]+)\s*\(', text))
+
+
+def test_header_symbols_are_exported_and_bound():
+    lib = _lib.load()
+    declared = declared_symbols()
+    assert len(declared) >= 30
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r' T (a3d_[a-z0-9_]+)', out))
+    assert declared <= exported, declared - exported
+    assert exported <= declared, f'exported but undeclared: {exported - declared}'
+    assert set(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert getattr(lib, name).argtypes is not None
+    assert b'gfx950' in lib.a3d_version()
+
+
+def test_errors_are_reported_not_thrown():
+    lib = _lib.load()
+    d = _lib.ConvDesc(n=1, h=8, w=8, c=4, k=4, r=3, s=3, stride=3, pad_t=1, pad_l=1, ho=8, wo=8, ldx=4, ldy=4)
+    assert lib.a3d_conv2d_fwd_ws_bytes(d) == 0                       # invalid descriptor: no workspace answer
+    rc = lib.a3d_conv2d_fwd(d, None, None, None, None, 0, None, 0, None)
+    assert rc == -1 and 'stride' in _lib.last_error()                # A3D_EINVAL before anything touches a device
+    rc = lib.a3d_adam_apply_tf1(0, None, None, None, None, 0, 0, 0, 0, 0, 0, 1, None)
+    assert rc == -1
+
+
+def test_gemm_code_objects_are_gfx950_mfma():
+    """The shipped library holds gfx950 code with fp32 MFMA instructions (not a host fallback)."""
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        return
+    out = subprocess.run([objdump, '--offloading', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'gfx950' in out

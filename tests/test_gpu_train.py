@@ -1,0 +1,157 @@
+"""BASELINE config 1 on the GPU: `make train`'s path end to end — TFRecord shard (48x64x3 / 6x8x1 records, B=4)
+-> dataset plugin -> model plugin -> driver loop with summaries, checkpoint, resume and signal stop; plus the
+committed golden vectors and the DCNF unary stack against the oracle."""
+import json
+import os
+import signal
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dcnf as OD
+from oracle import msdn as O
+from oracle import tf13_ops as T
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def write_shard(root, n=40, seed=0):
+    from ann3depth_amd import tfrecord
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, 'nyu'), exist_ok=True)
+    with tfrecord.TFRecordWriter(os.path.join(root, 'nyu', 'train.tfrecords')) as w:
+        for _ in range(n):
+            img = rng.integers(0, 256, (48, 64, 3)).astype(np.float32) / np.float32(255) - np.float32(.5)
+            dep = rng.integers(0, 256, (6, 8, 1)).astype(np.float32) / np.float32(255) - np.float32(.5)
+            w.write_example(img, dep)
+
+
+def test_train_op_matches_oracle_on_a_dequeued_batch(tmp_path):
+    from ann3depth_amd import data, models
+    write_shard(str(tmp_path))
+    inputs, targets = data.inputs(str(tmp_path), 'nyu', 4, seed=3)
+    op = models.msdn(inputs, targets)
+    out = op.run()
+    torch.cuda.synchronize()
+    img, dep = op.dev[0].cpu().numpy(), op.dev[1].cpu().numpy()
+    assert img.shape == (4, 48, 64, 3) and dep.shape == (4, 6, 8, 1)
+    assert img.min() >= 0 and img.max() <= 1                               # '+0.5' applied: k/255
+    keep = op.keep.cpu().numpy().astype(bool)
+    assert 0.45 < keep.mean() < 0.55
+    a = O.forward(O.init_params(3000), img, dep, keep)
+    assert rel(op.replica.coarse.cpu().numpy(), a['coarse']) < 1e-3
+    assert rel(op.replica.fine.cpu().numpy(), a['fine']) < 1e-3
+    assert abs(float(out['coarse_loss']) - a['loss_coarse']) < 1e-4 * abs(a['loss_coarse'])
+    assert op.global_step == 1
+    op.pipeline.close()
+
+
+def test_make_train_drop_in(tmp_path):
+    from ann3depth_amd import ann3depth
+    write_shard(str(tmp_path))
+    ck = str(tmp_path / 'ckpt')
+    base = ['--model', 'msdn', '--batchsize', '4', '--ckptdir', ck, '--datadir', str(tmp_path), '--sumfreq', '2',
+            '--id', 'r1']
+    assert ann3depth.main(base + ['--steps', '6', 'nyu']) == 0
+    d = os.path.join(ck, 'msdn_r1')                                       # <ckptdir>/<model>_<id>, src/ann3depth.py:73-75
+    assert ann3depth.latest_checkpoint(d).endswith('model.ckpt-6.pt')
+    sums = [json.loads(l) for l in open(os.path.join(d, 'summaries.jsonl'))]
+    assert [s['global_step'] for s in sums] == [2, 4, 6]
+    assert all(np.isfinite(s['coarse/coarse_loss']) and s['Phase'] == 1 for s in sums)
+    sd = torch.load(ann3depth.latest_checkpoint(d))
+    assert int(sd['global_step']) == 6
+    assert 'coarse/conv/conv2d_0/kernel' in sd and 'coarse/conv/conv2d_0/kernel/CoarseConv' in sd
+    w0 = O.init_params(3000)['coarse/dense/dense_1/kernel']
+    np.testing.assert_array_equal(sd['coarse/dense/dense_1/kernel'].numpy(), w0)       # beta2 = 1: weights frozen
+    assert float(sd['coarse/dense/dense_1/kernel/CoarseDense'].abs().max()) > 0       # ... but m evolves
+    # resume from the checkpoint
+    assert ann3depth.main(base + ['--steps', '8', 'nyu']) == 0
+    assert ann3depth.latest_checkpoint(d).endswith('model.ckpt-8.pt')
+    assert int(torch.load(ann3depth.latest_checkpoint(d))['global_step']) == 8
+    # StopAtSignalHook: stop after the current step, save, exit code = signal number (src/ann3depth.py:129)
+    threading.Thread(target=lambda: (time.sleep(1.0), os.kill(os.getpid(), signal.SIGUSR1)), daemon=True).start()
+    rc = ann3depth.main(base + ['--steps', '100000000', 'nyu'])
+    assert rc == signal.SIGUSR1
+    assert int(torch.load(ann3depth.latest_checkpoint(d))['global_step']) > 8
+    for s in (signal.SIGUSR1, signal.SIGUSR2, signal.SIGALRM, signal.SIGINT, signal.SIGTERM):
+        signal.signal(s, signal.SIG_DFL)
+    # parameter-server jobs do not exist any more
+    assert ann3depth.main(base + ['--job-name', 'ps', 'nyu']) == 0
+
+
+def test_golden_vectors_on_gpu():
+    from ann3depth_amd import models, ops
+    g = np.load(os.path.join(GOLD, 'msdn_b2.npz'))
+    net = models.MSDNReplica(2, params=O.init_params(int(g['seed_params'])))
+    cu = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).cuda()
+    net.forward(cu(g['images']), cu(g['depths']), cu(g['keep'], torch.uint8))
+    assert rel(net.coarse.cpu().numpy(), g['coarse']) < 1e-3 and rel(net.fine.cpu().numpy(), g['fine']) < 1e-3
+    assert abs(net.loss_coarse.item() - g['loss_coarse']) < 1e-4 * abs(g['loss_coarse'])
+    k = np.load(os.path.join(GOLD, 'op_kats.npz'))
+    for name in ('same5', 's2valid', 'cout63', 'cout1', 'cin3s4'):
+        st, same = (int(v) for v in k[f'conv_{name}_geom'])
+        x, w, b, dz = (k[f'conv_{name}_{q}'] for q in ('x', 'w', 'b', 'dz'))
+        n, h, wd, c = x.shape
+        d = ops.conv_desc(n, h, wd, c, w.shape[3], w.shape[0], w.shape[1], st, 'SAME' if same else 'VALID')
+        y = torch.empty(k[f'conv_{name}_y'].shape, device='cuda')
+        ops.conv2d_fwd(d, cu(x), cu(w), cu(b), y, 'relu')
+        assert rel(y.cpu().numpy(), k[f'conv_{name}_y']) < 1e-5
+        dw = torch.empty(w.shape, device='cuda'); db = torch.empty(b.shape, device='cuda')
+        ops.conv2d_bwd_filter(d, cu(x), cu(dz), dw, db)
+        assert rel(dw.cpu().numpy(), k[f'conv_{name}_dw']) < 1e-5 and rel(db.cpu().numpy(), k[f'conv_{name}_db']) < 1e-5
+        dx = torch.empty(x.shape, device='cuda')
+        ops.conv2d_bwd_data(d, cu(dz), cu(w), dx)
+        assert rel(dx.cpu().numpy(), k[f'conv_{name}_dx']) < 1e-5
+    y = torch.empty(k['pool_y'].shape, device='cuda'); dx = torch.empty(k['pool_x'].shape, device='cuda')
+    ops.maxpool2x2_fwd(cu(k['pool_x']), y)
+    ops.maxpool2x2_bwd(cu(k['pool_x']), cu(k['pool_dy']), dx, relu_mask=False)
+    np.testing.assert_array_equal(y.cpu().numpy(), k['pool_y'])
+    np.testing.assert_array_equal(dx.cpu().numpy(), k['pool_dx'])
+    for tag, oh, ow in (('up', 55, 74), ('dn', 23, 30)):
+        x = k[f'resize_{tag}_x']
+        y = torch.empty((x.shape[0], oh, ow, x.shape[3]), device='cuda')
+        ops.resize_bilinear_tf1(cu(x), y)
+        np.testing.assert_array_equal(y.cpu().numpy(), k[f'resize_{tag}_y'])
+    for tag, b2 in (('ref', 1.0), ('learn', 0.999)):
+        v = cu(k['adam_var0']); m = torch.zeros_like(v); s = torch.zeros_like(v)
+        b1p, b2p = np.float32(0.9), np.float32(b2)
+        for i in range(3):
+            ops.adam_apply_tf1(v, m, s, cu(k['adam_g'][i]), 0.1, 0.9, b2, 1e-8, float(b1p), float(b2p))
+            b1p, b2p = b1p * np.float32(0.9), b2p * np.float32(b2)
+        np.testing.assert_array_equal(v.cpu().numpy(), k[f'adam_{tag}_var'])
+        np.testing.assert_array_equal(m.cpu().numpy(), k[f'adam_{tag}_m'])
+
+
+def test_dcnf_unary_matches_oracle():
+    """BASELINE config 4 at B=1 (48 patches): forward z and the unary backward from a synthetic dz."""
+    from ann3depth_amd import models
+    rng = np.random.default_rng(5)
+    img = (rng.integers(0, 256, (1, 480, 640, 3)) / 255).astype(np.float32)
+    params = OD.init_params(3000)
+    net = models.DCNFUnary(1, params=params)
+    assert (net.rows, net.cols, net.P) == (6, 8, 48)
+    z = net.forward(torch.from_numpy(img).cuda())
+    patches = OD.patches(img)
+    np.testing.assert_array_equal(net.act['x'].cpu().numpy(), patches)                    # resize + patches bit-exact
+    a = OD.unary_forward(params, patches)
+    assert rel(z.cpu().numpy().reshape(48, 1), a['z']) < 1e-3
+    for n in ('conv2d', 'conv2d_1/pool', 'conv2d_4/pool', 'dense', 'dense_1'):
+        assert rel(net.act[n].cpu().numpy(), a[n]) < 1e-4, n
+    dz = rng.standard_normal((48, 1)).astype(np.float32)
+    net.backward(torch.from_numpy(dz).cuda())
+    torch.cuda.synchronize()
+    a_gpu = {k: v.cpu().numpy() for k, v in net.act.items()}
+    a_gpu['flat'] = a_gpu['conv2d_4/pool'].reshape(48, -1)
+    g = OD.unary_backward(params, a_gpu, dz)
+    for n, gref in g.items():
+        assert rel(net.group.view(net.group.grad, n).cpu().numpy(), gref) < 1e-4, n
