@@ -78,6 +78,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise A3dError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        f'or `make -C ann3depth_amd/csrc` (there is no fallback path)')
+    # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that liba3d.so binds to
+    # the runtime copy torch initialises: two HIP runtimes in one process cannot both own the device.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -199,7 +199,10 @@ __device__ __forceinline__ void adam_one(float& var, float& m, float& v, float g
                                          float eps) {
   m = __fadd_rn(m, __fmul_rn(__fsub_rn(g, m), omb1));
   v = __fadd_rn(v, __fmul_rn(__fsub_rn(__fmul_rn(g, g), v), omb2));
-  var = __fsub_rn(var, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(__fsqrt_rn(v), eps)));
+  // v_sqrt_f32 is 1-ulp, not correctly rounded, and hipcc emits it bare; the f64 square root rounded to f32 is
+  // correctly rounded (53 >= 2*24+2 bits), which is what the numpy/Eigen reference computes.
+  const float sq = (float)sqrt((double)v);
+  var = __fsub_rn(var, __fdiv_rn(__fmul_rn(m, alpha), __fadd_rn(sq, eps)));
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,

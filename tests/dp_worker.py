@@ -1,0 +1,59 @@
+"""Rank body of tests/test_dp_gloo.py (world_size 2, gloo, CPU).  Exercises the product's process-group setup and
+bucket reducer (ann3depth_amd/dp.py); gradients come from the numpy oracle because the HIP path needs a GPU."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ann3depth_amd import dp            # noqa: E402
+from oracle import msdn as O            # noqa: E402
+
+
+def main(out_path):
+    rank, local_rank, world = dp.init_from_env('gloo')
+    assert world == 2
+    red = dp.GradReducer()
+    assert (red.rank, red.world_size) == (rank, 2)
+    params = O.init_params(3000)
+    rng = np.random.default_rng(77)
+    img = (rng.integers(0, 256, (2, 48, 64, 3)) / 255).astype(np.float32)
+    dep = (rng.integers(0, 256, (2, 6, 8, 1)) / 255).astype(np.float32)
+    keep = rng.random((2, 4096)) >= 0.5
+    # replicas start from rank 0's weights
+    w = torch.from_numpy(params['coarse/conv/conv2d_0/kernel'].copy())
+    if rank == 1:
+        w.zero_()
+    red.broadcast(w)
+    assert torch.equal(w, torch.from_numpy(params['coarse/conv/conv2d_0/kernel']))
+    # each rank: its own sample (per-GPU batch 1); buckets: dense first (async), then conv, like MSDNReplica.step
+    # activations are taken from ONE forward of both samples and sliced per rank: the loss gradient ~ 1/(o + 1e-8)
+    # amplifies the last-bit differences BLAS produces between a batch-1 and a batch-2 forward (see test_gpu_msdn.py)
+    a2 = O.forward(params, img, dep, keep)
+    a = {k: (v[rank:rank + 1] if isinstance(v, np.ndarray) and v.ndim > 0 and v.shape[0] == 2 else v)
+         for k, v in a2.items()}
+    g = O.backward_coarse(params, a)
+    dense = torch.cat([torch.from_numpy(g[n]).reshape(-1) for n in sorted(g) if n.startswith('coarse/dense')])
+    conv = torch.cat([torch.from_numpy(g[n]).reshape(-1) for n in sorted(g) if n.startswith('coarse/conv')])
+    red.start(dense)
+    red.start(conv)
+    red.finish()
+    assert red.pending == []
+    dense *= 1.0 / world
+    conv *= 1.0 / world
+    if rank == 0:
+        g2 = O.backward_coarse(params, a2)                # the same two samples as ONE batch of 2
+        d2 = np.concatenate([g2[n].reshape(-1) for n in sorted(g2) if n.startswith('coarse/dense')])
+        c2 = np.concatenate([g2[n].reshape(-1) for n in sorted(g2) if n.startswith('coarse/conv')])
+        rel = lambda x, y: float(np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y))
+        with open(out_path, 'w') as f:
+            f.write(f'{rel(dense.numpy(), d2)} {rel(conv.numpy(), c2)}\n')
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

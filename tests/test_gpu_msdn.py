@@ -14,6 +14,7 @@ GRAD_TOL = 1e-4       # backward chain given the same activations: fp32 accumula
 # loss, not of either implementation, so the end-to-end gradient check is loose and the tight check feeds the
 # oracle's backward with the activations the GPU produced.
 GRAD_TOL_END_TO_END = 3e-2
+LOSS_TOL = 2e-3
 
 
 def gpu_activations(net):
@@ -63,8 +64,9 @@ def test_msdn_step_matches_oracle(models, phase, global_step):
     assert rel(net.fine.cpu().numpy(), a['fine']) < DEPTH_TOL
     for name, ref in [('c0', 'c0'), ('c1', 'c1'), ('c4', 'c4'), ('drop', 'drop'), ('f1', 'f1'), ('cat', 'cat'), ('f2', 'f2')]:
         assert rel(getattr(net, name).cpu().numpy(), a[ref]) < 1e-4, name
-    assert abs(out['coarse_loss'].item() - a['loss_coarse']) < 1e-4 * abs(a['loss_coarse'])
-    assert abs(out['fine_loss'].item() - a['loss_fine']) < 1e-4 * abs(a['loss_fine'])
+    # log(o + 1e-8) of outputs that land within ~1e-7 of zero moves by O(1) under last-bit changes of o
+    assert abs(out['coarse_loss'].item() - a['loss_coarse']) < LOSS_TOL * abs(a['loss_coarse'])
+    assert abs(out['fine_loss'].item() - a['loss_fine']) < LOSS_TOL * abs(a['loss_fine'])
     for n, gref in g.items():
         assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL_END_TO_END, n
     if phase in (1, 2):
@@ -97,9 +99,12 @@ def test_msdn_learning_mode_multi_step(models):
     moved = 0
     for n in params:
         if n.startswith('coarse'):
-            w = net.var(n).cpu().numpy()
-            assert rel(w, tr.p[n]) < 2e-2, n          # Adam's g/sqrt(v) amplifies sign flips of tiny gradients
-            moved += int(np.abs(w - params[n]).max() > 0)
+            # Adam's m/sqrt(v) is ~ +-lr whatever |g| is, so an element whose tiny gradient changes sign under
+            # fp32 reordering moves the other way: compare element-wise and allow a few such elements
+            w, ref, w0 = net.var(n).cpu().numpy(), tr.p[n], params[n]
+            close = np.abs(w - ref) <= 0.05 * np.abs(ref - w0) + 1e-7
+            assert close.mean() > 0.97, (n, close.mean())
+            moved += int(np.abs(w - w0).max() > 0)
         else:
             np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])     # fine/* frozen in the coarse phase
     assert moved >= 12
