@@ -45,8 +45,12 @@ GemmPlan plan_gemm(const GemmProblem& g);
 struct IgemmParams;
 int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st);
 
-// column sums of a [rows, ld] matrix (first n columns) -> out[n]; ws >= colsum_ws_bytes
-size_t colsum_ws_bytes(int rows, int n);
-int launch_colsum(const float* x, int rows, int n, int ld, float* out, void* ws, hipStream_t st);
+// ---- single-output-channel 5x5 stencil (stencil1.hip) ----
+bool stencil1_applicable(const a3d_conv_desc* d);
+size_t stencil1_bwdf_ws_bytes(const a3d_conv_desc* d);
+int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                 hipStream_t st);
+int stencil1_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
+                        hipStream_t st);
 
 }  // namespace a3d

@@ -52,6 +52,7 @@ struct IgemmParams {
   const float* bias;    // [N] or null            (FWD epilogue)
   const float* mask;    // [M, ldc] or null        (BWD_D epilogue: *= mask>0)
   const uint8_t* keep;  // [M, N] or null          (FWD epilogue: *= keep*mask_scale)
+  float* dbias;         // BWD_F: column sums of B (= BiasAddGrad), [N] or [splitk][N] slabs; null = not wanted
   float mask_scale;
   int mask_act;         // EPI_RELU: *= (mask > 0);  EPI_SIGMOID: *= mask * (1 - mask)
   int M, N, K;
@@ -325,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
   float ra[ATile::NL][AVEC];
   float rb[BNL][BVEC];
+  // BiasAddGrad rides along in BWD_F: the blocks of the first M-tile also sum the dz tiles they stage (column n0+tid)
+  const bool do_bias = (MODE == MODE_BWD_F) && p.dbias != nullptr && tile_m == 0 && tid < BN;
+  float bsum = 0.f;
 
   const int a_cq = tid % ATile::CPR;
   const int b_cq = tid % BTile::CPR;   // BWD_D only
@@ -379,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
     const float* Ac = As + cur * Cfg::A_ELEMS;
     const float* Bc = Bs + cur * Cfg::B_ELEMS;
+    if (MODE == MODE_BWD_F && do_bias) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) bsum += Bc[k * Cfg::B_LD + tid];
+    }
 #pragma unroll
     for (int u = 0; u < BK / 8; ++u) {
       f32x4 af[TM], bf[TN];
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     Cout = p.C + (size_t)split * p.slab;
     ldc = p.N;
   }
+  if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll

@@ -2,6 +2,7 @@
 // conv2d / dense entry points of include/a3d.h.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -18,8 +19,8 @@ struct TileCfg {
   int bm, bn;
   float eff;   // relative MFMA efficiency of the tile shape (bigger tiles amortise LDS traffic better)
 };
-static const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 96, 0.92f}, {128, 64, 0.85f}, {128, 32, 0.55f},
-                                {64, 64, 0.65f},   {32, 128, 0.60f}, {64, 128, 0.85f}};
+static const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 96, 1.00f}, {128, 64, 0.92f}, {128, 32, 0.60f},
+                                {64, 64, 0.98f},   {32, 128, 0.90f}, {64, 128, 1.00f}};
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -34,36 +35,56 @@ static bool g_timing_on = false;
 static std::vector<TimingSlot> g_timing;
 static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1};
 
+// Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 GemmPlan plan_gemm(const GemmProblem& g) {
   GemmPlan best{};
   double best_t = 1e300;
   const int nk = (g.K + 31) / 32;
+  const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
+  if (force_cfg >= 0 && force_cfg < kNumCfgs) {
+    const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
+    int splitk = std::max(1, std::min(force_split > 0 ? force_split : 1, nk));
+    while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
+    int kps = (nk + splitk - 1) / splitk;
+    splitk = (nk + kps - 1) / kps;
+    best.cfg = force_cfg; best.splitk = splitk; best.ktiles_per_split = kps;
+    best.tiles_m = (g.M + bm - 1) / bm; best.tiles_n = (g.N + bn - 1) / bn;
+    best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+    return best;
+  }
+  // Cost model calibrated on MI355X with tools/sweep_igemm.py (profiles/r01_sweep_igemm.txt): a block progresses at
+  // ~96.5 GMAC/s when two share a CU and ~1.6x that when alone; split-K costs one slab write+read at ~3 TB/s.
   for (int c = 0; c < kNumCfgs; ++c) {
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
-    int max_split = std::max(1, nk / 4);
-    max_split = std::min(max_split, 512);
-    long want = (kSlots + tiles - 1) / tiles;
-    int splitk = (int)std::min<long>(std::max<long>(want, 1), max_split);
-    while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
-    int kps = (nk + splitk - 1) / splitk;
-    splitk = (nk + kps - 1) / kps;
-    const long blocks = tiles * splitk;
-    const long rounds = (blocks + kSlots - 1) / kSlots;
-    // under-filled chip: a block alone on a CU runs ~1.6x faster than two sharing it
-    double fill = std::min(1.0, (double)blocks / kSlots);
-    double t_block = (double)bm * bn * kps * 32.0 / kCfgs[c].eff * (0.6 + 0.4 * fill);
-    double t = rounds * t_block;
-    if (splitk > 1) t += (double)g.M * g.N * (splitk + 1) * 24.0;   // slab write+read, in the same pseudo-units
-    if (t < best_t) {
-      best_t = t;
-      best.cfg = c;
-      best.splitk = splitk;
-      best.ktiles_per_split = kps;
-      best.tiles_m = tm;
-      best.tiles_n = tn;
-      best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+    for (int want = 1; want <= 256; want *= 2) {
+      if (want > 1 && want > nk / 2) break;
+      if ((size_t)want * g.M * g.N * 4 > kMaxSlabBytes) break;
+      const int kps = (nk + want - 1) / want;
+      const int splitk = (nk + kps - 1) / kps;
+      const long blocks = tiles * splitk;
+      const double t_b = (double)bm * bn * kps * 32.0 / (96.5e3 * kCfgs[c].eff);          // us
+      double f;
+      if (blocks <= 256) f = 0.62;
+      else if (blocks <= kSlots) f = 0.62 + 0.38 * (double)(blocks - 256) / 256.0;
+      else f = (double)blocks / kSlots + 0.35;
+      double t = t_b * f;
+      if (splitk > 1) t += 2.5 + (double)g.M * g.N * 4.0 * (splitk + 1) / 3.0e6;
+      if (t < best_t) {
+        best_t = t;
+        best.cfg = c;
+        best.splitk = splitk;
+        best.ktiles_per_split = kps;
+        best.tiles_m = tm;
+        best.tiles_n = tn;
+        best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+      }
     }
   }
   return best;
@@ -95,9 +116,11 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   p.tiles_n = plan.tiles_n;
   p.slab = (size_t)p.M * p.N;
   float* final_c = p.C;
+  float* final_dbias = p.dbias;
   if (plan.splitk > 1) {
     if (!ws) return set_error(A3D_EWORKSPACE, "igemm: split-K needs a workspace");
     p.C = static_cast<float*>(ws);
+    if (p.dbias) p.dbias = static_cast<float*>(ws) + (size_t)plan.splitk * p.slab;   // [splitk][N] after the C slabs
   }
   const unsigned grid = (unsigned)((long)plan.tiles_m * plan.tiles_n * plan.splitk);
   int rc;
@@ -135,47 +158,16 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     clear_stale_error();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
     rc = check_launch("splitk_reduce");
+    if (rc == A3D_OK && final_dbias) {
+      ReduceParams b{};
+      b.ws = p.dbias; b.C = final_dbias; b.M = 1; b.N = p.N; b.ldc = p.N; b.splitk = plan.splitk;
+      b.mode = MODE_BWD_F; b.slab = (size_t)p.N;
+      clear_stale_error();
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, b);
+      rc = check_launch("dbias_reduce");
+    }
   }
   return rc;
-}
-
-// ---- column sums (BiasAddGrad) ----
-static const int kColsumRowSplits = 128;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int rows, int n, int ld, float* part,
-                                                             int rows_per_split) {
-  __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  const int r_begin = blockIdx.y * rows_per_split;
-  const int r_end = min(rows, r_begin + rows_per_split);
-  float s = 0.f;
-  if (col < n)
-    for (int r = r_begin + rl; r < r_end; r += 4) s += x[(size_t)r * ld + col];
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && col < n) part[(size_t)blockIdx.y * n + col] = red[0][threadIdx.x] + red[1][threadIdx.x] +
-                                                                red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-size_t colsum_ws_bytes(int rows, int n) {
-  (void)rows;
-  return (size_t)kColsumRowSplits * n * 4;
-}
-
-int launch_colsum(const float* x, int rows, int n, int ld, float* out, void* ws, hipStream_t st) {
-  int splits = std::min(kColsumRowSplits, std::max(1, rows / 16));
-  int rps = (rows + splits - 1) / splits;
-  splits = (rows + rps - 1) / rps;
-  float* part = static_cast<float*>(ws);
-  clear_stale_error();
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, splits), dim3(256), 0, st, x, rows, n, ld, part, rps);
-  int rc = check_launch("colsum_partial");
-  if (rc != A3D_OK) return rc;
-  ReduceParams r{};
-  r.ws = part; r.C = out; r.M = 1; r.N = n; r.ldc = n; r.splitk = splits; r.mode = MODE_BWD_F; r.slab = (size_t)n;
-  clear_stale_error();
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, r);
-  return check_launch("colsum_reduce");
 }
 
 // ---- descriptor checks / parameter assembly ----
@@ -272,6 +264,7 @@ int a3d_timing_collect(a3d_timing_record* out, int cap) {
 
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
+  if (stencil1_applicable(d)) return 0;
   return plan_gemm(fwd_problem(d)).ws_bytes;
 }
 
@@ -281,6 +274,7 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
+  if (stencil1_applicable(d)) return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
@@ -329,8 +323,9 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
 
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
-  size_t slabs = plan_gemm(bwd_f_problem(d)).ws_bytes;
-  return std::max(slabs, colsum_ws_bytes(d->n * d->ho * d->wo, d->k));
+  if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
+  GemmPlan plan = plan_gemm(bwd_f_problem(d));
+  return plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
 }
 
 int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
@@ -338,20 +333,20 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && dz && dw, "conv2d_bwd_filter: null tensor");
+  if (stencil1_applicable(d)) {
+    if (stencil1_bwdf_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
+    return stencil1_bwd_filter(d, x, dz, dw, db, ws, static_cast<hipStream_t>(stream));
+  }
   GemmProblem g = bwd_f_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(dz)) g.bvec = 1;
   GemmPlan plan = plan_gemm(bwd_f_problem(d));
-  size_t need = std::max(plan.ws_bytes, db ? colsum_ws_bytes(g.K, g.N) : (size_t)0);
+  size_t need = plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (db) {   // BiasAddGrad first: it shares the workspace with the slabs, stream order keeps them apart
-    rc = launch_colsum(dz, g.K, g.N, d->ldy, db, ws, st);
-    if (rc != A3D_OK) return rc;
-  }
   IgemmParams p;
   fill_common(p, g);
-  p.A = x; p.B = dz; p.C = dw;
+  p.A = x; p.B = dz; p.C = dw; p.dbias = db;      // BiasAddGrad = column sums of dz, fused into the same kernel
   p.npix = g.K; p.nrsc = g.M;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
   p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;

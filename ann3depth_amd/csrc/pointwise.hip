@@ -233,6 +233,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
   }
 }
 
+// ApplyAdam specialised for alpha == 0 and 1-beta2 == 0 — what the reference's AdamOptimizer(rate, 0.9, 1) always is
+// (src/models.py:309).  Then v += (g*g - v)*0 and var -= (m*0)/(sqrt(v)+eps) leave v and var bit-identical unless a
+// non-finite value poisons them (inf*0 = NaN), so only m needs the full read-modify-write: 3 HBM streams instead of
+// 7.  Poisoned elements get exactly the NaNs the general formula would produce.  (Assumes v holds no +-inf from a
+// foreign checkpoint; v is only ever written by these two kernels, which never produce one.)
+__global__ __launch_bounds__(256) void adam_frozen_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                          float* __restrict__ v, const float* __restrict__ g,
+                                                          size_t count, float omb1, float gscale) {
+  const size_t nvec = count / 4;
+  const bool use_scale = gscale != 1.f;
+  const float qnan = __builtin_nanf("");
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], g4 = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
+      m4[j] = __fadd_rn(m4[j], __fmul_rn(__fsub_rn(gj, m4[j]), omb1));
+      const bool g_poison = !isfinite(__fmul_rn(gj, gj));
+      if (g_poison) v[4 * i + j] = qnan;
+      if (g_poison || !isfinite(m4[j])) var[4 * i + j] = qnan;
+    }
+    reinterpret_cast<f32x4*>(m)[i] = m4;
+  }
+  if (blockIdx.x == 0) {
+    const size_t i = nvec * 4 + threadIdx.x;
+    if (i < count) {
+      const float gj = use_scale ? __fmul_rn(g[i], gscale) : g[i];
+      const float mj = __fadd_rn(m[i], __fmul_rn(__fsub_rn(gj, m[i]), omb1));
+      m[i] = mj;
+      const bool g_poison = !isfinite(__fmul_rn(gj, gj));
+      if (g_poison) v[i] = qnan;
+      if (g_poison || !isfinite(mj)) var[i] = qnan;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ dropout keep mask (Philox4x32-10)
 // TF draws U[0,1) from its own Philox stream, which is not reproducible outside TF; this is the same generator
 // family keyed by (seed, step), one counter per 4 mask bytes.  keep = floor(keep_prob + u)  (nn.dropout, TF 1.3).
@@ -356,6 +392,12 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
   A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
                   reinterpret_cast<uintptr_t>(g)) & 15) == 0, "adam: buffers must be 16-byte aligned");
   const float alpha = lr * sqrtf(1.f - beta2_power) / (1.f - beta1_power);
+  if (alpha == 0.f && 1.f - beta2 == 0.f) {
+    clear_stale_error();
+    hipLaunchKernelGGL(adam_frozen_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, grad_scale);
+    return check_launch("adam_frozen");
+  }
   clear_stale_error();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,

@@ -36,7 +36,9 @@ CONV_CASES = [
     (2, 13, 18, 384, 256, 3, 2, 'VALID'),    # conv2d_4: stride-2 VALID 13x18 -> 6x8
     (2, 40, 52, 3, 63, 9, 2, 'VALID'),       # fine/first: Cout=63
     (2, 21, 30, 64, 64, 5, 1, 'SAME'),       # fine/second
-    (2, 21, 30, 64, 1, 5, 1, 'SAME'),        # fine/third: Cout=1
+    (2, 21, 30, 64, 1, 5, 1, 'SAME'),        # fine/third: Cout=1 (direct stencil kernels)
+    (3, 55, 74, 64, 1, 5, 1, 'SAME'),        # fine/third at full spatial size (74 = 9 strips of 8 + 2)
+    (2, 9, 13, 40, 1, 5, 1, 'VALID'),        # stencil path with Cin < 64 and VALID padding
     (1, 10, 11, 8, 12, 4, 2, 'SAME'),        # asymmetric SAME padding, stride 2
     (1, 9, 9, 5, 7, 3, 1, 'SAME'),           # Cin, Cout not multiples of 4
     (5, 24, 24, 64, 256, 5, 1, 'VALID'),     # dcnf conv2d_1 kind
@@ -231,6 +233,32 @@ def test_adam_bitexact(ops, beta2):
         np.testing.assert_array_equal(vd.cpu().numpy(), ref['w'])
     if beta2 == 1.0:
         np.testing.assert_array_equal(ref['w'], var)       # the reference's optimizer never moves the weights
+
+
+def test_adam_frozen_path_poison_semantics(ops):
+    """beta2 = 1 takes the 3-stream kernel; non-finite gradients must poison v / var exactly like the full formula
+    (inf * 0 = NaN), and a non-zero finite v (foreign checkpoint) must be left untouched."""
+    rng = np.random.default_rng(23)
+    count = 4 * 64 + 2
+    var = rng.standard_normal(count).astype(np.float32)
+    v0 = (rng.random(count) * 0.01).astype(np.float32)
+    g = rng.standard_normal((3, count)).astype(np.float32)
+    g[0, 5] = np.inf; g[0, 77] = np.nan; g[1, 130] = -np.inf; g[1, 200] = 3e19; g[2, count - 1] = np.inf
+    opt = T.AdamTF1(0.1, 0.9, 1.0)
+    opt.v['w'] = v0.copy()
+    opt.m['w'] = np.zeros(count, np.float32)
+    ref = {'w': var.copy()}
+    vd, md, sd = dev(var), torch.zeros(count, device='cuda'), dev(v0)
+    b1p = np.float32(0.9)
+    for step in range(3):
+        with np.errstate(invalid='ignore', over='ignore'):
+            opt.apply(ref, {'w': g[step]})
+        ops.adam_apply_tf1(vd, md, sd, dev(g[step]), 0.1, 0.9, 1.0, 1e-8, float(b1p), 1.0)
+        b1p = b1p * np.float32(0.9)
+        np.testing.assert_array_equal(md.cpu().numpy(), opt.m['w'])
+        np.testing.assert_array_equal(sd.cpu().numpy(), opt.v['w'])
+        np.testing.assert_array_equal(vd.cpu().numpy(), ref['w'])
+    assert np.isnan(ref['w']).sum() == 5 and np.isnan(opt.v['w']).sum() == 5
 
 
 def test_bad_arguments_fail_loudly(ops):
