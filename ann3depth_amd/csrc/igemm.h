@@ -7,7 +7,7 @@
 // Dense layers are the 1x1 / 1-pixel special case.  fp32 MFMA is bit-for-bit an fmaf chain, so results carry
 // plain fp32 rounding (no reduced-precision inputs).
 //
-// Block = 256 threads = 4 waves; each wave owns TM x TN accumulators of 32x32.  The K loop runs in tiles of BK=32
+// Block = 4 or 8 waves; each wave owns TM x TN accumulators of 32x32.  The K loop runs in tiles of BK=32
 // with a register-prefetched, double-buffered LDS pipeline (global loads of tile t+1 are in flight while the MFMAs
 // of tile t run; one __syncthreads per tile).  Inside a tile K is consumed in chunks of 8: lane half h supplies
 // k = 8u+4h+j to MFMA j of the chunk, for both operands, so a K-contiguous operand is read with one ds_read_b128.
@@ -75,10 +75,11 @@ struct IgemmParams {
   int tiles_m, tiles_n;
 };
 
-template <int MODE, int BM, int BN, int WAVES_M, int AVEC, int BVEC>
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
 struct IgemmCfg {
   static constexpr int BK = 32;
-  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int NT = 64 * NWAVES;
+  static constexpr int WAVES_N = NWAVES / WAVES_M;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1 && TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile");
@@ -141,11 +142,11 @@ __device__ __forceinline__ ColDec decode_col(const IgemmParams& p, int kcol) {
 
 // Gather ROWS x COLS (pixels x window elements) into registers. Thread t owns column chunk t % CPR and rows
 // t / CPR + j * RPP.
-template <int ROWS, int COLS, int VEC, bool TRANSPOSED>
+template <int NT, int ROWS, int COLS, int VEC, bool TRANSPOSED>
 struct Im2colTile {
   static constexpr int CPR = COLS / VEC;
-  static_assert(256 % CPR == 0, "cpr");
-  static constexpr int RPP = 256 / CPR;
+  static_assert(NT % CPR == 0, "cpr");
+  static constexpr int RPP = NT / CPR;
   static constexpr int NL = (ROWS + RPP - 1) / RPP;
   static_assert(ROWS % RPP == 0, "rows");
 
@@ -190,20 +191,20 @@ struct Im2colTile {
 };
 
 // Plain 2-D tile: src[(row0+r)*ld + col0+c], zero outside [0,rmax) x [0,cmax).
-template <int ROWS, int COLS, int VEC>
+template <int NT, int ROWS, int COLS, int VEC>
 struct PlainTile {
   static constexpr int CPR = COLS / VEC;
   static constexpr int TOTAL = ROWS * CPR;
-  static constexpr int NL = (TOTAL + 255) / 256;
+  static constexpr int NL = (TOTAL + NT - 1) / NT;
 
   __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const float* src, int ld, int row0, int col0,
                                               int rmax, int cmax, int tid) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      int idx = tid + j * 256;
+      int idx = tid + j * NT;
       int r = idx / CPR, cq = idx % CPR;
       int gr = row0 + r, gc = col0 + cq * VEC;
-      bool ok = (TOTAL % 256 == 0 || idx < TOTAL) && gr < rmax && gc < cmax;   // VEC=4 requires cmax % 4 == 0
+      bool ok = (TOTAL % NT == 0 || idx < TOTAL) && gr < rmax && gc < cmax;   // VEC=4 requires cmax % 4 == 0
       long off = (long)gr * ld + gc;
       if (VEC == 4) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -217,8 +218,8 @@ struct PlainTile {
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      int idx = tid + j * 256;
-      if (TOTAL % 256 != 0 && idx >= TOTAL) continue;
+      int idx = tid + j * NT;
+      if (TOTAL % NT != 0 && idx >= TOTAL) continue;
       int r = idx / CPR, cq = idx % CPR;
       float* dst = lds + r * ld + cq * VEC;
       if (VEC == 4) {
@@ -232,10 +233,10 @@ struct PlainTile {
 };
 
 // BWD_D filter tile: rows = Cin (GEMM N), cols = (rs, Cout) (GEMM K): W[rs][cin][cout].
-template <int ROWS, int COLS, int VEC>
+template <int NT, int ROWS, int COLS, int VEC>
 struct FilterTTile {
   static constexpr int CPR = COLS / VEC;
-  static constexpr int RPP = 256 / CPR;
+  static constexpr int RPP = NT / CPR;
   static constexpr int NL = ROWS / RPP;
   static_assert(ROWS % RPP == 0, "rows");
   __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const IgemmParams& p, int n0, int kcol,
@@ -275,15 +276,16 @@ struct FilterTTile {
   }
 };
 
-template <int MODE, int BM, int BN, int WAVES_M, int AVEC, int BVEC>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
-  using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, AVEC, BVEC>;
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
+__global__ __launch_bounds__(64 * NWAVES, NWAVES / 2) void igemm_kernel(const IgemmParams p) {
+  using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
+  constexpr int NT = Cfg::NT;
   constexpr int BK = Cfg::BK;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
   constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
-  using ATile = Im2colTile<Cfg::A_ROWS, Cfg::A_COLS, AVEC, TRANSPOSED>;
-  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<Cfg::B_ROWS, Cfg::B_COLS, BVEC>,
-                                          PlainTile<Cfg::B_ROWS, Cfg::B_COLS, BVEC>>::type;
+  using ATile = Im2colTile<NT, Cfg::A_ROWS, Cfg::A_COLS, AVEC, TRANSPOSED>;
+  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<NT, Cfg::B_ROWS, Cfg::B_COLS, BVEC>,
+                                          PlainTile<NT, Cfg::B_ROWS, Cfg::B_COLS, BVEC>>::type;
   constexpr int BNL = BTile::NL;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -411,6 +413,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           for (int j = 0; j < 4; ++j) bf[b][j] = Bc[(kk + j) * Cfg::B_LD + col];
         }
       }
+      // the next tile's global loads were issued before chunk 0; park them in the other LDS buffer ahead of the
+      // last chunk's MFMAs so that only the barrier is left at the end of the tile
+      if (u == BK / 8 - 1 && more) store_tiles(cur ^ 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -419,7 +424,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }

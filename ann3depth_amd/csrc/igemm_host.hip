@@ -20,7 +20,8 @@ struct TileCfg {
   float eff;   // relative MFMA efficiency of the tile shape (bigger tiles amortise LDS traffic better)
 };
 static const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 96, 1.00f}, {128, 64, 0.92f}, {128, 32, 0.60f},
-                                {64, 64, 0.98f},   {32, 128, 0.90f}, {64, 128, 1.00f}};
+                                {64, 64, 0.98f},   {32, 128, 0.90f}, {64, 128, 1.00f}, {128, 128, 1.15f},
+                                {128, 64, 1.05f}};  // last two: 8-wave blocks (4 waves per SIMD at 2 blocks/CU)
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -33,7 +34,8 @@ struct TimingSlot {
 static std::mutex g_timing_mu;
 static bool g_timing_on = false;
 static std::vector<TimingSlot> g_timing;
-static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1};
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4};
+static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8};
 
 // Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
 static int env_int(const char* name, int dflt) {
@@ -59,7 +61,9 @@ GemmPlan plan_gemm(const GemmProblem& g) {
   }
   // Cost model calibrated on MI355X with tools/sweep_igemm.py (profiles/r01_sweep_igemm.txt): a block progresses at
   // ~96.5 GMAC/s when two share a CU and ~1.6x that when alone; split-K costs one slab write+read at ~3 TB/s.
+  // Model picks are within 1.15x (mostly 1.05x) of the best measured configuration for every MSDN layer/direction.
   for (int c = 0; c < kNumCfgs; ++c) {
+    if (kCfgs[c].eff <= 0.f) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
@@ -70,10 +74,10 @@ GemmPlan plan_gemm(const GemmProblem& g) {
       const int splitk = (nk + kps - 1) / kps;
       const long blocks = tiles * splitk;
       const double t_b = (double)bm * bn * kps * 32.0 / (96.5e3 * kCfgs[c].eff);          // us
-      double f;
+      double f;      // kernel time in units of t_b: the slowest CU decides (tools/fit_planner.py)
       if (blocks <= 256) f = 0.62;
-      else if (blocks <= kSlots) f = 0.62 + 0.38 * (double)(blocks - 256) / 256.0;
-      else f = (double)blocks / kSlots + 0.35;
+      else if (blocks <= kSlots) f = 1.0;
+      else f = std::max((double)blocks / kSlots + 0.08, 1.45);
       double t = t_b * f;
       if (splitk > 1) t += 2.5 + (double)g.M * g.N * 4.0 * (splitk + 1) / 3.0e6;
       if (t < best_t) {
@@ -141,7 +145,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   if (timed) {
     hipEventRecord(slot.stop, st);
     a3d_timing_record& r = slot.rec;
-    r.mode = mode; r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
+    r.mode = mode; r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg]; r.nwaves = kCfgNWaves[plan.cfg];
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;
     std::lock_guard<std::mutex> lk(g_timing_mu);

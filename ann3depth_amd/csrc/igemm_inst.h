@@ -5,13 +5,15 @@
 
 namespace a3d {
 
-#define A3D_CFGS(X) X(0, 128, 128, 2) X(1, 128, 96, 4) X(2, 128, 64, 4) X(3, 128, 32, 4) X(4, 64, 64, 2) \
-                    X(5, 32, 128, 1) X(6, 64, 128, 1)
+// index, BM, BN, WAVES_M, NWAVES  (keep in step with kCfgs in igemm_host.hip)
+#define A3D_CFGS(X) X(0, 128, 128, 2, 4) X(1, 128, 96, 4, 4) X(2, 128, 64, 4, 4) X(3, 128, 32, 4, 4) \
+                    X(4, 64, 64, 2, 4) X(5, 32, 128, 1, 4) X(6, 64, 128, 1, 4) X(7, 128, 128, 4, 8) \
+                    X(8, 128, 64, 4, 8)
 
-template <int BM, int BN, int WAVES_M, int AVEC, int BVEC>
+template <int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
 static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
-  using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, AVEC, BVEC>;
-  auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, AVEC, BVEC>;
+  using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
+  auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
   static bool attr_done = false;   // idempotent attribute, benign if set twice
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -20,16 +22,16 @@ static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
     attr_done = true;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
   return check_launch("igemm");
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, int NWAVES>
 static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
-  if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, 4, 4>(p, grid, st);
-  if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, 4, 1>(p, grid, st);
-  if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, 1, 4>(p, grid, st);
-  return launch_one<BM, BN, WAVES_M, 1, 1>(p, grid, st);
+  if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, 4, 4>(p, grid, st);
+  if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, NWAVES, 4, 1>(p, grid, st);
+  if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, 1, 4>(p, grid, st);
+  return launch_one<BM, BN, WAVES_M, NWAVES, 1, 1>(p, grid, st);
 }
 
 #define A3D_CAT_(a, b) a##b
@@ -37,8 +39,8 @@ static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStre
 
 int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
   switch (cfg) {
-#define X(i, bm, bn, wm) \
-  case i: return launch_vec<bm, bn, wm>(avec, bvec, p, grid, st);
+#define X(i, bm, bn, wm, nw) \
+  case i: return launch_vec<bm, bn, wm, nw>(avec, bvec, p, grid, st);
     A3D_CFGS(X)
 #undef X
   }

@@ -121,7 +121,18 @@ __global__ __launch_bounds__(256) void stencil1_bwdf_kernel(const Stencil1Params
   for (int i = threadIdx.x; i < KS * KS * 64 + 1; i += 256) slab[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
-// out: dw[t][c] (c < C) and db from the [blocks][KS*KS*64+1] slabs
+// Two-level deterministic slab reduction.  Level 1: out[g][i] = sum of `per` consecutive slabs (grid.y = groups).
+__global__ __launch_bounds__(256) void stencil1_slab_group_kernel(const float* slabs, int blocks, int per, int width,
+                                                                  float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= width) return;
+  const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += slabs[(size_t)b * width + i];
+  out[(size_t)blockIdx.y * width + i] = s;
+}
+
+// Level 2: dw[t][c] (c < C) and db from the remaining [groups][taps*64+1] slabs
 __global__ __launch_bounds__(256) void stencil1_bwdf_reduce_kernel(const float* slabs, int blocks, int taps, int c,
                                                                    float* dw, float* db) {
   const int width = taps * 64 + 1;
@@ -138,6 +149,7 @@ __global__ __launch_bounds__(256) void stencil1_bwdf_reduce_kernel(const float* 
 }
 
 static const int kStencilBlocks = 1024;
+static const int kStencilGroup = 32;
 
 bool stencil1_applicable(const a3d_conv_desc* d) {
   return d->k == 1 && d->r == 5 && d->s == 5 && d->stride == 1 && d->c <= 64;
@@ -145,7 +157,7 @@ bool stencil1_applicable(const a3d_conv_desc* d) {
 
 size_t stencil1_bwdf_ws_bytes(const a3d_conv_desc* d) {
   (void)d;
-  return (size_t)kStencilBlocks * (25 * 64 + 1) * 4;
+  return (size_t)(kStencilBlocks + kStencilBlocks / kStencilGroup) * (25 * 64 + 1) * 4;
 }
 
 static Stencil1Params make_params(const a3d_conv_desc* d) {
@@ -176,9 +188,17 @@ int stencil1_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz,
   hipLaunchKernelGGL(stencil1_bwdf_kernel<5>, dim3(blocks), dim3(256), 0, st, p);
   int rc = check_launch("stencil1_bwd_filter");
   if (rc != A3D_OK) return rc;
+  const int width = 25 * 64 + 1;
+  const int groups = (blocks + kStencilGroup - 1) / kStencilGroup;
+  float* level1 = static_cast<float*>(ws) + (size_t)kStencilBlocks * width;
   clear_stale_error();
-  hipLaunchKernelGGL(stencil1_bwdf_reduce_kernel, dim3((25 * 64 + 1 + 255) / 256), dim3(256), 0, st,
-                     static_cast<const float*>(ws), blocks, 25, d->c, dw, db);
+  hipLaunchKernelGGL(stencil1_slab_group_kernel, dim3((width + 255) / 256, groups), dim3(256), 0, st,
+                     static_cast<const float*>(ws), blocks, kStencilGroup, width, level1);
+  rc = check_launch("stencil1_slab_group");
+  if (rc != A3D_OK) return rc;
+  clear_stale_error();
+  hipLaunchKernelGGL(stencil1_bwdf_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, st,
+                     static_cast<const float*>(level1), groups, 25, d->c, dw, db);
   return check_launch("stencil1_bwd_filter_reduce");
 }
 

@@ -55,7 +55,7 @@ def collect_timing(lib):
 
 
 def kernel_name(r):
-    return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.avec}, {r.bvec}>'
+    return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.nwaves}, {r.avec}, {r.bvec}>'
 
 
 def run_phase(net, img, dep, masks, steps, warmup, global_step, lib, world, timed_kernels):

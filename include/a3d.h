@@ -124,7 +124,7 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
  * and clears the list.  Not for use inside graph capture. */
 typedef struct a3d_timing_record {
   int32_t mode;        /* 0 fwd, 1 bwd-data, 2 bwd-filter */
-  int32_t bm, bn, waves_m, avec, bvec;   /* template arguments of igemm_kernel<mode,bm,bn,waves_m,avec,bvec> */
+  int32_t bm, bn, waves_m, nwaves, avec, bvec;   /* igemm_kernel<mode,bm,bn,waves_m,nwaves,avec,bvec> */
   int32_t splitk;
   int32_t m, n, k;     /* GEMM extents of the launch */
   float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */

@@ -16,7 +16,7 @@ LAYERS = [  # name, h, w, cin, cout, k, stride, pad
     ('fine2', 55, 74, 64, 64, 5, 1, 'SAME'), ('fine3', 55, 74, 64, 1, 5, 1, 'SAME'),
     ('dense_0', 1, 1, 12288, 4096, 1, 1, 'VALID'), ('dense_1', 1, 1, 4096, 4070, 1, 1, 'VALID'),
 ]
-CFGS = ['128x128', '128x96', '128x64', '128x32', '64x64', '32x128', '64x128']
+CFGS = ['128x128', '128x96', '128x64', '128x32', '64x64', '32x128', '64x128', '128x128w8', '128x64w8']
 
 
 def timeit(fn, reps=5):
@@ -31,8 +31,11 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e3     # us
 
 
+ALL = []
+
+
 def main():
-    only = sys.argv[1:] or None
+    only = [a for a in sys.argv[1:] if not a.startswith('--')] or None
     for name, h, w, c, k, ks, st, pad in LAYERS:
         if only and name not in only:
             continue
@@ -63,13 +66,21 @@ def main():
                     except Exception as e:   # noqa
                         continue
                     res.append((t, cn, sk))
-                    if t > 20 * t_auto:
+                    if t > 6 * t_auto and sk >= 64:
                         break
+            ALL.append({'layer': name, 'mode': mode, 'M': {'fwd': B * d.ho * d.wo, 'bwd_d': B * h * w, 'bwd_f': ks * ks * c}[mode],
+                        'N': {'fwd': k, 'bwd_d': c, 'bwd_f': k}[mode],
+                        'K': {'fwd': ks * ks * c, 'bwd_d': ks * ks * k, 'bwd_f': B * d.ho * d.wo}[mode],
+                        'auto_us': t_auto, 'results': [(cn, sk, t) for t, cn, sk in res]})
             res.sort()
             best = ' | '.join(f'{cn} sk{sk} {t:.0f}us {flops / t / 1e6:.0f}TF' for t, cn, sk in res[:6])
             print(f'{name:9s} {mode:6s} {flops / 1e9:6.2f}GF auto {t_auto:7.0f}us {flops / t_auto / 1e6:5.0f}TF || {best}', flush=True)
     os.environ.pop('A3D_FORCE_CFG', None)
     os.environ.pop('A3D_FORCE_SPLITK', None)
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'sweep_full.json')
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(ALL, open(out, 'w'))
 
 
 if __name__ == '__main__':
