@@ -46,7 +46,7 @@ def main(argv=None):
     rank, local_rank, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise RuntimeError('ann3depth_amd needs an MI355X: the training path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     chief = rank == 0
     logger.info(f'Task: {rank} of {world} -- Chief? {chief}')
 

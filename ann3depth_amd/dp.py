@@ -43,8 +43,8 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'    # 'nccl' is RCCL on ROCm
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+            backend = os.environ.get('A3D_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():                                    # 'nccl' is RCCL on ROCm
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world

@@ -145,7 +145,7 @@ def main():
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run',
                   file=sys.stderr)
         sys.exit(2)
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     B = args.batch
     reducer = dp.GradReducer() if world > 1 else None
