@@ -75,9 +75,9 @@ struct IgemmParams {
   int tiles_m, tiles_n;
 };
 
-template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
 struct IgemmCfg {
-  static constexpr int BK = 32;
+  static constexpr int BK = BKT;
   static constexpr int NT = 64 * NWAVES;
   static constexpr int WAVES_N = NWAVES / WAVES_M;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -148,11 +148,13 @@ struct Im2colTile {
   static_assert(NT % CPR == 0, "cpr");
   static constexpr int RPP = NT / CPR;
   static constexpr int NL = (ROWS + RPP - 1) / RPP;
-  static_assert(ROWS % RPP == 0, "rows");
+  static constexpr bool PARTIAL = RPP > ROWS;      // fewer chunks than threads: the upper threads idle
+  static_assert(PARTIAL || ROWS % RPP == 0, "rows");
 
   __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const IgemmParams& p, const int4* pixtab,
                                               const ColDec& cd, int tid) {
     const int r0 = tid / CPR;
+    if (PARTIAL && r0 >= ROWS) return;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int4 pt = pixtab[r0 + j * RPP];
@@ -177,6 +179,7 @@ struct Im2colTile {
   }
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
     const int r0 = tid / CPR, cq = tid % CPR;
+    if (PARTIAL && r0 >= ROWS) return;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
@@ -237,11 +240,13 @@ template <int NT, int ROWS, int COLS, int VEC>
 struct FilterTTile {
   static constexpr int CPR = COLS / VEC;
   static constexpr int RPP = NT / CPR;
-  static constexpr int NL = ROWS / RPP;
-  static_assert(ROWS % RPP == 0, "rows");
+  static constexpr int NL = (ROWS + RPP - 1) / RPP;
+  static constexpr bool PARTIAL = RPP > ROWS;
+  static_assert(PARTIAL || ROWS % RPP == 0, "rows");
   __device__ __forceinline__ static void load(float (&regs)[NL][VEC], const IgemmParams& p, int n0, int kcol,
                                               int tid) {
     const int r0 = tid / CPR;
+    if (PARTIAL && r0 >= ROWS) return;
     bool kvalid = kcol < p.K;
     uint32_t k = kvalid ? (uint32_t)kcol : 0u;
     uint32_t rs = fdiv(k, p.div_c);              // div_c.d == Cout here
@@ -263,6 +268,7 @@ struct FilterTTile {
   }
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
     const int r0 = tid / CPR, cq = tid % CPR;
+    if (PARTIAL && r0 >= ROWS) return;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
@@ -276,9 +282,9 @@ struct FilterTTile {
   }
 };
 
-template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
-__global__ __launch_bounds__(64 * NWAVES, NWAVES / 2) void igemm_kernel(const IgemmParams p) {
-  using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
+__global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void igemm_kernel(const IgemmParams p) {
+  using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, NWAVES, BKT, AVEC, BVEC>;
   constexpr int NT = Cfg::NT;
   constexpr int BK = Cfg::BK;
   constexpr int TM = Cfg::TM, TN = Cfg::TN;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 2) void igemm_kernel(const Ig
   const int tile_m = tmn / p.tiles_n, tile_n = tmn - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int nk_total = (p.K + BK - 1) / BK;
+  const int nk_total = (p.K + BK - 1) / BK;      // p.ktiles_per_split is in units of this kernel's BK
   const int kt_begin = split * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nk_total) kt_end = nk_total;
@@ -416,6 +422,9 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 2) void igemm_kernel(const Ig
       // the next tile's global loads were issued before chunk 0; park them in the other LDS buffer ahead of the
       // last chunk's MFMAs so that only the barrier is left at the end of the tile
       if (u == BK / 8 - 1 && more) store_tiles(cur ^ 1);
+#ifdef A3D_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -423,6 +432,9 @@ __global__ __launch_bounds__(64 * NWAVES, NWAVES / 2) void igemm_kernel(const Ig
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+#ifdef A3D_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     __syncthreads();
     cur ^= 1;

@@ -17,11 +17,13 @@ int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned gri
 
 struct TileCfg {
   int bm, bn;
-  float eff;   // relative MFMA efficiency of the tile shape (bigger tiles amortise LDS traffic better)
+  float eff;   // relative efficiency of the configuration, fitted (tools/fit_planner.py); 0 = only via A3D_FORCE_CFG
+  int bk;
 };
-static const TileCfg kCfgs[] = {{128, 128, 1.00f}, {128, 96, 1.00f}, {128, 64, 0.92f}, {128, 32, 0.60f},
-                                {64, 64, 0.98f},   {32, 128, 0.90f}, {64, 128, 1.00f}, {128, 128, 1.15f},
-                                {128, 64, 1.05f}};  // last two: 8-wave blocks (4 waves per SIMD at 2 blocks/CU)
+static const TileCfg kCfgs[] = {{128, 128, 1.00f, 32}, {128, 96, 1.00f, 32}, {128, 64, 0.92f, 32}, {128, 32, 0.60f, 32},
+                                {64, 64, 0.98f, 32},   {32, 128, 0.90f, 32}, {64, 128, 1.00f, 32},
+                                {128, 128, 1.15f, 32}, {128, 64, 1.05f, 32},      // 8-wave blocks
+                                {128, 128, 0.0f, 16},  {128, 64, 0.0f, 16}};      // 8-wave, BK = 16 (experimental)
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -34,8 +36,8 @@ struct TimingSlot {
 static std::mutex g_timing_mu;
 static bool g_timing_on = false;
 static std::vector<TimingSlot> g_timing;
-static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4};
-static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8};
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
+static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
 
 // Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
 static int env_int(const char* name, int dflt) {
@@ -50,6 +52,7 @@ GemmPlan plan_gemm(const GemmProblem& g) {
   const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
+    const int nk = (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk;
     int splitk = std::max(1, std::min(force_split > 0 ? force_split : 1, nk));
     while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
     int kps = (nk + splitk - 1) / splitk;

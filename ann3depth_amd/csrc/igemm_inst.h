@@ -5,15 +5,15 @@
 
 namespace a3d {
 
-// index, BM, BN, WAVES_M, NWAVES  (keep in step with kCfgs in igemm_host.hip)
-#define A3D_CFGS(X) X(0, 128, 128, 2, 4) X(1, 128, 96, 4, 4) X(2, 128, 64, 4, 4) X(3, 128, 32, 4, 4) \
-                    X(4, 64, 64, 2, 4) X(5, 32, 128, 1, 4) X(6, 64, 128, 1, 4) X(7, 128, 128, 4, 8) \
-                    X(8, 128, 64, 4, 8)
+// index, BM, BN, WAVES_M, NWAVES, BK  (keep in step with kCfgs in igemm_host.hip)
+#define A3D_CFGS(X) X(0, 128, 128, 2, 4, 32) X(1, 128, 96, 4, 4, 32) X(2, 128, 64, 4, 4, 32) X(3, 128, 32, 4, 4, 32) \
+                    X(4, 64, 64, 2, 4, 32) X(5, 32, 128, 1, 4, 32) X(6, 64, 128, 1, 4, 32) X(7, 128, 128, 4, 8, 32) \
+                    X(8, 128, 64, 4, 8, 32) X(9, 128, 128, 4, 8, 16) X(10, 128, 64, 4, 8, 16)
 
-template <int BM, int BN, int WAVES_M, int NWAVES, int AVEC, int BVEC>
+template <int BM, int BN, int WAVES_M, int NWAVES, int BK, int AVEC, int BVEC>
 static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
-  using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
-  auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES, AVEC, BVEC>;
+  using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, NWAVES, BK, AVEC, BVEC>;
+  auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES, BK, AVEC, BVEC>;
   static bool attr_done = false;   // idempotent attribute, benign if set twice
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -26,12 +26,12 @@ static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
   return check_launch("igemm");
 }
 
-template <int BM, int BN, int WAVES_M, int NWAVES>
+template <int BM, int BN, int WAVES_M, int NWAVES, int BK>
 static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
-  if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, 4, 4>(p, grid, st);
-  if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, NWAVES, 4, 1>(p, grid, st);
-  if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, 1, 4>(p, grid, st);
-  return launch_one<BM, BN, WAVES_M, NWAVES, 1, 1>(p, grid, st);
+  if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 4, 4>(p, grid, st);
+  if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 4, 1>(p, grid, st);
+  if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 1, 4>(p, grid, st);
+  return launch_one<BM, BN, WAVES_M, NWAVES, BK, 1, 1>(p, grid, st);
 }
 
 #define A3D_CAT_(a, b) a##b
@@ -39,8 +39,8 @@ static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStre
 
 int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
   switch (cfg) {
-#define X(i, bm, bn, wm, nw) \
-  case i: return launch_vec<bm, bn, wm, nw>(avec, bvec, p, grid, st);
+#define X(i, bm, bn, wm, nw, bk) \
+  case i: return launch_vec<bm, bn, wm, nw, bk>(avec, bvec, p, grid, st);
     A3D_CFGS(X)
 #undef X
   }
