@@ -72,7 +72,7 @@ GemmPlan plan_gemm(const GemmProblem& g) {
     const long tiles = (long)tm * tn;
     for (int want = 1; want <= 256; want *= 2) {
       if (want > 1 && want > nk / 2) break;
-      if ((size_t)want * g.M * g.N * 4 > kMaxSlabBytes) break;
+      if (want > 1 && (size_t)want * g.M * g.N * 4 > kMaxSlabBytes) break;
       const int kps = (nk + want - 1) / want;
       const int splitk = (nk + kps - 1) / kps;
       const long blocks = tiles * splitk;

@@ -261,6 +261,20 @@ def test_adam_frozen_path_poison_semantics(ops):
     assert np.isnan(ref['w']).sum() == 5 and np.isnan(opt.v['w']).sum() == 5
 
 
+def test_large_problem_plans_without_split(ops):
+    """An output larger than the split-K slab budget (DCNF conv2d at batch 16: 1.6 GB) must still get a plan."""
+    n = 96
+    d = ops.conv_desc(n, 100, 100, 3, 64, 11, 11, 1, 'VALID')
+    x = torch.randn((n, 100, 100, 3), device='cuda')
+    w = torch.randn((11, 11, 3, 64), device='cuda') * 0.05
+    y = torch.empty((n, 90, 90, 64), device='cuda')
+    ops.conv2d_fwd(d, x, w, None, y, None)
+    ref = T.conv2d_fwd(x[:2].cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64), None, 1, 'VALID')
+    assert rel_l2(y[:2].cpu().numpy(), ref) < RTOL_F32
+    ref = T.conv2d_fwd(x[-1:].cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64), None, 1, 'VALID')
+    assert rel_l2(y[-1:].cpu().numpy(), ref) < RTOL_F32
+
+
 def test_bad_arguments_fail_loudly(ops):
     from ann3depth_amd._lib import A3dError
     x = torch.zeros((1, 8, 8, 4), device='cuda')
