@@ -5,9 +5,10 @@ dataset name with a default, and ``inputs(datadir, dataset, batch_size, train_or
 The reference builds TF queue ops: ``string_input_producer`` (one file, no file shuffle, src/data.py:35-38) ->
 ``TFRecordReader`` (:18,62-67) -> ``_convert_img_depth`` (:70-86) -> ``shuffle_batch(capacity=20B,
 min_after_dequeue=5B, num_threads=2)`` (:51-55).  Here the same stages run on host threads over a memory-mapped
-file, with CRC / protobuf / decode in liba3d.so (the GIL is released inside those calls) and batches assembled in
-pinned memory for asynchronous H2D copies.  With world_size > 1 each rank reads the records whose index is
-congruent to its rank.
+file: CRC check, protobuf parse and ``decode_raw + 0.5`` happen in liba3d.so (GIL released) and write straight
+into a slot of a staging pool; the shuffle queue holds slot numbers, so a record is copied exactly once on the host
+(into pinned memory when a GPU consumer asks for it) and then DMA'd to HBM.  With world_size > 1 each rank reads the
+records whose index is congruent to its rank.
 """
 import collections
 import os
@@ -32,11 +33,14 @@ def _read(files, epochs, rank=0, world=1):
     """TFRecordReader over string_input_producer(files, num_epochs=epochs, shuffle=False): yields
     (RecordFile, offset, length); epochs=None cycles forever."""
     epoch = 0
+    handles = {}
     while epochs is None or epoch < epochs:
         n = 0
         for path in files:
-            rf = tfrecord.RecordFile(path)
-            for i, (off, ln) in enumerate(rf):
+            rf = handles.get(path)
+            if rf is None:
+                rf = handles[path] = tfrecord.RecordFile(path)
+            for i, (off, ln) in enumerate(rf.frames()):     # payload CRCs are checked by the reader threads
                 if i % world == rank:
                     n += 1
                     yield rf, off, ln
@@ -45,8 +49,10 @@ def _read(files, epochs, rank=0, world=1):
         epoch += 1
 
 
-def _convert_img_depth(rf, off, ln):
-    return rf.parse(off, ln)                                                # src/data.py:70-86
+def _convert_img_depth(rf, off, ln, image, depth):
+    """src/data.py:70-86, decoding into the destination arrays (after the record's payload CRC check)."""
+    rf.verify_payload(off, ln)
+    rf.parse_into(off, ln, image, depth)
 
 
 def _get_pipeline(dataset):
@@ -55,16 +61,27 @@ def _get_pipeline(dataset):
     return pipelines.get(dataset, default)
 
 
+def default_reader_threads():
+    """The reference uses num_threads=2 (src/data.py:55), enough for a 2017 GPU; an MI355X eats ~8k records/s."""
+    env = os.environ.get('A3D_READER_THREADS')
+    return int(env) if env else max(2, min(16, (os.cpu_count() or 2) // 2))
+
+
 class ShuffleBatch:
     """tf.train.shuffle_batch: a bounded random-shuffle queue fed by `num_threads` producer threads.
-    next_batch() blocks until more than min_after_dequeue elements would remain (or the producers finished), then
-    removes batch_size uniformly chosen elements."""
+    dequeue() blocks until more than min_after_dequeue elements would remain (or the producers finished), then
+    removes batch_size uniformly chosen elements.  Elements live in a slot pool (`images[slot]`, `depths[slot]`);
+    the consumer gives slots back with release()."""
 
-    def __init__(self, records, convert, batch_size, capacity, min_after_dequeue, num_threads=2, seed=None):
+    def __init__(self, records, convert, batch_size, capacity, min_after_dequeue, num_threads=2, seed=None,
+                 in_flight_batches=3):
         self.records, self.convert = records, convert
         self.B, self.capacity, self.min_after = batch_size, capacity, min_after_dequeue
+        self.nslots = capacity + in_flight_batches * batch_size
         self.rng = np.random.default_rng(seed)
-        self.queue = []
+        self.queue = []                       # filled slot numbers
+        self.free = None                      # free slot numbers (after allocate())
+        self.images = self.depths = None
         self.cv = threading.Condition()
         self.src_lock = threading.Lock()
         self.live = num_threads
@@ -72,24 +89,57 @@ class ShuffleBatch:
         self.closed = False
         self.threads = [threading.Thread(target=self._produce, daemon=True) for _ in range(num_threads)]
         self.started = False
+        self.first = None
+
+    # ---- staging pool ----
+    def shapes(self):
+        """(image shape, depth shape) of the dataset, from its first record."""
+        if self.first is None:
+            try:
+                self.first = next(self.records)
+            except StopIteration:
+                raise OutOfRangeError('empty dataset')
+        rf, off, ln = self.first
+        rf.verify_payload(off, ln)
+        _, ishape, dshape = rf.header(off, ln)
+        return ishape, dshape
+
+    def allocate(self, alloc=None):
+        """Create the slot pool.  alloc(shape) -> float32 ndarray; default plain numpy, a GPU consumer passes an
+        allocator of pinned memory."""
+        if self.images is not None:
+            return
+        ishape, dshape = self.shapes()
+        alloc = alloc or (lambda shape: np.empty(shape, np.float32))
+        self.images = alloc((self.nslots,) + tuple(ishape))
+        self.depths = alloc((self.nslots,) + tuple(dshape))
+        self.free = collections.deque(range(self.nslots))
+
+    def _next_record(self):
+        with self.src_lock:                    # the reader op is shared: each record goes to exactly one thread
+            if self.first is not None:
+                rec, self.first = self.first, None
+                return rec
+            return next(self.records)
 
     def _produce(self):
         try:
             while True:
-                with self.src_lock:                 # the reader op is shared: each record goes to one thread
-                    try:
-                        rec = next(self.records)
-                    except StopIteration:
-                        break
-                item = self.convert(*rec)           # CRC-checked parse + decode in C, outside the GIL
+                try:
+                    rec = self._next_record()
+                except StopIteration:
+                    break
                 with self.cv:
-                    while len(self.queue) >= self.capacity and not self.closed:
+                    while (len(self.queue) >= self.capacity or not self.free) and not self.closed:
                         self.cv.wait()
                     if self.closed:
                         return
-                    self.queue.append(item)
+                    slot = self.free.popleft()
+                self.convert(*rec, self.images[slot], self.depths[slot])      # C code, outside the GIL
+                with self.cv:
+                    self.queue.append(slot)
                     self.cv.notify_all()
-        except BaseException as e:                  # surfaced by next_batch(): never swallow a corrupt record
+        except BaseException as e:                  # surfaced by dequeue(): never swallow a corrupt record
             with self.cv:
                 self.error = e
         finally:
@@ -99,6 +149,7 @@ class ShuffleBatch:
 
     def start(self):
         if not self.started:
+            self.allocate()
             self.started = True
             for t in self.threads:
                 t.start()
@@ -108,7 +159,8 @@ class ShuffleBatch:
             self.closed = True
             self.cv.notify_all()
 
-    def next_batch(self, out_images=None, out_depths=None):
+    def dequeue(self):
+        """-> list of batch_size slot numbers (their contents stay valid until release())."""
         self.start()
         with self.cv:
             while True:
@@ -127,15 +179,23 @@ class ShuffleBatch:
                 self.queue[i], self.queue[-1] = self.queue[-1], self.queue[i]
                 picks.append(self.queue.pop())
             self.cv.notify_all()
-        ishape, dshape = picks[0][0].shape, picks[0][1].shape
+        return picks
+
+    def release(self, slots):
+        with self.cv:
+            self.free.extend(slots)
+            self.cv.notify_all()
+
+    def next_batch(self, out_images=None, out_depths=None):
+        """Dequeue into freshly stacked (or caller-provided) host arrays: ([B,H,W,3], [B,H',W',1]) float32."""
+        slots = self.dequeue()
         if out_images is None:
-            out_images = np.empty((self.B,) + ishape, np.float32)
-            out_depths = np.empty((self.B,) + dshape, np.float32)
-        for b, (img, dep) in enumerate(picks):
-            if img.shape != ishape or dep.shape != dshape:
-                raise ValueError(f'records of different sizes cannot be batched: {img.shape} vs {ishape}')
-            out_images[b] = img
-            out_depths[b] = dep
+            out_images = np.empty((self.B,) + self.images.shape[1:], np.float32)
+            out_depths = np.empty((self.B,) + self.depths.shape[1:], np.float32)
+        for b, s in enumerate(slots):
+            out_images[b] = self.images[s]
+            out_depths[b] = self.depths[s]
+        self.release(slots)
         return out_images, out_depths
 
 
@@ -146,9 +206,10 @@ class BatchHandle:
         self.pipeline, self.index = pipeline, index
 
 
-def inputs(datadir, dataset, batch_size=32, train_or_test='train', epochs=None, rank=0, world=1, seed=None):
+def inputs(datadir, dataset, batch_size=32, train_or_test='train', epochs=None, rank=0, world=1, seed=None,
+           num_threads=None):
     """src/data.py:28-55.  Returns (inputs, targets) handles; `inputs.pipeline.next_batch()` dequeues
-    ([B,H,W,3], [B,H',W',1]) float32 arrays."""
+    ([B,H,W,3], [B,H',W',1]) float32 arrays, `.dequeue()` the slots of the staging pool."""
     epochs = epochs if train_or_test == 'train' else 1
     pipeline = _get_pipeline(dataset)
     base_dir = os.path.join(datadir, dataset)
@@ -158,5 +219,6 @@ def inputs(datadir, dataset, batch_size=32, train_or_test='train', epochs=None, 
             raise FileNotFoundError(f)
     records = pipeline.reader(files, epochs, rank, world)
     sb = ShuffleBatch(records, pipeline.convert, batch_size, capacity=20 * batch_size,
-                      min_after_dequeue=5 * batch_size, num_threads=2, seed=seed)
+                      min_after_dequeue=5 * batch_size, num_threads=num_threads or default_reader_threads(),
+                      seed=seed)
     return BatchHandle(sb, 0), BatchHandle(sb, 1)

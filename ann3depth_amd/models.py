@@ -440,29 +440,68 @@ class DCNFUnary:
 # plugin surface: models.msdn / models.dcnf  (src/models.py:370-371)
 # =====================================================================================================
 class TrainOp:
-    """What `model(inputs, targets)` returns: run() is one `session.run(train_op)` — dequeue a batch, copy it to
-    HBM, draw the dropout mask, run the replica's step."""
+    """What `model(inputs, targets)` returns: run() is one `session.run(train_op)`.
+
+    Input side: the shuffle queue's staging pool is pinned memory; a dequeued batch is B slot numbers, DMA'd to HBM
+    on a side stream into one of two device batch buffers.  Batch k+1 is in flight while step k computes, so host
+    decode, PCIe transfer and the training step overlap."""
 
     def __init__(self, replica, pipeline, seed=0):
         self.replica, self.pipeline, self.seed = replica, pipeline, seed
-        self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=replica.device)
-        self.host = None
-        self.dev = None
+        dev = replica.device
+        self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=dev)
+        pipeline.allocate(lambda shape: torch.empty(shape, dtype=torch.float32).pin_memory().numpy())
+        self.pool = (torch.from_numpy(pipeline.images), torch.from_numpy(pipeline.depths))      # pinned views
+        self.dev = [tuple(torch.empty((replica.B,) + tuple(p.shape[1:]), device=dev) for p in self.pool)
+                    for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.copied = [None, None]          # event: the DMA into buffer i finished
+        self.consumed = [None, None]        # event: the step that read buffer i finished
+        self.held = [[], []]                # pool slots buffer i was filled from
+        self.k = 0                          # batches consumed
+        self.end = None                     # (batch index, exception) once the pipeline ran dry
         self.last = None
+        self._prefetch(0)
+        self._prefetch(1)
+
+    def _prefetch(self, j):
+        """Dequeue batch j and start its DMA into device buffer j & 1 on the copy stream."""
+        if self.end is not None:
+            return
+        i = j & 1
+        try:
+            slots = self.pipeline.dequeue()
+        except BaseException as e:          # raised to the caller when batch j would have been consumed
+            self.end = (j, e)
+            return
+        if self.consumed[i] is not None:
+            self.copy_stream.wait_event(self.consumed[i])
+        with torch.cuda.stream(self.copy_stream):
+            for b, s in enumerate(slots):
+                self.dev[i][0][b].copy_(self.pool[0][s], non_blocking=True)
+                self.dev[i][1][b].copy_(self.pool[1][s], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.copied[i] = ev
+        self.held[i] = slots
 
     def run(self):
         r = self.replica
-        if self.host is None:
-            img, dep = self.pipeline.next_batch()
-            self.host = (torch.from_numpy(img).pin_memory(), torch.from_numpy(dep).pin_memory())
-            self.dev = (torch.empty(img.shape, device=r.device), torch.empty(dep.shape, device=r.device))
-        else:
-            torch.cuda.current_stream().synchronize()      # previous H2D finished reading the pinned buffers
-            self.pipeline.next_batch(self.host[0].numpy(), self.host[1].numpy())
-        self.dev[0].copy_(self.host[0], non_blocking=True)
-        self.dev[1].copy_(self.host[1], non_blocking=True)
+        i = self.k & 1
+        if self.end is not None and self.end[0] == self.k:
+            raise self.end[1]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.copied[i])
         ops.dropout_keep_mask(self.keep, self.seed, r.global_step)
-        self.last = r.step(self.dev[0], self.dev[1], self.keep)
+        self.last = r.step(self.dev[i][0], self.dev[i][1], self.keep)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.consumed[i] = ev
+        self.copied[i].synchronize()        # issued a whole step ago: the staging slots can go back to the readers
+        self.pipeline.release(self.held[i])
+        self.held[i] = []
+        self.k += 1
+        self._prefetch(self.k + 1)          # into the buffer this step just read; the DMA waits for `consumed`
         return self.last
 
     @property

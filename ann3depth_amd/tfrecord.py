@@ -74,9 +74,26 @@ class RecordFile:
             yield pos + off.value, ln.value
             pos += used.value
 
-    def parse(self, offset, length):
-        """data._convert_img_depth (src/data.py:70-86): -> (image [H,W,C], depth [H,W,C']) float32 with '+ 0.5'.
-        Sizes come from the record's own size features (the reference hard-codes 480x640)."""
+    def frames(self):
+        """Like iteration, but only the 12-byte length header of each frame is checked (cheap, serial); the payload
+        CRC is left to verify_payload(), which reader threads run in parallel."""
+        lib = _lib.load()
+        pos = 0
+        off, ln, used = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        while pos < self.size:
+            check(lib.a3d_tfrecord_next(self.base + pos, self.size - pos, 0, ctypes.byref(off), ctypes.byref(ln),
+                                        ctypes.byref(used)), f'a3d_tfrecord_next({self.path}@{pos})')
+            yield pos + off.value, ln.value
+            pos += used.value
+
+    def verify_payload(self, offset, length):
+        lib = _lib.load()
+        want = int.from_bytes(self.mm[offset + length:offset + length + 4], 'little')
+        if lib.a3d_masked_crc32c(self.base + offset, length) != want:
+            raise _lib.A3dError(f'{self.path}: corrupt payload at offset {offset}')
+
+    def header(self, offset, length):
+        """Parse the Example at (offset, length): -> (ExampleView, image shape, depth shape)."""
         lib = _lib.load()
         ev = ExampleView()
         check(lib.a3d_example_parse(self.base + offset, length, ctypes.byref(ev)), 'a3d_example_parse')
@@ -85,10 +102,26 @@ class RecordFile:
         if ev.image_bytes != 4 * int(np.prod(ishape)) or ev.depth_bytes != 4 * int(np.prod(dshape)):
             raise _lib.A3dError(f'{self.path}: feature byte counts do not match the size features '
                                 f'({ev.image_bytes} vs {ishape}, {ev.depth_bytes} vs {dshape})')
-        image = np.empty(ishape, np.float32)
-        depth = np.empty(dshape, np.float32)
+        return ev, ishape, dshape
+
+    def parse_into(self, offset, length, image, depth):
+        """data._convert_img_depth (src/data.py:70-86) straight into caller-owned float32 arrays (e.g. slots of a
+        pinned staging pool): decode_raw + reshape + '+ 0.5'."""
+        lib = _lib.load()
+        ev, ishape, dshape = self.header(offset, length)
+        if tuple(image.shape) != ishape or tuple(depth.shape) != dshape:
+            raise ValueError(f'{self.path}: record is {ishape}/{dshape}, destination is '
+                             f'{tuple(image.shape)}/{tuple(depth.shape)}: records of different sizes cannot be batched')
         check(lib.a3d_decode_raw_plus_half(ev.image, ev.image_bytes, image.ctypes.data), 'a3d_decode_raw_plus_half')
         check(lib.a3d_decode_raw_plus_half(ev.depth, ev.depth_bytes, depth.ctypes.data), 'a3d_decode_raw_plus_half')
+
+    def parse(self, offset, length):
+        """-> (image [H,W,C], depth [H,W,C']) float32 with '+ 0.5'.  Sizes come from the record's own size features
+        (the reference hard-codes 480x640, src/data.py:84-85)."""
+        _, ishape, dshape = self.header(offset, length)
+        image = np.empty(ishape, np.float32)
+        depth = np.empty(dshape, np.float32)
+        self.parse_into(offset, length, image, depth)
         return image, depth
 
 

@@ -41,9 +41,10 @@ def test_train_op_matches_oracle_on_a_dequeued_batch(tmp_path):
     write_shard(str(tmp_path))
     inputs, targets = data.inputs(str(tmp_path), 'nyu', 4, seed=3)
     op = models.msdn(inputs, targets)
-    out = op.run()
+    op.copied[0].synchronize()                       # batch 0 has landed in device buffer 0 (prefetched)
+    img, dep = op.dev[0][0].cpu().numpy(), op.dev[0][1].cpu().numpy()
+    out = op.run()                                   # consumes it; the buffer is refilled with batch 2 afterwards
     torch.cuda.synchronize()
-    img, dep = op.dev[0].cpu().numpy(), op.dev[1].cpu().numpy()
     assert img.shape == (4, 48, 64, 3) and dep.shape == (4, 6, 8, 1)
     assert img.min() >= 0 and img.max() <= 1                               # '+0.5' applied: k/255
     keep = op.keep.cpu().numpy().astype(bool)

@@ -152,10 +152,11 @@ def test_inputs_pipeline_semantics(tmp_path):
     capacity 20B / min_after_dequeue 5B, every record seen once per epoch, '+0.5' applied."""
     B, n = 4, 64
     samples = _write_dataset(str(tmp_path), 'nyu', n, 6, 8, 3, 4)
-    inp, tgt = data.inputs(str(tmp_path), 'nyu', B, epochs=1, seed=7)
+    inp, tgt = data.inputs(str(tmp_path), 'nyu', B, epochs=1, seed=7, num_threads=2)
     assert inp.pipeline is tgt.pipeline and (inp.index, tgt.index) == (0, 1)
     sb = inp.pipeline
-    assert (sb.capacity, sb.min_after, len(sb.threads)) == (20 * B, 5 * B, 2)
+    assert (sb.capacity, sb.min_after, len(sb.threads)) == (20 * B, 5 * B, 2)       # src/data.py:51-55
+    assert sb.shapes() == ((6, 8, 3), (3, 4, 1))
     seen = []
     while True:
         try:
