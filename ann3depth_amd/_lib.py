@@ -13,7 +13,7 @@ class A3dError(RuntimeError):
 class ConvDesc(ctypes.Structure):
     """struct a3d_conv_desc"""
     _fields_ = [(n, c_int32) for n in ('n', 'h', 'w', 'c', 'k', 'r', 's', 'stride', 'pad_t', 'pad_l', 'ho', 'wo',
-                                       'ldx', 'ldy')]
+                                       'ldx', 'ldy', 'precision')]
 
 
 class ExampleView(ctypes.Structure):
@@ -25,7 +25,7 @@ class ExampleView(ctypes.Structure):
 
 class TimingRecord(ctypes.Structure):
     """struct a3d_timing_record"""
-    _fields_ = [(n, c_int32) for n in ('mode', 'bm', 'bn', 'waves_m', 'nwaves', 'avec', 'bvec', 'splitk', 'm', 'n', 'k')] + \
+    _fields_ = [(n, c_int32) for n in ('mode', 'bm', 'bn', 'waves_m', 'nwaves', 'bk', 'avec', 'bvec', 'prec', 'splitk', 'm', 'n', 'k')] + \
                [('ms', c_float), ('flops', ctypes.c_double)]
 
 

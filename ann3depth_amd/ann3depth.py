@@ -83,6 +83,7 @@ def setup_model(args, rank=0, world=1):
         model.reducer = dp.GradReducer()
     if args.beta2 is not None:
         model.beta2 = args.beta2
+    model.precision = args.precision
     inputs, targets = data.inputs(args.datadir, args.dataset, args.batchsize, rank=rank, world=world,
                                   seed=args.seed + rank)
     return model(inputs, targets)
@@ -221,6 +222,8 @@ def parse_args(argv=None):
     parser.add_argument('--task-index', default=0, type=int, help='(ignored) rank comes from the launcher.')
     parser.add_argument('--beta2', default=None, type=float,
                         help='NON-REFERENCE: Adam beta2 (the reference hard-codes 1, which freezes the weights).')
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+                        help='NON-REFERENCE unless fp32: arithmetic of the conv contractions.')
     parser.add_argument('--seed', default=0, type=int, help='Shuffle-queue seed.')
     parser.add_argument('--trace-every', default=5000, type=int,
                         help='TraceHook period (src/ann3depth.py:105); traces are taken with rocprofv3 externally.')

@@ -27,6 +27,8 @@ inline int check_launch(const char* what) {
 
 // ---- implicit-GEMM front end (igemm_host.hip) ----
 struct GemmPlan {
+  int prec;          // A3D_PREC_*: 0 = fp32 kernel (cfg valid), else bf16 kernel (bf16_bn valid)
+  int bf16_bn;       // 128 or 64
   int cfg;           // index into the config table
   int splitk;
   int ktiles_per_split;
@@ -40,7 +42,7 @@ struct GemmProblem {
   int avec, bvec;    // 1 or 4
 };
 
-GemmPlan plan_gemm(const GemmProblem& g);
+GemmPlan plan_gemm(const GemmProblem& g, int precision = 0);
 
 struct IgemmParams;
 int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st);

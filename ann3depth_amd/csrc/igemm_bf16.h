@@ -1,0 +1,294 @@
+// igemm_bf16.h — the implicit-GEMM convolution of igemm.h on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
+// for fp32 tensors in HBM.  Two precisions:
+//   X3 = false : operands rounded to bf16, fp32 accumulate (BASELINE config 5's compute: ~3 significant digits).
+//   X3 = true  : each fp32 operand split into hi = bf16(x), lo = bf16(x - hi); products hi*hi + hi*lo + lo*hi
+//                (the lo*lo term, 2^-16 relative, is dropped).  ~1e-5 relative accuracy at 16/3 x the fp32 MFMA rate.
+// Same three contraction modes, pixel tables, loaders, XCD-aware tile order, split-K and epilogues as the fp32 kernel;
+// what changes is the staging: fp32 global -> registers -> convert -> bf16 planes in LDS, and the fragment reads.
+// MFMA 32x32x16 wants 8 consecutive k per lane for BOTH operands:
+//   * operands whose tile is k-contiguous in memory (im2col rows in FWD / BWD_D, the filter in BWD_D) are stored
+//     [row][k] and read with one ds_read_b128 per fragment (row stride 80 B: conflict-free);
+//   * operands whose tile has k as the SLOW axis (filter [k][n] in FWD; im2col [pixel][rsc] and dz [pixel][n] in
+//     BWD_F) are stored as they arrive and read with the hardware-transposing ds_read_b64_tr_b16 (two per fragment;
+//     row stride = cols + 32 elements puts the 4 rows of a block 16 banks apart: conflict-free).
+#pragma once
+#include "igemm.h"
+
+namespace a3d {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int BM, int BN, bool X3>
+struct Bf16Cfg {
+  static constexpr int BK = 32;
+  static constexpr int NWAVES = 8, NT = 512, WAVES_M = 4, WAVES_N = 2;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(TM == 1 && TN >= 1 && TN * 32 * WAVES_N == BN, "tile");
+  static constexpr bool A_KC = (MODE != MODE_BWD_F);     // A tile k-contiguous?
+  static constexpr bool B_KC = (MODE == MODE_BWD_D);
+  static constexpr int A_ROWS = A_KC ? BM : BK, A_COLS = A_KC ? BK : BM;     // same tile shapes as the fp32 kernel
+  static constexpr int B_ROWS = B_KC ? BN : BK, B_COLS = B_KC ? BK : BN;
+  static constexpr int A_LD = A_KC ? BK + 8 : BM + 32;                         // bf16 elements
+  static constexpr int B_LD = B_KC ? BK + 8 : BN + 32;
+  static constexpr int A_ELEMS = A_ROWS * A_LD, B_ELEMS = B_ROWS * B_LD;
+  static constexpr int PLANES = X3 ? 2 : 1;
+  static constexpr int BUF_ELEMS = PLANES * (A_ELEMS + B_ELEMS);
+  static constexpr int PIX = A_ROWS;
+  static constexpr size_t TILE_BYTES = (size_t)2 * BUF_ELEMS * 2;
+  static constexpr size_t LDS_BYTES = TILE_BYTES + (size_t)2 * PIX * 16;
+  static_assert((A_ELEMS * 2) % 16 == 0 && (B_ELEMS * 2) % 16 == 0, "plane alignment");
+  static_assert(TILE_BYTES >= (size_t)(NT / (BN / 4)) * BN * 4, "bias-gradient scratch must fit in the tile buffers");
+};
+
+// fp32 registers of a loader tile -> bf16 plane(s), same [row][col] orientation as the global tile
+template <class Tile, bool X3, bool PLAIN>
+__device__ __forceinline__ void store_bf16(const float (&regs)[Tile::NL][4], __bf16* hi, __bf16* lo, int ld, int tid) {
+#pragma unroll
+  for (int j = 0; j < Tile::NL; ++j) {
+    int row, cq;
+    if constexpr (PLAIN) {
+      const int idx = tid + j * 512;
+      if (Tile::TOTAL % 512 != 0 && idx >= Tile::TOTAL) continue;
+      row = idx / Tile::CPR;
+      cq = idx % Tile::CPR;
+    } else {
+      static_assert(!Tile::PARTIAL, "tile must cover all threads");
+      row = tid / Tile::CPR + j * Tile::RPP;
+      cq = tid % Tile::CPR;
+    }
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (__bf16)regs[j][e];
+      if (X3) l[e] = (__bf16)(regs[j][e] - (float)h[e]);
+    }
+    *reinterpret_cast<bf16x4*>(hi + row * ld + cq * 4) = h;
+    if (X3) *reinterpret_cast<bf16x4*>(lo + row * ld + cq * 4) = l;
+  }
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const __bf16* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+// fragment of a k-contiguous plane: 8 bf16 at [row][koff]
+__device__ __forceinline__ bf16x8 frag_kc(const __bf16* plane, int ld, int row, int koff) {
+  return *reinterpret_cast<const bf16x8*>(plane + row * ld + koff);
+}
+// fragment of a [k][col] plane for the 32 columns col0..col0+31: lane l gets column col0 + (l & 31),
+// k = kbase + 8*(l >> 5) + 0..7
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane, int ld, int col0, int kbase, int lane) {
+  const int g = lane >> 4, l16 = lane & 15;
+  const int q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
+  const __bf16* a0 = plane + (kbase + 8 * h + q) * ld + col0 + 16 * cb + 4 * pp;
+  bf16x4 lo4 = lds_read_tr(a0);
+  bf16x4 hi4 = lds_read_tr(a0 + 4 * ld);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo4[e]; r[4 + e] = hi4[e]; }
+  return r;
+}
+
+template <int MODE, int BM, int BN, bool X3>
+__global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p) {
+  using Cfg = Bf16Cfg<MODE, BM, BN, X3>;
+  constexpr int BK = Cfg::BK, NT = Cfg::NT, TN = Cfg::TN;
+  constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
+  using ATile = Im2colTile<NT, Cfg::A_ROWS, Cfg::A_COLS, 4, TRANSPOSED>;
+  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<NT, Cfg::B_ROWS, Cfg::B_COLS, 4>,
+                                          PlainTile<NT, Cfg::B_ROWS, Cfg::B_COLS, 4>>::type;
+  static_assert(!ATile::PARTIAL, "A tile must cover all threads");
+  constexpr bool B_PLAIN = (MODE != MODE_BWD_D);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* tiles = reinterpret_cast<__bf16*>(smem_raw);
+  int4* pixtab = reinterpret_cast<int4*>(smem_raw + Cfg::TILE_BYTES);
+  auto A_hi = [&](int buf) { return tiles + buf * Cfg::BUF_ELEMS; };
+  auto A_lo = [&](int buf) { return tiles + buf * Cfg::BUF_ELEMS + Cfg::A_ELEMS; };
+  auto B_hi = [&](int buf) { return tiles + buf * Cfg::BUF_ELEMS + Cfg::PLANES * Cfg::A_ELEMS; };
+  auto B_lo = [&](int buf) { return tiles + buf * Cfg::BUF_ELEMS + Cfg::PLANES * Cfg::A_ELEMS + Cfg::B_ELEMS; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const uint32_t nwg = gridDim.x;
+  uint32_t bid = blockIdx.x;
+  {
+    uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_mn = p.tiles_m * p.tiles_n;
+  const int split = bid / tiles_mn;
+  const int tmn = bid - split * tiles_mn;
+  const int tile_m = tmn / p.tiles_n, tile_n = tmn - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+  const int nkt = kt_end - kt_begin;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+
+  float ra[ATile::NL][4];
+  float rb[BTile::NL][4];
+  // BiasAddGrad (BWD_F): every thread sums, in fp32 and over the whole K range, the dz values it stages (its 4
+  // columns, its rows of each tile); one LDS reduction in the epilogue
+  const bool do_bias = (MODE == MODE_BWD_F) && p.dbias != nullptr && tile_m == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int a_cq = tid % ATile::CPR;
+  const int b_cq = tid % BTile::CPR;
+
+  if (MODE == MODE_BWD_F) {
+    if (tid < 2 * Cfg::PIX) {
+      int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
+      pixtab[which * Cfg::PIX + e] = make_pix<false>(p, (kt_begin + which) * BK + e);
+    }
+  } else {
+    if (tid < Cfg::PIX) pixtab[tid] = make_pix<TRANSPOSED>(p, m0 + tid);
+  }
+  __syncthreads();
+
+  ColDec cdec;
+  if (MODE == MODE_BWD_F) cdec = decode_col(p, m0 + a_cq * 4);
+
+  auto load_tiles = [&](int kt, int pbuf) {
+    if constexpr (MODE == MODE_BWD_F) {
+      ATile::load(ra, p, pixtab + pbuf * Cfg::PIX, cdec, tid);
+      BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < BTile::NL; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[e] += rb[j][e];
+      }
+    } else {
+      ColDec cd = decode_col(p, kt * BK + a_cq * 4);
+      ATile::load(ra, p, pixtab, cd, tid);
+      if constexpr (MODE == MODE_FWD)
+        BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+      else
+        BTile::load(rb, p, n0, kt * BK + b_cq * 4, tid);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    store_bf16<ATile, X3, false>(ra, A_hi(buf), A_lo(buf), Cfg::A_LD, tid);
+    store_bf16<BTile, X3, B_PLAIN>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
+  };
+
+  if (nkt > 0) {
+    load_tiles(kt_begin, 0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int it = 0; it < nkt; ++it) {
+    const int kt = kt_begin + it;
+    const bool more = it + 1 < nkt;
+    if (more) load_tiles(kt + 1, (it + 1) & 1);
+    if (MODE == MODE_BWD_F) {
+      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
+    }
+    const __bf16* ah = A_hi(cur);
+    const __bf16* al = A_lo(cur);
+    const __bf16* bh = B_hi(cur);
+    const __bf16* bl = B_lo(cur);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 a_hi, a_lo, b_hi[TN], b_lo[TN];
+      const int arow = wm * Cfg::WM + li;
+      if (Cfg::A_KC) {
+        a_hi = frag_kc(ah, Cfg::A_LD, arow, 16 * s + 8 * lh);
+        if (X3) a_lo = frag_kc(al, Cfg::A_LD, arow, 16 * s + 8 * lh);
+      } else {
+        a_hi = frag_tr(ah, Cfg::A_LD, wm * Cfg::WM, 16 * s, lane);
+        if (X3) a_lo = frag_tr(al, Cfg::A_LD, wm * Cfg::WM, 16 * s, lane);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int bcol0 = wn * Cfg::WN + b * 32;
+        if (Cfg::B_KC) {
+          b_hi[b] = frag_kc(bh, Cfg::B_LD, bcol0 + li, 16 * s + 8 * lh);
+          if (X3) b_lo[b] = frag_kc(bl, Cfg::B_LD, bcol0 + li, 16 * s + 8 * lh);
+        } else {
+          b_hi[b] = frag_tr(bh, Cfg::B_LD, bcol0, 16 * s, lane);
+          if (X3) b_lo[b] = frag_tr(bl, Cfg::B_LD, bcol0, 16 * s, lane);
+        }
+      }
+      if (s == BK / 16 - 1 && more) store_tiles(cur ^ 1);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        if (X3) {
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[b], acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[b], acc[b], 0, 0, 0);
+        }
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[b], acc[b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue (as igemm_kernel) ----
+  float* Cout = p.C;
+  int ldc = p.ldc;
+  const bool partial = p.splitk > 1;
+  if (partial) {
+    Cout = p.C + (size_t)split * p.slab;
+    ldc = p.N;
+  }
+  if (MODE == MODE_BWD_F && p.dbias != nullptr && tile_m == 0) {        // block-uniform branch
+    float* red = reinterpret_cast<float*>(smem_raw);                       // tile buffers are free now
+    constexpr int RG = NT / (BN / 4);                                      // row groups: threads sharing a column chunk
+    const int rg = tid / (BN / 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg * BN + b_cq * 4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float s = 0.f;
+      for (int r = 0; r < RG; ++r) s += red[r * BN + tid];
+      p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = s;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = n0 + wn * Cfg::WN + b * 32 + li;
+    if (col >= p.N) continue;
+    float bias = 0.f;
+    if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + wm * Cfg::WM + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (row >= p.M) continue;
+      float val = acc[b][v];
+      const size_t o = (size_t)row * ldc + col;
+      if (!partial) {
+        if (MODE == MODE_FWD) {
+          val += bias;
+          if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
+          else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + expf(-val));
+          if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
+        } else if (MODE == MODE_BWD_D) {
+          if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
+        }
+      }
+      Cout[o] = val;
+    }
+  }
+}
+
+}  // namespace a3d

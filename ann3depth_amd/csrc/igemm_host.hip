@@ -14,6 +14,7 @@ namespace a3d {
 int launch_igemm_mode0(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode1(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st);
 
 struct TileCfg {
   int bm, bn;
@@ -28,6 +29,12 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
 
+// Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 // ---- opt-in launch timing (a3d_timing_*) ----
 struct TimingSlot {
   hipEvent_t start, stop;
@@ -39,13 +46,27 @@ static std::vector<TimingSlot> g_timing;
 static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
 static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
 
-// Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
+// bf16 / bf16x3 kernel: BM = 128; staging-bound rather than MFMA-bound, so just fill the chip (>= ~1024 blocks)
+static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
+  GemmPlan pl{};
+  pl.prec = precision;
+  pl.bf16_bn = (precision == A3D_PREC_BF16X3 || g.N <= 64) ? 64 : 128;     // x3 planes: 128x64 keeps 2 blocks per CU
+  pl.tiles_m = (g.M + 127) / 128;
+  pl.tiles_n = (g.N + pl.bf16_bn - 1) / pl.bf16_bn;
+  const int nk = (g.K + 31) / 32;
+  const long tiles = (long)pl.tiles_m * pl.tiles_n;
+  int splitk = (int)std::min<long>(std::max<long>((1024 + tiles - 1) / tiles, 1), std::max(1, nk / 4));
+  splitk = std::min(splitk, env_int("A3D_FORCE_SPLITK", 1 << 20));
+  while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
+  const int kps = (nk + splitk - 1) / splitk;
+  pl.splitk = (nk + kps - 1) / kps;
+  pl.ktiles_per_split = kps;
+  pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * g.M * g.N * 4 : 0;
+  return pl;
 }
 
-GemmPlan plan_gemm(const GemmProblem& g) {
+GemmPlan plan_gemm(const GemmProblem& g, int precision) {
+  if (precision != A3D_PREC_F32 && g.avec == 4 && g.bvec == 4) return plan_gemm_bf16(g, precision);
   GemmPlan best{};
   double best_t = 1e300;
   const int nk = (g.K + 31) / 32;
@@ -142,13 +163,20 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
       return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
     hipEventRecord(slot.start, st);
   }
-  if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
+  if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
+  else if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
   else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
   else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
   if (timed) {
     hipEventRecord(slot.stop, st);
     a3d_timing_record& r = slot.rec;
-    r.mode = mode; r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg]; r.nwaves = kCfgNWaves[plan.cfg];
+    r.mode = mode; r.prec = plan.prec;
+    if (plan.prec != A3D_PREC_F32) {
+      r.bm = 128; r.bn = plan.bf16_bn; r.waves_m = 4; r.nwaves = 8; r.bk = 32;
+    } else {
+      r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
+      r.nwaves = kCfgNWaves[plan.cfg]; r.bk = kCfgs[plan.cfg].bk;
+    }
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;
     std::lock_guard<std::mutex> lk(g_timing_mu);
@@ -193,6 +221,7 @@ static int check_desc(const a3d_conv_desc* d) {
   A3D_CHECK_ARG((d->ho - 1) * d->stride - d->pad_t < d->h && (d->wo - 1) * d->stride - d->pad_l < d->w,
                 "conv: output size inconsistent with input");
   A3D_CHECK_ARG(d->ldx >= d->c && d->ldy >= d->k, "conv: pixel strides smaller than channel counts");
+  A3D_CHECK_ARG(d->precision >= A3D_PREC_F32 && d->precision <= A3D_PREC_BF16, "conv: unknown precision %d", d->precision);
   const double lim = 2147483647.0;
   A3D_CHECK_ARG((double)d->n * d->h * d->w * d->ldx < lim && (double)d->n * d->ho * d->wo * d->ldy < lim &&
                     (double)d->r * d->s * d->c * d->k < lim,
@@ -272,7 +301,7 @@ int a3d_timing_collect(a3d_timing_record* out, int cap) {
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
-  return plan_gemm(fwd_problem(d)).ws_bytes;
+  return plan_gemm(fwd_problem(d), d->precision).ws_bytes;
 }
 
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
@@ -285,7 +314,7 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
   GemmProblem g = fwd_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(fwd_problem(d));
+  GemmPlan plan = plan_gemm(g, d->precision);
   if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
@@ -302,7 +331,7 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
 
 size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
-  return plan_gemm(bwd_d_problem(d)).ws_bytes;
+  return plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
 }
 
 int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w, float* dx, const float* relu_mask,
@@ -313,7 +342,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   GemmProblem g = bwd_d_problem(d);
   if (!aligned16(dz)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(bwd_d_problem(d));
+  GemmPlan plan = plan_gemm(g, d->precision);
   if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
@@ -331,7 +360,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
-  GemmPlan plan = plan_gemm(bwd_f_problem(d));
+  GemmPlan plan = plan_gemm(bwd_f_problem(d), d->precision);
   return plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
 }
 
@@ -347,7 +376,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   GemmProblem g = bwd_f_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(dz)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(bwd_f_problem(d));
+  GemmPlan plan = plan_gemm(g, d->precision);
   size_t need = plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);

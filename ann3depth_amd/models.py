@@ -100,7 +100,12 @@ class ParamGroup:
 class MSDNReplica:
     """One data-parallel replica of the MSDN training graph (src/models.py:203-367) on one GPU."""
 
-    def __init__(self, batchsize, device='cuda', params=None, seed=3000, global_step=0, beta2=1.0, reducer=None):
+    def __init__(self, batchsize, device='cuda', params=None, seed=3000, global_step=0, beta2=1.0, reducer=None,
+                 precision='fp32'):
+        """precision: arithmetic of the conv contractions — 'fp32' (exact, the parity default), 'bf16x3' (split
+        operands on the bf16 matrix cores, ~1e-5) or 'bf16' (BASELINE config 5).  Tensors stay float32 in HBM; the
+        Cin = 3 layers, the dense layers and everything element-wise always compute in fp32."""
+        self.precision = precision
         self.B = B = batchsize
         self.device = torch.device(device)
         self.global_step = global_step
@@ -153,7 +158,8 @@ class MSDNReplica:
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = buf(B, OUT_H, OUT_W, 64)
         self.dcat = buf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
         # descriptors
-        D = ops.conv_desc
+        def D(*a):
+            return ops.conv_desc(*a, precision=precision)
         self.d = {
             'coarse/conv/conv2d_0': D(B, NET_H, NET_W, 3, 96, 11, 11, 4, 'VALID'),
             'coarse/conv/conv2d_1': D(B, 27, 37, 96, 256, 5, 5, 1, 'SAME'),
@@ -333,7 +339,7 @@ class DCNFUnary:
     batch with tf.map_fn, src/models.py:89): images [B,H,W,3] -> z [B,48,1].  backward() takes a synthetic
     upstream gradient dz (the CRF loss that would produce it is outside the north-star path)."""
 
-    def __init__(self, batchsize, device='cuda', params=None, seed=3000):
+    def __init__(self, batchsize, device='cuda', params=None, seed=3000, precision='fp32'):
         self.B = batchsize
         self.device = dev = torch.device(device)
         self.rows, _ = ops.same_pad(DCNF_IMG_H, DCNF_PATCH, DCNF_SP)
@@ -364,7 +370,7 @@ class DCNFUnary:
         self.act['x'] = buf(P, DCNF_PATCH, DCNF_PATCH, 3)
         h = DCNF_PATCH
         for n, ci, co, k in DCNF_CONVS:
-            self.desc[n] = ops.conv_desc(P, h, h, ci, co, k, k, 1, 'VALID')
+            self.desc[n] = ops.conv_desc(P, h, h, ci, co, k, k, 1, 'VALID', precision=precision)
             h = h - k + 1
             self.act[n] = buf(P, h, h, co)
             if n in DCNF_POOL_AFTER:
@@ -514,12 +520,13 @@ class _MultiScaleDeepNetwork:
     beta2 = 1.0          # the reference's AdamOptimizer(rate, momentum, 1): alpha == 0, weights never move
     reducer = None       # set by the driver when world_size > 1
     seed = 3000
+    precision = 'fp32'   # --precision: 'fp32' | 'bf16x3' | 'bf16' (see MSDNReplica)
 
     def __call__(self, images, depths, train=True):
         assert images.pipeline is depths.pipeline, 'inputs and targets must come from the same data.inputs() call'
         self.train = train
         replica = MSDNReplica(images.pipeline.B, device=torch.device('cuda', torch.cuda.current_device()),
-                              seed=self.seed, beta2=self.beta2, reducer=self.reducer)
+                              seed=self.seed, beta2=self.beta2, reducer=self.reducer, precision=self.precision)
         if self.reducer is not None:                         # replicas start from rank 0's weights
             for g in replica.groups.values():
                 self.reducer.broadcast(g.var)

@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 ACT = {None: 0, 'relu': 1, 'sigmoid': 2}
+PREC = {'fp32': 0, 'f32': 0, 'bf16x3': 1, 'bf16': 2}
 
 
 def _ptr(t):
@@ -49,8 +50,9 @@ def same_pad(in_size, k, stride):
     return out, pad // 2
 
 
-def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None):
-    """Descriptor of tf.layers.conv2d(x[n,h,w,c], k, (r,s), (stride,stride), padding)."""
+def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32'):
+    """Descriptor of tf.layers.conv2d(x[n,h,w,c], k, (r,s), (stride,stride), padding).  precision selects the
+    arithmetic of the contraction: 'fp32' (exact, default), 'bf16x3' (split operands) or 'bf16'."""
     padding = padding.upper()
     if padding == 'SAME':
         ho, pt = same_pad(h, r, stride)
@@ -61,7 +63,7 @@ def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None):
     else:
         raise ValueError(padding)
     return ConvDesc(n=n, h=h, w=w, c=c, k=k, r=r, s=s, stride=stride, pad_t=pt, pad_l=pl, ho=ho, wo=wo,
-                    ldx=ldx or c, ldy=ldy or k)
+                    ldx=ldx or c, ldy=ldy or k, precision=PREC[precision])
 
 
 def conv2d_fwd(d, x, w, bias, y, act=None):

@@ -55,7 +55,9 @@ def collect_timing(lib):
 
 
 def kernel_name(r):
-    return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.nwaves}, {r.avec}, {r.bvec}>'
+    if r.prec:
+        return f'igemm_bf16_kernel<{r.mode}, {r.bm}, {r.bn}, {"true" if r.prec == 1 else "false"}>'
+    return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.nwaves}, {r.bk}, {r.avec}, {r.bvec}>'
 
 
 def run_phase(net, img, dep, masks, steps, warmup, global_step, lib, world, timed_kernels):
@@ -134,6 +136,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 2/3: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+                    help='conv arithmetic; the headline (and parity) mode is fp32')
+    ap.add_argument('--also', default='bf16x3', help='comma list of extra precisions measured after the headline run')
     ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
     args = ap.parse_args()
 
@@ -149,7 +154,7 @@ def main():
     torch.cuda.set_device(device)
     B = args.batch
     reducer = dp.GradReducer() if world > 1 else None
-    net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer)
+    net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=args.precision)
     img, dep = synth_batch(B, rank, device)
     masks = keep_masks(B, 8, rank, device)
 
@@ -162,11 +167,19 @@ def main():
         dtf, _ = run_phase(net, img, dep, masks, args.steps, min(args.warmup, 2), models.SAMPLES_COARSE // B, lib,
                            world, timed_kernels=False)
         extra['fine_phase'] = {'value': round(world * B * args.steps / dtf, 1), 'ms_per_step': round(1e3 * dtf / args.steps, 3)}
+    for prec in [p for p in args.also.split(',') if p and p != args.precision]:
+        alt = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=prec)
+        dta, _ = run_phase(alt, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
+        extra.setdefault('other_precisions', {})[prec] = {
+            'value': round(world * B * args.steps / dta, 1), 'ms_per_step': round(1e3 * dta / args.steps, 3),
+            'note': 'conv contractions on the bf16 matrix cores; NOT the headline: parity is stated for fp32'}
+        del alt
     if rank == 0:
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.precision, args.precision),
+            'data': 'synthetic',
             'config': {'workload': 'MSDN coarse+fine, batch 32 per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
                                    'coarse-phase train step (global_step 0): both forwards + both losses, backward of '
                                    'coarse/*, 2x ApplyAdam(beta2=1)',

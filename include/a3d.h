@@ -44,7 +44,12 @@ typedef struct a3d_conv_desc {
   int32_t ho, wo;            /* output [n,ho,wo,k] */
   int32_t ldx;               /* elements between consecutive input pixels  (>= c; c if dense-packed) */
   int32_t ldy;               /* elements between consecutive output pixels (>= k) */
+  int32_t precision;         /* A3D_PREC_*: arithmetic of the contraction (tensors are float32 in memory either way) */
 } a3d_conv_desc;
+
+#define A3D_PREC_F32 0     /* exact fp32 on the fp32 matrix cores (default; what parity is stated for) */
+#define A3D_PREC_BF16X3 1  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product: ~1e-5 relative */
+#define A3D_PREC_BF16 2    /* operands rounded to bf16, fp32 accumulate (BASELINE config 5) */
 
 const char* a3d_version(void);
 int a3d_last_error(char* buf, size_t len);
@@ -124,7 +129,8 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
  * and clears the list.  Not for use inside graph capture. */
 typedef struct a3d_timing_record {
   int32_t mode;        /* 0 fwd, 1 bwd-data, 2 bwd-filter */
-  int32_t bm, bn, waves_m, nwaves, avec, bvec;   /* igemm_kernel<mode,bm,bn,waves_m,nwaves,avec,bvec> */
+  int32_t bm, bn, waves_m, nwaves, bk, avec, bvec;   /* igemm_kernel<mode,bm,bn,waves_m,nwaves,bk,avec,bvec> */
+  int32_t prec;        /* A3D_PREC_*; for bf16 modes the kernel is igemm_bf16_kernel<mode,bm,bn,x3> */
   int32_t splitk;
   int32_t m, n, k;     /* GEMM extents of the launch */
   float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */

@@ -130,3 +130,25 @@ def test_msdn_full_batch_properties(models):
     torch.cuda.synchronize()
     assert rel(small.coarse.cpu().numpy(), coarse[5:7].cpu().numpy()) < 1e-5
     assert rel(small.fine.cpu().numpy(), fine[5:7].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 5e-2)])
+def test_msdn_bf16_modes_keep_the_depth_tolerance(models, prec, tol):
+    """The bf16-MFMA modes end to end: bf16x3 stays far inside the north-star 1e-3 depth tolerance; plain bf16
+    (BASELINE config 5's arithmetic) is reported with its own, looser tolerance."""
+    B = 2
+    img, dep, keep = synth(B, 1000)
+    params = O.init_params(3000)
+    net = models.MSDNReplica(B, params=params, precision=prec)
+    net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    torch.cuda.synchronize()
+    a = O.forward(params, img, dep, keep)
+    assert rel(net.coarse.cpu().numpy(), a['coarse']) < tol
+    assert rel(net.fine.cpu().numpy(), a['fine']) < tol
+    if prec == 'bf16x3':
+        assert tol <= DEPTH_TOL
+        a_gpu = gpu_activations(net)
+        a_gpu['keep_mask'] = keep
+        g = O.backward_coarse(params, a_gpu)
+        for n, gref in g.items():
+            assert rel(net.grad(n).cpu().numpy(), gref) < 2e-4, n

@@ -83,6 +83,39 @@ def test_conv2d_fwd_bwd(ops, n, h, w, c, k, ks, st, pad):
     assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < RTOL_F32
 
 
+BF16_CASES = [c for c in CONV_CASES if c[3] % 4 == 0 and c[4] % 4 == 0 and c[4] > 1]
+
+
+@pytest.mark.parametrize('prec,tol', [('bf16x3', 5e-5), ('bf16', 2e-2)])
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', BF16_CASES)
+def test_conv2d_bf16_modes(ops, n, h, w, c, k, ks, st, pad, prec, tol):
+    """The bf16-MFMA kernels (split-operand bf16x3 and plain bf16) against the float64 oracle: all three directions,
+    fused bias/ReLU, fused ReluGrad mask and the fused BiasAddGrad."""
+    rng = np.random.default_rng(300 + h * w + c + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    b = rng.standard_normal(k).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, precision=prec)
+    x64, w64, b64 = x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64)
+    y_ref = T.conv2d_fwd(x64, w64, b64, st, pad, relu=True)
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    y = torch.empty(y_ref.shape, device='cuda')
+    ops.conv2d_fwd(d, xd, wd, bd, y, 'relu')
+    assert rel_l2(y.cpu().numpy(), y_ref) < tol
+    dz = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dw_ref, db_ref = T.conv2d_bwd_filter(x64, dz.astype(np.float64), wt.shape, st, pad)
+    dx_ref = T.conv2d_bwd_data(dz.astype(np.float64), w64, x.shape, st, pad)
+    dzd = dev(dz)
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    ops.conv2d_bwd_filter(d, xd, dzd, dw, db)
+    assert rel_l2(dw.cpu().numpy(), dw_ref) < tol
+    assert rel_l2(db.cpu().numpy(), db_ref) < 1e-5          # bias gradient is summed in fp32 in every mode
+    dx = torch.full_like(xd, float('nan'))
+    ops.conv2d_bwd_data(d, dzd, wd, dx, relu_mask=xd)
+    assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < tol
+
+
 def test_conv2d_strided_pixels(ops):
     """ldx / ldy pixel strides: the fine/second layer reads the 64-channel concat buffer and bwd-data writes it."""
     rng = np.random.default_rng(5)
