@@ -46,17 +46,20 @@ static std::vector<TimingSlot> g_timing;
 static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
 static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
 
-// bf16 / bf16x3 kernel: BM = 128; staging-bound rather than MFMA-bound, so just fill the chip (>= ~1024 blocks)
+// bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
+// (even at one block per CU for the two-plane x3 variant), and ~600 blocks with >= 12 k-tiles each fill the chip
+// (sweep: profiles/r01_sweep_bf16.txt).
 static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   GemmPlan pl{};
   pl.prec = precision;
-  pl.bf16_bn = (precision == A3D_PREC_BF16X3 || g.N <= 64) ? 64 : 128;     // x3 planes: 128x64 keeps 2 blocks per CU
+  pl.bf16_bn = g.N <= 64 ? 64 : 128;
+  if (env_int("A3D_BF16_BN", 0) == 64 || env_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = env_int("A3D_BF16_BN", 0);
   pl.tiles_m = (g.M + 127) / 128;
   pl.tiles_n = (g.N + pl.bf16_bn - 1) / pl.bf16_bn;
   const int nk = (g.K + 31) / 32;
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
-  int splitk = (int)std::min<long>(std::max<long>((1024 + tiles - 1) / tiles, 1), std::max(1, nk / 4));
-  splitk = std::min(splitk, env_int("A3D_FORCE_SPLITK", 1 << 20));
+  int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk / 12));
+  if (env_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(env_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
   pl.splitk = (nk + kps - 1) / kps;

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ann3depth_amd import ops  # noqa: E402
 
 B = int(os.environ.get('B', 32))
+PREC = os.environ.get('PREC', 'fp32')
 LAYERS = [  # name, h, w, cin, cout, k, stride, pad
     ('conv2d_0', 228, 304, 3, 96, 11, 4, 'VALID'), ('conv2d_1', 27, 37, 96, 256, 5, 1, 'SAME'),
     ('conv2d_2', 13, 18, 256, 384, 3, 1, 'SAME'), ('conv2d_3', 13, 18, 384, 384, 3, 1, 'SAME'),
@@ -39,7 +40,7 @@ def main():
     for name, h, w, c, k, ks, st, pad in LAYERS:
         if only and name not in only:
             continue
-        d = ops.conv_desc(B, h, w, c, k, ks, ks, st, pad)
+        d = ops.conv_desc(B, h, w, c, k, ks, ks, st, pad, precision=PREC)
         x = torch.randn((B, h, w, c), device='cuda')
         wt = torch.randn((ks, ks, c, k), device='cuda') * 0.01
         bias = torch.zeros(k, device='cuda')
@@ -57,7 +58,15 @@ def main():
             os.environ.pop('A3D_FORCE_SPLITK', None)
             t_auto = timeit(fn)
             res = []
-            for ci, cn in enumerate(CFGS):
+            if PREC != 'fp32':
+                for bn in (64, 128):
+                    for sk in (1, 2, 4, 8, 16, 32, 64):
+                        os.environ['A3D_BF16_BN'] = str(bn)
+                        os.environ['A3D_FORCE_SPLITK'] = str(sk)
+                        res.append((timeit(fn, 3), f'bn{bn}', sk))
+                os.environ.pop('A3D_BF16_BN', None)
+                os.environ.pop('A3D_FORCE_SPLITK', None)
+            for ci, cn in enumerate(CFGS if PREC == 'fp32' else []):
                 for sk in (1, 2, 4, 8, 16, 32, 64, 128, 256):
                     os.environ['A3D_FORCE_CFG'] = str(ci)
                     os.environ['A3D_FORCE_SPLITK'] = str(sk)
