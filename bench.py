@@ -86,6 +86,20 @@ def run_phase(net, img, dep, masks, steps, warmup, global_step, lib, world, time
     return dt, recs
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 read correction applied); None if not profiled."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            k = json.load(open(path))['kernels'].get('a3d::' + kernel)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k:
+            return k['hbm_bytes_per_launch']
+    return None
+
+
 def roofline_from(recs):
     groups = {}
     for r in recs:
@@ -100,7 +114,7 @@ def roofline_from(recs):
     table = {k: {'calls': v['calls'], 'avg_us': round(1e3 * v['ms'] / v['calls'], 2),
                  'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
     roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(name),
             'calls': g['calls'], 'avg_launch_us': round(1e3 * g['ms'] / g['calls'], 2),
             'flops_per_launch': g['flops'] / g['calls']}
     return roof, table
