@@ -73,7 +73,22 @@ struct IgemmParams {
   int splitk, ktiles_per_split;
   size_t slab;          // elements per split-K slab
   int tiles_m, tiles_n;
+  // BWD_D with stride > 1 runs one launch per output-parity class (h % stride, w % stride): only the filter taps
+  // r = tap_r0 + stride*r', s = tap_s0 + stride*s' reach such a pixel, so each class is a stride-1 problem over a
+  // sub-sampled pixel grid and a sub-sampled filter.  sub_step == 1: plain launch.
+  int sub_step, sub_ph, sub_pw, tap_r0, tap_s0, S_full, outW, outHW;
 };
+
+// linear pixel of the (sub-)problem -> pixel index in the full output tensor
+__device__ __forceinline__ size_t remap_row(int row, int sub_step, int sub_ph, int sub_pw, int outW, int outHW,
+                                            const FastDiv& div_phw, const FastDiv& div_pw) {
+  if (sub_step <= 1) return (size_t)row;
+  const uint32_t n = fdiv((uint32_t)row, div_phw);
+  const uint32_t rem = (uint32_t)row - n * div_phw.d;
+  const uint32_t i = fdiv(rem, div_pw);
+  const uint32_t j = rem - i * div_pw.d;
+  return (size_t)n * outHW + (size_t)(sub_step * i + sub_ph) * outW + sub_step * j + sub_pw;
+}
 
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
 struct IgemmCfg {
@@ -251,6 +266,11 @@ struct FilterTTile {
     uint32_t k = kvalid ? (uint32_t)kcol : 0u;
     uint32_t rs = fdiv(k, p.div_c);              // div_c.d == Cout here
     int ko = (int)(k - rs * p.div_c.d);
+    if (p.sub_step > 1) {                        // tap of the sub-sampled filter -> tap of the stored filter
+      const uint32_t rp = fdiv(rs, p.div_s);
+      const uint32_t sp = rs - rp * p.div_s.d;
+      rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
+    }
     long base = (long)rs * p.Cn * p.Cg + ko;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -462,7 +482,10 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
         const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
         if (row >= p.M) continue;
         float val = acc[a][b][v];
-        const size_t o = (size_t)row * ldc + col;
+        const size_t o = (partial || MODE != MODE_BWD_D
+                              ? (size_t)row
+                              : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
+                             ldc + col;
         if (!partial) {
           if (MODE == MODE_FWD) {
             val += bias;
@@ -483,6 +506,7 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
 struct ReduceParams {
   const float* ws; float* C; const float* bias; const float* mask; const uint8_t* keep; float mask_scale;
   int M, N, ldc, splitk, act, mode, mask_act; size_t slab;
+  int sub_step, sub_ph, sub_pw, outW, outHW; FastDiv div_phw, div_pw;     // BWD_D parity-class row remap
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
 

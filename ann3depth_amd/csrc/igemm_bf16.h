@@ -275,7 +275,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
       const int row = m0 + wm * Cfg::WM + (v & 3) + 8 * (v >> 2) + 4 * lh;
       if (row >= p.M) continue;
       float val = acc[b][v];
-      const size_t o = (size_t)row * ldc + col;
+      const size_t o = (partial || MODE != MODE_BWD_D
+                            ? (size_t)row
+                            : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
+                           ldc + col;
       if (!partial) {
         if (MODE == MODE_FWD) {
           val += bias;

@@ -56,7 +56,7 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   if (env_int("A3D_BF16_BN", 0) == 64 || env_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = env_int("A3D_BF16_BN", 0);
   pl.tiles_m = (g.M + 127) / 128;
   pl.tiles_n = (g.N + pl.bf16_bn - 1) / pl.bf16_bn;
-  const int nk = (g.K + 31) / 32;
+  const int nk = std::max(1, (g.K + 31) / 32);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk / 12));
   if (env_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(env_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
@@ -72,7 +72,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   if (precision != A3D_PREC_F32 && g.avec == 4 && g.bvec == 4) return plan_gemm_bf16(g, precision);
   GemmPlan best{};
   double best_t = 1e300;
-  const int nk = (g.K + 31) / 32;
+  const int nk = std::max(1, (g.K + 31) / 32);
   const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
     float s = 0.f;
     for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * p.slab + i];
     const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
-    const size_t o = (size_t)row * p.ldc + col;
+    const size_t o = remap_row(row, p.mode == MODE_BWD_D ? p.sub_step : 1, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw,
+                               p.div_pw) * p.ldc + col;
     if (p.mode == MODE_FWD) {
       if (p.bias) s += p.bias[col];
       if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
@@ -191,6 +192,8 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
     r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act;
+    r.sub_step = p.sub_step; r.sub_ph = p.sub_ph; r.sub_pw = p.sub_pw; r.outW = p.outW; r.outHW = p.outHW;
+    r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     size_t total = (size_t)p.M * p.N;
     unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 2048);
     clear_stale_error();
@@ -268,6 +271,7 @@ static void fill_common(IgemmParams& p, const GemmProblem& g) {
   p.M = g.M; p.N = g.N; p.K = g.K;
   p.mask_scale = 1.f;
   p.mask_act = EPI_RELU;
+  p.sub_step = 1;
 }
 
 }  // namespace a3d
@@ -332,9 +336,38 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
 }
 
+// One parity class (ph, pw) of a strided bwd-data as a stride-1 problem; false if the class has no pixels.
+struct BwdDClass {
+  int hc, wc, r0, s0, rp, sp, off_y, off_x;
+  GemmProblem g;
+};
+static bool bwd_d_class(const a3d_conv_desc* d, int ph, int pw, BwdDClass* c) {
+  const int st = d->stride;
+  c->hc = (d->h - ph + st - 1) / st;
+  c->wc = (d->w - pw + st - 1) / st;
+  if (c->hc <= 0 || c->wc <= 0) return false;
+  c->r0 = (ph + d->pad_t) % st;
+  c->s0 = (pw + d->pad_l) % st;
+  c->rp = c->r0 < d->r ? (d->r - c->r0 + st - 1) / st : 0;
+  c->sp = c->s0 < d->s ? (d->s - c->s0 + st - 1) / st : 0;
+  c->off_y = (ph + d->pad_t - c->r0) / st;
+  c->off_x = (pw + d->pad_l - c->s0) / st;
+  c->g = bwd_d_problem(d);
+  c->g.M = d->n * c->hc * c->wc;
+  c->g.K = c->rp * c->sp * d->k;          // 0: no tap reaches this class, the launch only writes zeros
+  return true;
+}
+
 size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
-  return plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
+  if (d->stride == 1) return plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
+  size_t need = 0;
+  for (int ph = 0; ph < d->stride; ++ph)
+    for (int pw = 0; pw < d->stride; ++pw) {
+      BwdDClass c;
+      if (bwd_d_class(d, ph, pw, &c)) need = std::max(need, plan_gemm(c.g, d->precision).ws_bytes);
+    }
+  return need;
 }
 
 int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w, float* dx, const float* relu_mask,
@@ -342,22 +375,35 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(dz && w && dx, "conv2d_bwd_data: null tensor");
-  GemmProblem g = bwd_d_problem(d);
-  if (!aligned16(dz)) g.avec = 1;
-  if (!aligned16(w)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(g, d->precision);
-  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
-  IgemmParams p;
-  fill_common(p, g);
-  p.A = dz; p.B = w; p.C = dx; p.mask = relu_mask;
-  p.npix = g.M; p.nrsc = g.K;
-  p.H = d->ho; p.W = d->wo; p.ld = d->ldy; p.pHW = d->ho * d->wo;
-  p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-  p.S = d->s; p.Cg = d->k; p.Cn = d->c;
-  p.div_phw = make_fastdiv(d->h * d->w); p.div_pw = make_fastdiv(d->w);
-  p.div_c = make_fastdiv(d->k); p.div_s = make_fastdiv(d->s);
-  p.ldb = 0; p.ldc = d->ldx;
-  return launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+  const bool vec_ok_a = aligned16(dz), vec_ok_b = aligned16(w);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int ph = 0; ph < d->stride; ++ph) {
+    for (int pw = 0; pw < d->stride; ++pw) {
+      BwdDClass c;
+      if (!bwd_d_class(d, ph, pw, &c)) continue;
+      GemmProblem g = c.g;
+      if (!vec_ok_a) g.avec = 1;
+      if (!vec_ok_b) g.bvec = 1;
+      GemmPlan plan = plan_gemm(g, d->precision);
+      if (plan.ws_bytes > ws_bytes)
+        return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
+      IgemmParams p;
+      fill_common(p, g);
+      p.A = dz; p.B = w; p.C = dx; p.mask = relu_mask;
+      p.npix = g.M; p.nrsc = g.K;
+      p.H = d->ho; p.W = d->wo; p.ld = d->ldy; p.pHW = d->ho * d->wo;
+      p.stride = 1; p.lstride = 0; p.pad_t = c.off_y; p.pad_l = c.off_x;      // the class is a stride-1 problem
+      p.S = std::max(c.sp, 1); p.Cg = d->k; p.Cn = d->c;
+      p.div_phw = make_fastdiv(c.hc * c.wc); p.div_pw = make_fastdiv(c.wc);
+      p.div_c = make_fastdiv(d->k); p.div_s = make_fastdiv(std::max(c.sp, 1));
+      p.ldb = 0; p.ldc = d->ldx;
+      p.sub_step = d->stride; p.sub_ph = ph; p.sub_pw = pw; p.tap_r0 = c.r0; p.tap_s0 = c.s0; p.S_full = d->s;
+      p.outW = d->w; p.outHW = d->h * d->w;
+      rc = launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, st);
+      if (rc != A3D_OK) return rc;
+    }
+  }
+  return A3D_OK;
 }
 
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {

@@ -43,6 +43,8 @@ CONV_CASES = [
     (1, 9, 9, 5, 7, 3, 1, 'SAME'),           # Cin, Cout not multiples of 4
     (5, 24, 24, 64, 256, 5, 1, 'VALID'),     # dcnf conv2d_1 kind
     (1, 1, 1, 16, 8, 1, 1, 'VALID'),         # degenerate 1x1
+    (2, 13, 14, 4, 8, 3, 4, 'VALID'),        # stride 4 > kernel 3: some input pixels receive no gradient at all
+    (2, 12, 16, 8, 8, 2, 2, 'SAME'),         # stride 2, kernel 2
 ]
 
 
