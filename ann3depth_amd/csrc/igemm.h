@@ -42,6 +42,10 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
   return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
 }
 
+// Out-of-range tile elements (padding halo, K / M / N tails) are LOADED from this zero line instead of being
+// branched around: the select is one v_cndmask on the address, the load itself is unconditional.
+__device__ __attribute__((aligned(16))) const float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+
 enum { MODE_FWD = 0, MODE_BWD_D = 1, MODE_BWD_F = 2 };
 enum { EPI_RELU = 1, EPI_SIGMOID = 2 };
 
@@ -182,13 +186,13 @@ struct Im2colTile {
         x >>= p.lstride;
       }
       ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      long off = ((long)pt.x + (long)y * p.W + x) * (long)p.ld + cd.c;
+      const uint32_t off = (uint32_t)(pt.x + y * p.W + x) * (uint32_t)p.ld + (uint32_t)cd.c;   // < 2^31 (check_desc)
+      const float* src = ok ? p.A + off : g_zero_line;
       if (VEC == 4) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.A + off);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src);
         regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
       } else {
-        regs[j][0] = ok ? p.A[off] : 0.f;
+        regs[j][0] = *src;
       }
     }
   }
@@ -223,13 +227,13 @@ struct PlainTile {
       int r = idx / CPR, cq = idx % CPR;
       int gr = row0 + r, gc = col0 + cq * VEC;
       bool ok = (TOTAL % NT == 0 || idx < TOTAL) && gr < rmax && gc < cmax;   // VEC=4 requires cmax % 4 == 0
-      long off = (long)gr * ld + gc;
+      const uint32_t off = (uint32_t)gr * (uint32_t)ld + (uint32_t)gc;
+      const float* ptr = ok ? src + off : g_zero_line;
       if (VEC == 4) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(src + off);
+        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
         regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
       } else {
-        regs[j][0] = ok ? src[off] : 0.f;
+        regs[j][0] = *ptr;
       }
     }
   }
@@ -271,18 +275,18 @@ struct FilterTTile {
       const uint32_t sp = rs - rp * p.div_s.d;
       rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
     }
-    long base = (long)rs * p.Cn * p.Cg + ko;
+    const uint32_t base = rs * (uint32_t)(p.Cn * p.Cg) + (uint32_t)ko;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int cin = n0 + r0 + j * RPP;
       bool ok = kvalid && cin < p.N;
-      long off = base + (long)cin * p.Cg;
+      const uint32_t off = base + (uint32_t)cin * (uint32_t)p.Cg;
+      const float* ptr = ok ? p.B + off : g_zero_line;
       if (VEC == 4) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.B + off);
+        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
         regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
       } else {
-        regs[j][0] = ok ? p.B[off] : 0.f;
+        regs[j][0] = *ptr;
       }
     }
   }
@@ -403,8 +407,14 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
   int cur = 0;
   for (int it = 0; it < nkt; ++it) {
     const int kt = kt_begin + it;
+#ifdef A3D_ABLATE_LOADS
+    const bool more = false;
+#else
     const bool more = it + 1 < nkt;
+#endif
+#ifndef A3D_ABLATE_GLOAD
     if (more) load_tiles(kt + 1, (it + 1) & 1);
+#endif
     if (MODE == MODE_BWD_F) {
       // table for tile kt+2 goes into the buffer tile kt used (all its loads were issued before the last barrier)
       if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
@@ -441,7 +451,9 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
       }
       // the next tile's global loads were issued before chunk 0; park them in the other LDS buffer ahead of the
       // last chunk's MFMAs so that only the barrier is left at the end of the tile
+#ifndef A3D_ABLATE_STORE
       if (u == BK / 8 - 1 && more) store_tiles(cur ^ 1);
+#endif
 #ifdef A3D_SETPRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
@@ -456,8 +468,12 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
+#ifndef A3D_ABLATE_BARRIER
     __syncthreads();
+#endif
+#ifndef A3D_ABLATE_LOADS
     cur ^= 1;
+#endif
   }
 
   // ---- epilogue ----

@@ -24,7 +24,11 @@ struct TileCfg {
 static const TileCfg kCfgs[] = {{128, 128, 1.00f, 32}, {128, 96, 1.00f, 32}, {128, 64, 0.92f, 32}, {128, 32, 0.60f, 32},
                                 {64, 64, 0.98f, 32},   {32, 128, 0.90f, 32}, {64, 128, 1.00f, 32},
                                 {128, 128, 1.15f, 32}, {128, 64, 1.05f, 32},      // 8-wave blocks
-                                {128, 128, 0.0f, 16},  {128, 64, 0.0f, 16}};      // 8-wave, BK = 16 (experimental)
+                                {128, 128, 0.0f, 16},  {128, 64, 0.0f, 16},       // 8-wave, BK = 16 (experimental)
+                                // LDS-DMA staged (igemm_glds.h), same order as A3D_GLDS_CFGS
+                                // sweep: the two 8-wave tiles gain 3-5 % in FWD, the rest tie or lose -> off (eff 0)
+                                {128, 128, 1.19f, 32}, {128, 64, 1.09f, 32}, {128, 96, 0.0f, 32}, {64, 64, 0.0f, 32},
+                                {32, 128, 0.0f, 32},   {64, 128, 0.0f, 32}};
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -43,8 +47,9 @@ struct TimingSlot {
 static std::mutex g_timing_mu;
 static bool g_timing_on = false;
 static std::vector<TimingSlot> g_timing;
-static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
-static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4, 4, 4, 4, 2, 1, 1};
+static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 4, 4, 4, 4};
+static const int kFirstGldsCfg = 11;
 
 // bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
 // (even at one block per CU for the two-plane x3 variant), and ~600 blocks with >= 12 k-tiles each fill the chip
@@ -76,7 +81,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
-    const int nk = (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk;
+    const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
     int splitk = std::max(1, std::min(force_split > 0 ? force_split : 1, nk));
     while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
     int kps = (nk + splitk - 1) / splitk;
@@ -91,6 +96,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   // Model picks are within 1.15x (mostly 1.05x) of the best measured configuration for every MSDN layer/direction.
   for (int c = 0; c < kNumCfgs; ++c) {
     if (kCfgs[c].eff <= 0.f) continue;
+    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4)) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;

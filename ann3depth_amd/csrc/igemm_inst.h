@@ -2,6 +2,7 @@
 // with A3D_MODE defined, so the three modes compile in parallel.
 #include "a3d_internal.h"
 #include "igemm.h"
+#include "igemm_glds.h"
 
 namespace a3d {
 
@@ -34,10 +35,40 @@ static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStre
   return launch_one<BM, BN, WAVES_M, NWAVES, BK, 1, 1>(p, grid, st);
 }
 
+// LDS-DMA staged variants (igemm_glds.h): index, BM, BN, WAVES_M, NWAVES, index of the register-staged twin used
+// when an operand is not 16-byte vectorisable
+#define A3D_GLDS_CFGS(X) X(11, 128, 128, 4, 8, 7) X(12, 128, 64, 4, 8, 8) X(13, 128, 96, 4, 4, 1) X(14, 64, 64, 2, 4, 4) \
+                         X(15, 32, 128, 1, 4, 5) X(16, 64, 128, 1, 4, 6)
+
+template <int BM, int BN, int WAVES_M, int NWAVES>
+static int launch_glds(IgemmParams& p, unsigned grid, hipStream_t st) {
+  using Cfg = GldsCfg<A3D_MODE, BM, BN, WAVES_M, NWAVES>;
+  auto kern = igemm_glds_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  clear_stale_error();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+  return check_launch("igemm_glds");
+}
+
 #define A3D_CAT_(a, b) a##b
 #define A3D_CAT(a, b) A3D_CAT_(a, b)
 
 int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
+  switch (cfg) {
+#define X(i, bm, bn, wm, nw, twin) \
+  case i:                          \
+    if (avec == 4 && bvec == 4) return launch_glds<bm, bn, wm, nw>(p, grid, st); \
+    cfg = twin;                    \
+    break;
+    A3D_GLDS_CFGS(X)
+#undef X
+  }
   switch (cfg) {
 #define X(i, bm, bn, wm, nw, bk) \
   case i: return launch_vec<bm, bn, wm, nw, bk>(avec, bvec, p, grid, st);
