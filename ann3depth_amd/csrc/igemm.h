@@ -407,14 +407,8 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
   int cur = 0;
   for (int it = 0; it < nkt; ++it) {
     const int kt = kt_begin + it;
-#ifdef A3D_ABLATE_LOADS
-    const bool more = false;
-#else
     const bool more = it + 1 < nkt;
-#endif
-#ifndef A3D_ABLATE_GLOAD
     if (more) load_tiles(kt + 1, (it + 1) & 1);
-#endif
     if (MODE == MODE_BWD_F) {
       // table for tile kt+2 goes into the buffer tile kt used (all its loads were issued before the last barrier)
       if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
@@ -451,12 +445,7 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
       }
       // the next tile's global loads were issued before chunk 0; park them in the other LDS buffer ahead of the
       // last chunk's MFMAs so that only the barrier is left at the end of the tile
-#ifndef A3D_ABLATE_STORE
       if (u == BK / 8 - 1 && more) store_tiles(cur ^ 1);
-#endif
-#ifdef A3D_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -464,16 +453,9 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
-#ifdef A3D_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
-#ifndef A3D_ABLATE_BARRIER
     __syncthreads();
-#endif
-#ifndef A3D_ABLATE_LOADS
     cur ^= 1;
-#endif
   }
 
   // ---- epilogue ----
