@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import data, dp, models
+from . import _lib, data, dp, models
 
 
 def main(argv=None):
@@ -115,6 +115,7 @@ class Session:
         self.ckpt_secs, self.sum_steps, self.trace_every = save_checkpoint_secs, save_summaries_steps, trace_every
         self.log, self.world = logger, world
         self.stop = False
+        self.trace_next = True               # TraceHook: the first step after every (re)start is traced
         self.t_last_ckpt = time.time()
         self.t_last_sum, self.step_last_sum = time.time(), None
         self.summaries = None
@@ -146,13 +147,21 @@ class Session:
 
     def run(self, train_op):
         rep = train_op.replica
+        tracing = self.trace_next and self.dir is not None
+        if tracing:
+            _lib.load().a3d_timing_enable(1)
         try:
             out = train_op.run()
         except data.OutOfRangeError as e:
             self.log.info(f'Input pipeline exhausted: {e}')
             self.stop = True
             return None
+        finally:
+            if tracing:
+                self._write_trace(rep.global_step)
         step = rep.global_step
+        # tfhelper.TraceHook (src/tfhelper.py:192-249): trace the first step and every `trace_every`-th global step
+        self.trace_next = bool(self.trace_every) and (step + 1) % self.trace_every == 0
         if self.sig.signal_received:                                     # StopAtSignalHook.after_run
             self.stop = True
         if self.sum_steps and step % self.sum_steps == 0:
@@ -169,6 +178,20 @@ class Session:
         if self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs:
             self.save()
         return out
+
+    def _write_trace(self, step):
+        """Per-launch timings of the implicit-GEMM kernels of one step (hipEvent pairs recorded by the library),
+        the stand-in for the reference's RunMetadata FULL_TRACE; whole-process traces come from rocprofv3."""
+        lib = _lib.load()
+        lib.a3d_timing_enable(0)
+        cap = 4096
+        arr = (_lib.TimingRecord * cap)()
+        n = lib.a3d_timing_collect(arr, cap)
+        recs = [{'mode': ('fwd', 'bwd_data', 'bwd_filter')[r.mode], 'tile': f'{r.bm}x{r.bn}', 'waves': r.nwaves,
+                 'precision': ('fp32', 'bf16x3', 'bf16')[r.prec], 'splitk': r.splitk, 'm': r.m, 'n': r.n, 'k': r.k,
+                 'ms': round(r.ms, 4), 'tflops': round(r.flops / max(r.ms, 1e-6) / 1e9, 1)} for r in arr[:n]]
+        with open(os.path.join(self.dir, f'trace-{step}.json'), 'w') as f:
+            json.dump({'global_step': step, 'launches': recs}, f)
 
     def save(self):
         rep = self.op.replica

@@ -66,6 +66,9 @@ def test_make_train_drop_in(tmp_path):
     assert ann3depth.main(base + ['--steps', '6', 'nyu']) == 0
     d = os.path.join(ck, 'msdn_r1')                                       # <ckptdir>/<model>_<id>, src/ann3depth.py:73-75
     assert ann3depth.latest_checkpoint(d).endswith('model.ckpt-6.pt')
+    trace = json.load(open(os.path.join(d, 'trace-1.json')))                # TraceHook: first step after start
+    assert trace['global_step'] == 1 and len(trace['launches']) > 20
+    assert all(r['ms'] > 0 for r in trace['launches'])
     sums = [json.loads(l) for l in open(os.path.join(d, 'summaries.jsonl'))]
     assert [s['global_step'] for s in sums] == [2, 4, 6]
     assert all(np.isfinite(s['coarse/coarse_loss']) and s['Phase'] == 1 for s in sums)
