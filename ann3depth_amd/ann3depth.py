@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import _lib, data, dp, models
+from . import _lib, data, dp, models, summary
 
 
 def main(argv=None):
@@ -119,6 +119,7 @@ class Session:
         self.t_last_ckpt = time.time()
         self.t_last_sum, self.step_last_sum = time.time(), None
         self.summaries = None
+        self.events = None
 
     def __enter__(self):
         rep = self.op.replica
@@ -139,6 +140,7 @@ class Session:
         if self.dir:
             os.makedirs(self.dir, exist_ok=True)
             self.summaries = open(os.path.join(self.dir, 'summaries.jsonl'), 'a')
+            self.events = summary.EventFileWriter(self.dir)
         self.step_last_sum = rep.global_step
         return self
 
@@ -167,13 +169,19 @@ class Session:
         if self.sum_steps and step % self.sum_steps == 0:
             now = time.time()
             rate = (step - self.step_last_sum) / max(now - self.t_last_sum, 1e-9)
-            rec = {'global_step': step, 'coarse/coarse_loss': float(out['coarse_loss']),
-                   'fine/fine_loss': float(out['fine_loss']), 'Phase': out['phase'],
+            # tag names as the reference's summaries: name scopes 'loss' (src/models.py:288) and 'optimizers' (:347)
+            rec = {'global_step': step, 'loss/coarse_loss': float(out['coarse_loss']),
+                   'loss/fine_loss': float(out['fine_loss']), 'optimizers/Phase': out['phase'],
                    'global_step/sec': rate, 'images/sec': rate * rep.B * self.world}
             self.log.info('global_step/sec: %.4g  %s', rate, json.dumps(rec))
             if self.summaries:
                 self.summaries.write(json.dumps(rec) + '\n')
                 self.summaries.flush()
+                self.events.add_scalars(step, {k: v for k, v in rec.items() if k != 'global_step'})
+                for tag, t in (('summaries/Input', rep.x), ('summaries/Coarse', rep.coarse),
+                               ('summaries/Fine', rep.fine), ('summaries/Target', rep.t)):   # src/models.py:292-296
+                    self.events.add_images(step, tag, t[:3].cpu().numpy())
+                self.events.flush()
             self.t_last_sum, self.step_last_sum = now, step
         if self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs:
             self.save()
@@ -211,6 +219,8 @@ class Session:
             self.save()                                                  # session close saves a final checkpoint
         if self.summaries:
             self.summaries.close()
+        if self.events:
+            self.events.close()
         return False
 
 

@@ -71,7 +71,8 @@ def test_make_train_drop_in(tmp_path):
     assert all(r['ms'] > 0 for r in trace['launches'])
     sums = [json.loads(l) for l in open(os.path.join(d, 'summaries.jsonl'))]
     assert [s['global_step'] for s in sums] == [2, 4, 6]
-    assert all(np.isfinite(s['coarse/coarse_loss']) and s['Phase'] == 1 for s in sums)
+    assert all(np.isfinite(s['loss/coarse_loss']) and s['optimizers/Phase'] == 1 for s in sums)
+    assert any(f.startswith('events.out.tfevents.') for f in os.listdir(d))
     sd = torch.load(ann3depth.latest_checkpoint(d))
     assert int(sd['global_step']) == 6
     assert 'coarse/conv/conv2d_0/kernel' in sd and 'coarse/conv/conv2d_0/kernel/CoarseConv' in sd
