@@ -45,3 +45,36 @@ def test_gemm_code_objects_are_gfx950_mfma():
         return
     out = subprocess.run([objdump, '--offloading', _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert 'gfx950' in out
+
+
+def test_planner_handles_every_layer_shape_on_the_host():
+    """The tile / split-K planner runs on the host inside the *_ws_bytes queries: every MSDN (B = 32, 64) and DCNF
+    (B = 16 -> 768 patches) layer, every direction and precision must get a plan with a bounded workspace."""
+    from ann3depth_amd import models, ops
+    lib = _lib.load()
+    import ctypes
+    descs = []
+    for B in (1, 32, 64):
+        for prec in ('fp32', 'bf16x3', 'bf16'):
+            descs += [ops.conv_desc(B, 228, 304, 3, 96, 11, 11, 4, 'VALID', precision=prec),
+                      ops.conv_desc(B, 27, 37, 96, 256, 5, 5, 1, 'SAME', precision=prec),
+                      ops.conv_desc(B, 13, 18, 256, 384, 3, 3, 1, 'SAME', precision=prec),
+                      ops.conv_desc(B, 13, 18, 384, 384, 3, 3, 1, 'SAME', precision=prec),
+                      ops.conv_desc(B, 13, 18, 384, 256, 3, 3, 2, 'VALID', precision=prec),
+                      ops.conv_desc(B, 228, 304, 3, 63, 9, 9, 2, 'VALID', precision=prec),
+                      ops.conv_desc(B, 55, 74, 64, 64, 5, 5, 1, 'SAME', ldx=64, precision=prec),
+                      ops.conv_desc(B, 55, 74, 64, 1, 5, 5, 1, 'SAME', precision=prec)]
+    P = 768
+    h = 100
+    for n, ci, co, k in models.DCNF_CONVS:
+        descs.append(ops.conv_desc(P, h, h, ci, co, k, k, 1, 'VALID'))
+        h = h - k + 1
+        if n in models.DCNF_POOL_AFTER:
+            h //= 2
+    for d in descs:
+        for fn in (lib.a3d_conv2d_fwd_ws_bytes, lib.a3d_conv2d_bwd_data_ws_bytes, lib.a3d_conv2d_bwd_filter_ws_bytes):
+            ws = fn(ctypes.byref(d))
+            assert 0 <= ws <= 200 << 20, (d.n, d.c, d.k, d.r, fn.__name__, ws)
+    for m, k, n in [(32, 12288, 4096), (32, 4096, 4070), (64, 12288, 4096), (768, 12544, 128), (768, 128, 16), (768, 16, 1)]:
+        for fn in (lib.a3d_dense_fwd_ws_bytes, lib.a3d_dense_bwd_data_ws_bytes, lib.a3d_dense_bwd_filter_ws_bytes):
+            assert 0 <= fn(m, k, n) <= 200 << 20
