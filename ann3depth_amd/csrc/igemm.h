@@ -505,6 +505,7 @@ struct ReduceParams {
   const float* ws; float* C; const float* bias; const float* mask; const uint8_t* keep; float mask_scale;
   int M, N, ldc, splitk, act, mode, mask_act; size_t slab;
   int sub_step, sub_ph, sub_pw, outW, outHW; FastDiv div_phw, div_pw;     // BWD_D parity-class row remap
+  int vec4;              // plain 16-byte sum (bwd-filter slabs)
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
 

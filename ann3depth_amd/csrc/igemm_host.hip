@@ -33,6 +33,8 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
 
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -127,11 +129,42 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   return best;
 }
 
+// Sums the split-K slabs in slab order (deterministic) and applies the epilogue.  Slab reads are issued four at a
+// time into independent registers: a thread's serial chain of `splitk` dependent loads was the cost of this kernel.
+__device__ __forceinline__ float slab_sum(const float* ws, size_t slab, int splitk, size_t i) {
+  float s = 0.f;
+  int z = 0;
+  for (; z + 4 <= splitk; z += 4) {
+    const float a = ws[(size_t)z * slab + i], b = ws[(size_t)(z + 1) * slab + i];
+    const float c = ws[(size_t)(z + 2) * slab + i], d = ws[(size_t)(z + 3) * slab + i];
+    s += a; s += b; s += c; s += d;
+  }
+  for (; z < splitk; ++z) s += ws[(size_t)z * slab + i];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   const size_t total = (size_t)p.M * p.N;
+  if (p.vec4) {   // plain sum of 16-byte columns: bwd-filter slabs (no epilogue, contiguous output)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const size_t nv = total / 4;
+    const f4* ws4 = reinterpret_cast<const f4*>(p.ws);
+    const size_t slab4 = p.slab / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+      f4 s = {0.f, 0.f, 0.f, 0.f};
+      int z = 0;
+      for (; z + 4 <= p.splitk; z += 4) {
+        const f4 a = ws4[(size_t)z * slab4 + i], b = ws4[(size_t)(z + 1) * slab4 + i];
+        const f4 c = ws4[(size_t)(z + 2) * slab4 + i], d = ws4[(size_t)(z + 3) * slab4 + i];
+        s += a; s += b; s += c; s += d;
+      }
+      for (; z < p.splitk; ++z) s += ws4[(size_t)z * slab4 + i];
+      reinterpret_cast<f4*>(p.C)[i] = s;
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * p.slab + i];
+    float s = slab_sum(p.ws, p.slab, p.splitk, i);
     const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
     const size_t o = remap_row(row, p.mode == MODE_BWD_D ? p.sub_step : 1, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw,
                                p.div_pw) * p.ldc + col;
@@ -198,10 +231,11 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
     r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act;
+    r.vec4 = mode == MODE_BWD_F && p.ldc == p.N && (p.slab % 4) == 0 && aligned16(final_c) && aligned16(ws);
     r.sub_step = p.sub_step; r.sub_ph = p.sub_ph; r.sub_pw = p.sub_pw; r.outW = p.outW; r.outHW = p.outHW;
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     size_t total = (size_t)p.M * p.N;
-    unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 2048);
+    unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
     clear_stale_error();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
     rc = check_launch("splitk_reduce");
@@ -241,7 +275,6 @@ static int check_desc(const a3d_conv_desc* d) {
   return A3D_OK;
 }
 
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 struct ConvProblem {
   GemmProblem g;
