@@ -25,7 +25,7 @@ class ExampleView(ctypes.Structure):
 
 class TimingRecord(ctypes.Structure):
     """struct a3d_timing_record"""
-    _fields_ = [(n, c_int32) for n in ('mode', 'bm', 'bn', 'waves_m', 'nwaves', 'bk', 'avec', 'bvec', 'prec', 'splitk', 'm', 'n', 'k')] + \
+    _fields_ = [(n, c_int32) for n in ('mode', 'bm', 'bn', 'waves_m', 'nwaves', 'bk', 'avec', 'bvec', 'prec', 'lds_dma', 'splitk', 'm', 'n', 'k')] + \
                [('ms', c_float), ('flops', ctypes.c_double)]
 
 

@@ -219,6 +219,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     } else {
       r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
       r.nwaves = kCfgNWaves[plan.cfg]; r.bk = kCfgs[plan.cfg].bk;
+      r.lds_dma = plan.cfg >= kFirstGldsCfg && avec == 4 && bvec == 4;
     }
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;

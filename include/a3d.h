@@ -131,6 +131,7 @@ typedef struct a3d_timing_record {
   int32_t mode;        /* 0 fwd, 1 bwd-data, 2 bwd-filter */
   int32_t bm, bn, waves_m, nwaves, bk, avec, bvec;   /* igemm_kernel<mode,bm,bn,waves_m,nwaves,bk,avec,bvec> */
   int32_t prec;        /* A3D_PREC_*; for bf16 modes the kernel is igemm_bf16_kernel<mode,bm,bn,x3> */
+  int32_t lds_dma;     /* 1: igemm_glds_kernel<mode,bm,bn,waves_m,nwaves> (tiles staged by global_load_lds) */
   int32_t splitk;
   int32_t m, n, k;     /* GEMM extents of the launch */
   float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */
