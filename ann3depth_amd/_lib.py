@@ -64,6 +64,7 @@ SIGNATURES = {
     'a3d_tfrecord_next': (c_int, [_P, c_size_t, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t)]),
     'a3d_example_parse': (c_int, [_P, c_size_t, POINTER(ExampleView)]),
     'a3d_decode_raw_plus_half': (c_int, [_P, c_size_t, _P]),
+    'a3d_record_decode': (c_int, [_P, c_size_t, c_int, _P, c_size_t, _P, c_size_t, POINTER(ExampleView)]),
     'a3d_example_write': (c_int64, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_size_t]),
 }
 

@@ -50,9 +50,8 @@ def _read(files, epochs, rank=0, world=1):
 
 
 def _convert_img_depth(rf, off, ln, image, depth):
-    """src/data.py:70-86, decoding into the destination arrays (after the record's payload CRC check)."""
-    rf.verify_payload(off, ln)
-    rf.parse_into(off, ln, image, depth)
+    """src/data.py:70-86, decoding into the destination arrays; the record's payload CRC is checked in the same pass."""
+    rf.decode_into(off, ln, image, depth)
 
 
 def _get_pipeline(dataset):

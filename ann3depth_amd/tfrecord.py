@@ -115,6 +115,19 @@ class RecordFile:
         check(lib.a3d_decode_raw_plus_half(ev.image, ev.image_bytes, image.ctypes.data), 'a3d_decode_raw_plus_half')
         check(lib.a3d_decode_raw_plus_half(ev.depth, ev.depth_bytes, depth.ctypes.data), 'a3d_decode_raw_plus_half')
 
+    def decode_into(self, offset, length, image, depth, verify_crc=True):
+        """Reader fast path: CRC check + parse + decode of the record whose payload is at (offset, length), in one pass
+        over its bytes (a3d_record_decode).  image / depth are caller-owned float32 arrays of the record's shapes."""
+        ev = ExampleView()
+        check(_lib.load().a3d_record_decode(self.base + offset - 12, length + 16, int(verify_crc), image.ctypes.data,
+                                            image.size, depth.ctypes.data, depth.size, ctypes.byref(ev)),
+              f'a3d_record_decode({self.path}@{offset})')
+        ishape = (ev.image_height, ev.image_width, ev.image_channels)
+        dshape = (ev.depth_height, ev.depth_width, ev.depth_channels)
+        if tuple(image.shape) != ishape or tuple(depth.shape) != dshape:
+            raise ValueError(f'{self.path}: record is {ishape}/{dshape}, destination is '
+                             f'{tuple(image.shape)}/{tuple(depth.shape)}: records of different sizes cannot be batched')
+
     def parse(self, offset, length):
         """-> (image [H,W,C], depth [H,W,C']) float32 with '+ 0.5'.  Sizes come from the record's own size features
         (the reference hard-codes 480x640, src/data.py:84-85)."""

@@ -160,6 +160,11 @@ int a3d_tfrecord_next(const uint8_t* buf, size_t len, int verify_crc, size_t* pa
 int a3d_example_parse(const uint8_t* payload, size_t len, a3d_example_view* out);
 /* data._convert_img_depth (src/data.py:82-85): dst[i] = src_le_f32[i] + 0.5 */
 int a3d_decode_raw_plus_half(const uint8_t* src, size_t bytes, float* dst);
+/* Reader fast path: one framed record at `frame` -> payload CRC check (if verify_crc), Example parse and
+ * decode_raw + 0.5 of both features into image_dst / depth_dst (float counts must match the record) in a single pass
+ * over the bytes.  *view (optional) receives the size features. */
+int a3d_record_decode(const uint8_t* frame, size_t len, int verify_crc, float* image_dst, size_t image_floats,
+                      float* depth_dst, size_t depth_floats, a3d_example_view* view);
 /* Serialise one framed record (writer side).  Returns bytes written, or the needed size if cap is too small
  * (nothing written then), or a negative error. */
 int64_t a3d_example_write(const float* image, int ih, int iw, int ic, const float* depth, int dh, int dw, int dc,

@@ -205,3 +205,29 @@ def test_inputs_sharding_and_endless_epochs(tmp_path):
     for _ in range(3 * n // B):
         inp.pipeline.next_batch()
     inp.pipeline.close()
+
+
+def test_pipeline_surfaces_corrupt_and_mismatched_records(tmp_path):
+    """The reader threads verify each payload CRC inside the fused decode; a flipped bit or a record of another size
+    must stop the pipeline with an error, never be batched."""
+    B = 2
+    _write_dataset(str(tmp_path), 'nyu', 16, 4, 4, 2, 2)
+    path = tmp_path / 'nyu' / 'train.tfrecords'
+    raw = bytearray(path.read_bytes())
+    raw[len(raw) // 2] ^= 0x01                                   # somewhere inside a payload
+    path.write_bytes(bytes(raw))
+    inp, _ = data.inputs(str(tmp_path), 'nyu', B, epochs=1, seed=0, num_threads=2)
+    with pytest.raises(_lib.A3dError, match='corrupt'):
+        while True:
+            inp.pipeline.next_batch()
+    # records of two different sizes in one shard
+    d2 = tmp_path / 'mixed'
+    rng = np.random.default_rng(0)
+    with tfrecord.TFRecordWriter(str(d2 / 'nyu' / 'train.tfrecords')) as w:
+        for i in range(12):
+            hw = (4, 4) if i < 11 else (4, 6)
+            w.write_example(_stored(rng, hw[0], hw[1], 3), _stored(rng, 2, 2, 1))
+    inp, _ = data.inputs(str(d2), 'nyu', B, epochs=1, seed=0, num_threads=1)
+    with pytest.raises((_lib.A3dError, ValueError)):
+        while True:
+            inp.pipeline.next_batch()
