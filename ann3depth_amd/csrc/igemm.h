@@ -46,6 +46,34 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // branched around: the select is one v_cndmask on the address, the load itself is unconditional.
 __device__ __attribute__((aligned(16))) const float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// VEC (1, 2 or 4) consecutive floats <-> registers, as one 4 / 8 / 16-byte access
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* src, float (&out)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+  } else if constexpr (VEC == 2) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(src);
+    out[0] = v[0]; out[1] = v[1];
+  } else {
+    out[0] = *src;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* dst, const float (&in)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f32x4 v = {in[0], in[1], in[2], in[3]};
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else if constexpr (VEC == 2) {
+    const f32x2 v = {in[0], in[1]};
+    *reinterpret_cast<f32x2*>(dst) = v;
+  } else {
+    *dst = in[0];
+  }
+}
+
 enum { MODE_FWD = 0, MODE_BWD_D = 1, MODE_BWD_F = 2 };
 enum { EPI_RELU = 1, EPI_SIGMOID = 2 };
 
@@ -187,13 +215,7 @@ struct Im2colTile {
       }
       ok = ok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       const uint32_t off = (uint32_t)(pt.x + y * p.W + x) * (uint32_t)p.ld + (uint32_t)cd.c;   // < 2^31 (check_desc)
-      const float* src = ok ? p.A + off : g_zero_line;
-      if (VEC == 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(src);
-        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
-      } else {
-        regs[j][0] = *src;
-      }
+      load_vec<VEC>(ok ? p.A + off : g_zero_line, regs[j]);
     }
   }
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
@@ -202,12 +224,7 @@ struct Im2colTile {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
-      if (VEC == 4) {
-        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        dst[0] = regs[j][0];
-      }
+      store_vec<VEC>(dst, regs[j]);
     }
   }
 };
@@ -228,13 +245,7 @@ struct PlainTile {
       int gr = row0 + r, gc = col0 + cq * VEC;
       bool ok = (TOTAL % NT == 0 || idx < TOTAL) && gr < rmax && gc < cmax;   // VEC=4 requires cmax % 4 == 0
       const uint32_t off = (uint32_t)gr * (uint32_t)ld + (uint32_t)gc;
-      const float* ptr = ok ? src + off : g_zero_line;
-      if (VEC == 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
-        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
-      } else {
-        regs[j][0] = *ptr;
-      }
+      load_vec<VEC>(ok ? src + off : g_zero_line, regs[j]);
     }
   }
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
@@ -244,12 +255,7 @@ struct PlainTile {
       if (TOTAL % NT != 0 && idx >= TOTAL) continue;
       int r = idx / CPR, cq = idx % CPR;
       float* dst = lds + r * ld + cq * VEC;
-      if (VEC == 4) {
-        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        dst[0] = regs[j][0];
-      }
+      store_vec<VEC>(dst, regs[j]);
     }
   }
 };
@@ -281,13 +287,7 @@ struct FilterTTile {
       int cin = n0 + r0 + j * RPP;
       bool ok = kvalid && cin < p.N;
       const uint32_t off = base + (uint32_t)cin * (uint32_t)p.Cg;
-      const float* ptr = ok ? p.B + off : g_zero_line;
-      if (VEC == 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
-        regs[j][0] = v[0]; regs[j][1 % VEC] = v[1]; regs[j][2 % VEC] = v[2]; regs[j][3 % VEC] = v[3];
-      } else {
-        regs[j][0] = *ptr;
-      }
+      load_vec<VEC>(ok ? p.B + off : g_zero_line, regs[j]);
     }
   }
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
@@ -296,12 +296,7 @@ struct FilterTTile {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
-      if (VEC == 4) {
-        f32x4 v = {regs[j][0], regs[j][1 % VEC], regs[j][2 % VEC], regs[j][3 % VEC]};
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-        dst[0] = regs[j][0];
-      }
+      store_vec<VEC>(dst, regs[j]);
     }
   }
 };

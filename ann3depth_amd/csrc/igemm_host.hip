@@ -252,6 +252,54 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   return rc;
 }
 
+// ---- "window-run" form of few-channel VALID convolutions (Cin = 3: conv2d_0, fine/first) ----
+// For an unpadded conv with densely packed pixels a filter row (s, c) is ONE contiguous run of S*Cin floats of the
+// input, starting stride*Cin floats after the previous output pixel's run.  When those starts are 16- (or 8-) byte
+// aligned the run is gathered with vector loads instead of float by float: the K axis becomes (r, q) with q padded
+// to a multiple of the vector width, the padded filter rows are zero, and the generic kernel sees a conv with S' = 1
+// and Cin' = padded run length.  The few floats read past a run belong to the next pixels of the same image row
+// (guaranteed in-bounds by run_form_ok) and meet zero weights.
+struct RunForm {
+  int vec;      // 4 or 2
+  int rl, rlp;  // run length S*Cin and its padded length
+  int kp;       // R * rlp
+};
+static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
+  if (d->pad_t || d->pad_l || d->ldx != d->c || d->c % 4 == 0 || d->c > 4) return false;
+  if (env_int("A3D_NO_RUNFORM", 0)) return false;
+  const int step = d->stride * d->c, row = d->w * d->c;
+  int vec = 0;
+  if (step % 4 == 0 && row % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) vec = 4;
+  else if (step % 2 == 0 && row % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) vec = 2;
+  if (!vec) return false;
+  rf->vec = vec;
+  rf->rl = d->s * d->c;
+  rf->rlp = (rf->rl + vec - 1) / vec * vec;
+  rf->kp = d->r * rf->rlp;
+  return (d->wo - 1) * step + rf->rlp <= row;      // the padded run of the last output column stays inside its row
+}
+
+// filter [R*RL][N] <-> padded [R*RLP][N] (pad rows zero)
+__global__ __launch_bounds__(256) void pad_filter_kernel(const float* w, float* wp, int r, int rl, int rlp, int n) {
+  const int total = r * rlp * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int col = i % n, row = i / n;
+    const int q = row % rlp, rr = row / rlp;
+    wp[i] = q < rl ? w[(size_t)(rr * rl + q) * n + col] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void unpad_filter_kernel(const float* wp, float* w, int r, int rl, int rlp, int n) {
+  const int total = r * rl * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int col = i % n, row = i / n;
+    const int q = row % rl, rr = row / rl;
+    w[i] = wp[(size_t)(rr * rlp + q) * n + col];
+  }
+}
+static size_t run_filter_bytes(const a3d_conv_desc* d, const RunForm& rf) {
+  return ((size_t)rf.kp * d->k * 4 + 255) / 256 * 256;
+}
+
 // ---- descriptor checks / parameter assembly ----
 static int ilog2_exact(int v) {
   for (int l = 0; l < 8; ++l)
@@ -348,7 +396,14 @@ int a3d_timing_collect(a3d_timing_record* out, int cap) {
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
-  return plan_gemm(fwd_problem(d), d->precision).ws_bytes;
+  size_t need = plan_gemm(fwd_problem(d), d->precision).ws_bytes;
+  RunForm rf;
+  if (run_form_ok(d, nullptr, &rf)) {
+    GemmProblem g = fwd_problem(d);
+    g.K = rf.kp; g.avec = rf.vec;
+    need = std::max(need, run_filter_bytes(d, rf) + plan_gemm(g, d->precision).ws_bytes);
+  }
+  return need;
 }
 
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
@@ -358,22 +413,40 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
   if (stencil1_applicable(d)) return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
   GemmProblem g = fwd_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
+  RunForm rf{};
+  const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
+  size_t ws_used = 0;
+  const float* filter = w;
+  if (run) {                                   // window-run form: K = (r, padded run), filter padded into the workspace
+    g.K = rf.kp; g.avec = rf.vec;
+    ws_used = run_filter_bytes(d, rf);
+    float* wp = static_cast<float*>(ws);
+    clear_stale_error();
+    hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * d->k + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
+                       rf.rlp, d->k);
+    rc = check_launch("pad_filter");
+    if (rc != A3D_OK) return rc;
+    filter = wp;
+    g.bvec = (d->k % 4 == 0) ? 4 : 1;           // the padded copy is 256-byte aligned
+  }
   GemmPlan plan = plan_gemm(g, d->precision);
-  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", plan.ws_bytes);
+  if (ws_used + plan.ws_bytes > ws_bytes)
+    return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
-  p.A = x; p.B = w; p.C = y; p.bias = bias; p.act = act;
+  p.A = x; p.B = filter; p.C = y; p.bias = bias; p.act = act;
   p.npix = g.M; p.nrsc = g.K;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
   p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-  p.S = d->s; p.Cg = d->c;
+  p.S = run ? 1 : d->s; p.Cg = run ? rf.rlp : d->c;
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
-  p.div_c = make_fastdiv(d->c); p.div_s = make_fastdiv(d->s);
+  p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
   p.ldb = d->k; p.ldc = d->ldy;
-  return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
+  return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
 }
 
 // One parity class (ph, pw) of a strided bwd-data as a stride-1 problem; false if the class has no pixels.
@@ -450,7 +523,15 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
   GemmPlan plan = plan_gemm(bwd_f_problem(d), d->precision);
-  return plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
+  size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
+  RunForm rf;
+  if (run_form_ok(d, nullptr, &rf)) {
+    GemmProblem g = bwd_f_problem(d);
+    g.M = rf.kp; g.avec = rf.vec;
+    GemmPlan pr = plan_gemm(g, d->precision);
+    need = std::max(need, run_filter_bytes(d, rf) + pr.ws_bytes + (pr.splitk > 1 ? (size_t)pr.splitk * d->k * 4 : 0));
+  }
+  return need;
 }
 
 int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
@@ -465,21 +546,35 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   GemmProblem g = bwd_f_problem(d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(dz)) g.bvec = 1;
+  RunForm rf{};
+  const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
+  size_t ws_used = 0;
+  float* out = dw;
+  if (run) {                                   // window-run form: gradient of the PADDED filter, unpadded afterwards
+    g.M = rf.kp; g.avec = rf.vec;
+    ws_used = run_filter_bytes(d, rf);
+    out = static_cast<float*>(ws);
+  }
   GemmPlan plan = plan_gemm(g, d->precision);
-  size_t need = plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
+  size_t need = ws_used + plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   IgemmParams p;
   fill_common(p, g);
-  p.A = x; p.B = dz; p.C = dw; p.dbias = db;      // BiasAddGrad = column sums of dz, fused into the same kernel
+  p.A = x; p.B = dz; p.C = out; p.dbias = db;     // BiasAddGrad = column sums of dz, fused into the same kernel
   p.npix = g.K; p.nrsc = g.M;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
   p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-  p.S = d->s; p.Cg = d->c;
+  p.S = run ? 1 : d->s; p.Cg = run ? rf.rlp : d->c;
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
-  p.div_c = make_fastdiv(d->c); p.div_s = make_fastdiv(d->s);
+  p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
   p.ldb = d->ldy; p.ldc = d->k;
-  return launch_igemm(MODE_BWD_F, plan, g.avec, g.bvec, p, ws, st);
+  rc = launch_igemm(MODE_BWD_F, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
+  if (rc != A3D_OK || !run) return rc;
+  clear_stale_error();
+  hipLaunchKernelGGL(unpad_filter_kernel, dim3((d->r * rf.rl * d->k + 255) / 256), dim3(256), 0, st, out, dw, d->r,
+                     rf.rl, rf.rlp, d->k);
+  return check_launch("unpad_filter");
 }
 
 // ---- dense = 1x1 conv over a 1x1 image ----

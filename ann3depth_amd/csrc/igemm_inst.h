@@ -32,6 +32,8 @@ static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStre
   if (avec == 4 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 4, 4>(p, grid, st);
   if (avec == 4 && bvec == 1) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 4, 1>(p, grid, st);
   if (avec == 1 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 1, 4>(p, grid, st);
+  if (avec == 2 && bvec == 4) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 2, 4>(p, grid, st);   // 8-byte window runs
+  if (avec == 2 && bvec == 1) return launch_one<BM, BN, WAVES_M, NWAVES, BK, 2, 1>(p, grid, st);
   return launch_one<BM, BN, WAVES_M, NWAVES, BK, 1, 1>(p, grid, st);
 }
 

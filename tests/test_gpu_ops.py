@@ -30,7 +30,9 @@ def ops():
 
 CONV_CASES = [
     # n, h, w, c, k, ksize, stride, padding            (edge cases of SURVEY 8c golden plan + every MSDN/DCNF layer kind)
-    (2, 35, 47, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind: Cin=3 scalar gather, N=96 tile
+    (2, 35, 47, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind: Cin=3 scalar gather (odd row length), N=96 tile
+    (2, 35, 48, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind in window-run form: 16-byte runs of 33 -> 36 floats
+    (1, 228, 304, 3, 96, 11, 4, 'VALID'),    # conv2d_0 itself (one image): last run ends exactly at the row end
     (2, 27, 37, 96, 256, 5, 1, 'SAME'),      # conv2d_1 at full spatial size
     (3, 13, 18, 256, 384, 3, 1, 'SAME'),     # conv2d_2
     (2, 13, 18, 384, 256, 3, 2, 'VALID'),    # conv2d_4: stride-2 VALID 13x18 -> 6x8
