@@ -152,3 +152,20 @@ def test_msdn_bf16_modes_keep_the_depth_tolerance(models, prec, tol):
         g = O.backward_coarse(params, a_gpu)
         for n, gref in g.items():
             assert rel(net.grad(n).cpu().numpy(), gref) < 2e-4, n
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_msdn_odd_batch_sizes(models, B):
+    """Batch sizes that leave ragged M tiles in every layer (B = 1: M = 4070, 999, 234, 48 ...)."""
+    img, dep, keep = synth(B, 77, 96, 128)
+    params = O.init_params(3000)
+    net = models.MSDNReplica(B, params=params)
+    net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    torch.cuda.synchronize()
+    a = O.forward(params, img, dep, keep)
+    assert rel(net.coarse.cpu().numpy(), a['coarse']) < DEPTH_TOL
+    assert rel(net.fine.cpu().numpy(), a['fine']) < DEPTH_TOL
+    a_gpu = gpu_activations(net)
+    a_gpu['keep_mask'] = keep
+    for n, gref in O.backward_coarse(params, a_gpu).items():
+        assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
