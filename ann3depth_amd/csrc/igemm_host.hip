@@ -24,11 +24,9 @@ struct TileCfg {
 static const TileCfg kCfgs[] = {{128, 128, 1.00f, 32}, {128, 96, 1.00f, 32}, {128, 64, 0.92f, 32}, {128, 32, 0.60f, 32},
                                 {64, 64, 0.98f, 32},   {32, 128, 0.90f, 32}, {64, 128, 1.00f, 32},
                                 {128, 128, 1.15f, 32}, {128, 64, 1.05f, 32},      // 8-wave blocks
-                                {128, 128, 0.0f, 16},  {128, 64, 0.0f, 16},       // 8-wave, BK = 16 (experimental)
-                                // LDS-DMA staged (igemm_glds.h), same order as A3D_GLDS_CFGS
-                                // sweep: the two 8-wave tiles gain 3-5 % in FWD, the rest tie or lose -> off (eff 0)
-                                {128, 128, 1.19f, 32}, {128, 64, 1.09f, 32}, {128, 96, 0.0f, 32}, {64, 64, 0.0f, 32},
-                                {32, 128, 0.0f, 32},   {64, 128, 0.0f, 32}};
+                                // LDS-DMA staged (igemm_glds.h), same order as A3D_GLDS_CFGS; forward only (sweep:
+                                // +3-5 % there, ties or loses in the other directions and on the other tiles)
+                                {128, 128, 1.19f, 32}, {128, 64, 1.09f, 32}};
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -49,9 +47,9 @@ struct TimingSlot {
 static std::mutex g_timing_mu;
 static bool g_timing_on = false;
 static std::vector<TimingSlot> g_timing;
-static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4, 4, 4, 4, 2, 1, 1};
-static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 4, 4, 4, 4};
-static const int kFirstGldsCfg = 11;
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
+static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
+static const int kFirstGldsCfg = 9;
 
 // bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
 // (even at one block per CU for the two-plane x3 variant), and ~600 blocks with >= 12 k-tiles each fill the chip

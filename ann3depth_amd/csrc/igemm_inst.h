@@ -9,7 +9,7 @@ namespace a3d {
 // index, BM, BN, WAVES_M, NWAVES, BK  (keep in step with kCfgs in igemm_host.hip)
 #define A3D_CFGS(X) X(0, 128, 128, 2, 4, 32) X(1, 128, 96, 4, 4, 32) X(2, 128, 64, 4, 4, 32) X(3, 128, 32, 4, 4, 32) \
                     X(4, 64, 64, 2, 4, 32) X(5, 32, 128, 1, 4, 32) X(6, 64, 128, 1, 4, 32) X(7, 128, 128, 4, 8, 32) \
-                    X(8, 128, 64, 4, 8, 32) X(9, 128, 128, 4, 8, 16) X(10, 128, 64, 4, 8, 16)
+                    X(8, 128, 64, 4, 8, 32)
 
 template <int BM, int BN, int WAVES_M, int NWAVES, int BK, int AVEC, int BVEC>
 static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
@@ -39,8 +39,7 @@ static int launch_vec(int avec, int bvec, IgemmParams& p, unsigned grid, hipStre
 
 // LDS-DMA staged variants (igemm_glds.h): index, BM, BN, WAVES_M, NWAVES, index of the register-staged twin used
 // when an operand is not 16-byte vectorisable
-#define A3D_GLDS_CFGS(X) X(11, 128, 128, 4, 8, 7) X(12, 128, 64, 4, 8, 8) X(13, 128, 96, 4, 4, 1) X(14, 64, 64, 2, 4, 4) \
-                         X(15, 32, 128, 1, 4, 5) X(16, 64, 128, 1, 4, 6)
+#define A3D_GLDS_CFGS(X) X(9, 128, 128, 4, 8, 7) X(10, 128, 64, 4, 8, 8)
 
 template <int BM, int BN, int WAVES_M, int NWAVES>
 static int launch_glds(IgemmParams& p, unsigned grid, hipStream_t st) {

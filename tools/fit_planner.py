@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = {  # name: (bm, bn, eff)
     '128x128': (128, 128, 1.00), '128x96': (128, 96, 1.00), '128x64': (128, 64, 0.92), '128x32': (128, 32, 0.60),
     '64x64': (64, 64, 0.98), '32x128': (32, 128, 0.90), '64x128': (64, 128, 1.00), '128x128w8': (128, 128, 1.15),
-    '128x64w8': (128, 64, 1.05),
+    '128x64w8': (128, 64, 1.05), 'G128x128w8': (128, 128, 1.19), 'G128x64w8': (128, 64, 1.09),
 }
 SLOTS = 512
 
