@@ -129,14 +129,7 @@ class Session:
             rep.load_state_dict(torch.load(latest, map_location=rep.device))
         if self.world > 1:                                    # non-chief replicas take the chief's state
             import torch.distributed as dist
-            for g in rep.groups.values():
-                for buf in (g.var, g.m, g.v):
-                    dist.broadcast(buf, 0)
-            st = torch.tensor([rep.global_step] + [float(x) for g in rep.groups.values()
-                                                    for x in (g.beta1_power, g.beta2_power)],
-                              dtype=torch.float64, device=rep.device)
-            dist.broadcast(st, 0)
-            rep.global_step = int(st[0].item())
+            rep.broadcast_state(dist, 0)
         if self.dir:
             os.makedirs(self.dir, exist_ok=True)
             self.summaries = open(os.path.join(self.dir, 'summaries.jsonl'), 'a')
@@ -169,18 +162,15 @@ class Session:
         if self.sum_steps and step % self.sum_steps == 0:
             now = time.time()
             rate = (step - self.step_last_sum) / max(now - self.t_last_sum, 1e-9)
-            # tag names as the reference's summaries: name scopes 'loss' (src/models.py:288) and 'optimizers' (:347)
-            rec = {'global_step': step, 'loss/coarse_loss': float(out['coarse_loss']),
-                   'loss/fine_loss': float(out['fine_loss']), 'optimizers/Phase': out['phase'],
+            rec = {'global_step': step, **rep.summary_scalars(out),       # the reference's summary tags
                    'global_step/sec': rate, 'images/sec': rate * rep.B * self.world}
             self.log.info('global_step/sec: %.4g  %s', rate, json.dumps(rec))
             if self.summaries:
                 self.summaries.write(json.dumps(rec) + '\n')
                 self.summaries.flush()
                 self.events.add_scalars(step, {k: v for k, v in rec.items() if k != 'global_step'})
-                for tag, t in (('summaries/Input', rep.x), ('summaries/Coarse', rep.coarse),
-                               ('summaries/Fine', rep.fine), ('summaries/Target', rep.t)):   # src/models.py:292-296
-                    self.events.add_images(step, tag, t[:3].cpu().numpy())
+                for tag, t, max_outputs in rep.summary_images():
+                    self.events.add_images(step, tag, t[:max_outputs].cpu().numpy(), max_outputs)
                 self.events.flush()
             self.t_last_sum, self.step_last_sum = now, step
         if self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs:

@@ -70,7 +70,7 @@ class ParamGroup:
     so the optimizer is a single streaming kernel and the data-parallel all-reduce a single bucket."""
     ALIGN = 64   # elements; keeps every tensor 256-byte aligned for 16-byte vector loads
 
-    def __init__(self, name, lr, shapes, device, beta1=0.9, beta2=1.0, eps=1e-8):
+    def __init__(self, name, lr, shapes, device, beta1=0.9, beta2=1.0, eps=1e-8, slots=True):
         self.name, self.lr, self.beta1, self.beta2, self.eps = name, lr, beta1, beta2, eps
         self.offsets = collections.OrderedDict()
         off = 0
@@ -80,8 +80,8 @@ class ParamGroup:
         self.count = off
         self.var = torch.zeros(off, device=device)
         self.grad = torch.zeros(off, device=device)
-        self.m = torch.zeros(off, device=device)
-        self.v = torch.zeros(off, device=device)
+        self.m = torch.zeros(off, device=device) if slots else None      # slots=False: plain gradient descent
+        self.v = torch.zeros(off, device=device) if slots else None
         # beta powers are host scalars, updated after each apply like AdamOptimizer._finish
         self.beta1_power = np.float32(beta1)
         self.beta2_power = np.float32(beta2)
@@ -95,6 +95,10 @@ class ParamGroup:
                            float(self.beta1_power), float(self.beta2_power), grad_scale)
         self.beta1_power = self.beta1_power * np.float32(self.beta1)
         self.beta2_power = self.beta2_power * np.float32(self.beta2)
+
+    def apply_sgd(self, grad_scale=1.0):
+        """tf.train.GradientDescentOptimizer(lr): var -= lr * grad_scale * g."""
+        ops.sgd_apply(self.var, self.grad, self.lr * grad_scale)
 
 
 class MSDNReplica:
@@ -213,6 +217,31 @@ class MSDNReplica:
             g.beta1_power = np.float32(sd[gname + '/beta1_power'].item())
             g.beta2_power = np.float32(sd[gname + '/beta2_power'].item())
         self.global_step = int(sd['global_step'].item())
+
+    uses_dropout = True
+
+    def summary_scalars(self, out):
+        """Tags as the reference's name scopes 'loss' (src/models.py:288) and 'optimizers' (:347)."""
+        return {'loss/coarse_loss': float(out['coarse_loss']), 'loss/fine_loss': float(out['fine_loss']),
+                'optimizers/Phase': out['phase']}
+
+    def summary_images(self):
+        """src/models.py:292-296: (tag, batch, max_outputs)."""
+        return [('summaries/Input', self.x, 3), ('summaries/Coarse', self.coarse, 3), ('summaries/Fine', self.fine, 3),
+                ('summaries/Target', self.t, 3)]
+
+    def broadcast_state(self, dist, src=0):
+        """Non-chief replicas take the chief's variables, slots, beta powers and global_step."""
+        for g in self.groups.values():
+            for buf in (g.var, g.m, g.v):
+                dist.broadcast(buf, src)
+        st = torch.tensor([self.global_step] + [float(x) for g in self.groups.values()
+                                                for x in (g.beta1_power, g.beta2_power)],
+                          dtype=torch.float64, device=self.device)
+        dist.broadcast(st, src)
+        self.global_step = int(st[0].item())
+        for i, g in enumerate(self.groups.values()):
+            g.beta1_power, g.beta2_power = np.float32(st[1 + 2 * i].item()), np.float32(st[2 + 2 * i].item())
 
     def _kb(self, name):
         return self.var(name + '/kernel'), self.var(name + '/bias')
@@ -337,7 +366,7 @@ DCNF_DENSES = [('dense', 12544, 128, 'relu'), ('dense_1', 128, 16, 'sigmoid'), (
 class DCNFUnary:
     """The shared-weight unary conv stack over all patches of a batch at once (the reference maps it over the
     batch with tf.map_fn, src/models.py:89): images [B,H,W,3] -> z [B,48,1].  backward() takes a synthetic
-    upstream gradient dz (the CRF loss that would produce it is outside the north-star path)."""
+    upstream gradient dz (DCNFReplica feeds it the CRF loss gradient)."""
 
     def __init__(self, batchsize, device='cuda', params=None, seed=3000, precision='fp32'):
         self.B = batchsize
@@ -353,7 +382,7 @@ class DCNFUnary:
             shapes[DCNF_PREFIX + n + '/kernel'] = (i, o)
             shapes[DCNF_PREFIX + n + '/bias'] = (o,)
         self.shapes = shapes
-        self.group = ParamGroup('unary', 0.1, shapes, dev)      # GradientDescentOptimizer(0.1), src/models.py:198
+        self.group = ParamGroup('unary', 0.1, shapes, dev, slots=False)    # GradientDescentOptimizer(0.1), src/models.py:198
         if params is None:
             rng = np.random.default_rng(seed)
             params = {n: (glorot_uniform(rng, s) if n.endswith('/kernel') else np.zeros(s, np.float32))
@@ -442,6 +471,122 @@ class DCNFUnary:
                 d = dx
 
 
+DCNF_GAMMA, DCNF_EPSILON = 1.0, 1e-7    # src/models.py:17-18
+DCNF_PAIR_PREFIX = 'pairwise/pairwise_layers/dense/'
+
+
+def dcnf_pair_indices(rows, cols):
+    """src/models.py:20-30: every interior superpixel on one colour of the checkerboard, paired with its four
+    neighbours (up, down, left, right): two int lists (left, right)."""
+    left, right = [], []
+    for row in range(1, rows - 1):
+        for col in range(2 - (row & 1), cols - 1, 2):
+            pixel = row * cols + col
+            for addend in (-cols, cols, -1, 1):
+                left.append(pixel)
+                right.append(pixel + addend)
+    return left, right
+
+
+class DCNFReplica:
+    """The whole DCNF train step (src/models.py:179-200): resize to 240x320, unary z over 48 patches, pairwise r over 48
+    superpixel pairs, CRF negative log-likelihood, gradient descent (0.1) on what receives a gradient.
+
+    TF-1.3 semantics assumed (the oracle states the same, oracle/dcnf.py): scatter_nd_update has no gradient, so the CRF
+    matrix A is a constant for the optimizer — the pairwise dense layer never moves and only the unary stack trains."""
+    uses_dropout = False
+
+    def __init__(self, batchsize, device='cuda', params=None, seed=3000, global_step=0, reducer=None,
+                 precision='fp32'):
+        self.B = batchsize
+        self.device = dev = torch.device(device)
+        self.reducer = reducer
+        self.global_step = global_step
+        self.unary = DCNFUnary(batchsize, dev, params=params, seed=seed, precision=precision)
+        self.rows, self.cols = DCNF_IMG_H // DCNF_SP, DCNF_IMG_W // DCNF_SP
+        assert (self.rows, self.cols) == (self.unary.rows, self.unary.cols)
+        self.nsp = self.rows * self.cols
+        left, right = dcnf_pair_indices(self.rows, self.cols)
+        self.left = torch.tensor(left, dtype=torch.int32, device=dev)
+        self.right = torch.tensor(right, dtype=torch.int32, device=dev)
+        pshapes = collections.OrderedDict([(DCNF_PAIR_PREFIX + 'kernel', (2, 1)), (DCNF_PAIR_PREFIX + 'bias', (1,))])
+        self.pair_group = ParamGroup('pairwise', 0.1, pshapes, dev, slots=False)
+        if params is None or DCNF_PAIR_PREFIX + 'kernel' not in params:
+            rng = np.random.default_rng(seed + 1)
+            pw = {DCNF_PAIR_PREFIX + 'kernel': glorot_uniform(rng, (2, 1)),
+                  DCNF_PAIR_PREFIX + 'bias': np.zeros((1,), np.float32)}
+        else:
+            pw = params
+        for n in pshapes:
+            self.pair_group.view(self.pair_group.var, n).copy_(
+                torch.from_numpy(np.ascontiguousarray(pw[n], np.float32)))
+        self.groups = collections.OrderedDict([('unary', self.unary.group), ('pairwise', self.pair_group)])
+        self.depths240 = torch.empty((batchsize, DCNF_IMG_H, DCNF_IMG_W, 1), device=dev)
+        self.hist = torch.empty((batchsize, self.nsp, 256), device=dev)
+        self.y = torch.empty((batchsize, self.nsp, 1), device=dev)
+        self.output = torch.empty((batchsize, DCNF_IMG_H, DCNF_IMG_W, 1), device=dev)
+        self.sims = self.r = self.loss = self.loss_per_image = self.dz = None
+
+    def pair_var(self, name):
+        return self.pair_group.view(self.pair_group.var, DCNF_PAIR_PREFIX + name)
+
+    def forward(self, images, depths):
+        """z, r and the loss; leaves d loss / d z in self.dz."""
+        u = self.unary
+        ops.resize_bilinear_tf1(depths, self.depths240)                                   # src/models.py:181
+        z = u.forward(images)                                                             # :180,183
+        ops.superpixel_hist(u.resized, DCNF_SP, self.hist)                                # :112-113
+        self.sims, self.r = ops.pair_similarity(u.resized, DCNF_SP, self.hist, self.left, self.right,
+                                                self.pair_var('kernel'), self.pair_var('bias'), DCNF_GAMMA)  # :115-127
+        ops.superpixel_mean(self.depths240, DCNF_SP, self.y)                              # :131-132
+        self.loss, self.loss_per_image, self.dz = ops.crf_loss(z.view(self.B, self.nsp), self.y.view(self.B, self.nsp),
+                                                               self.r, self.left, self.right, DCNF_EPSILON)  # :129-177
+        return self.loss
+
+    def step(self, images, depths, keep_mask=None):
+        self.forward(images, depths)
+        self.unary.backward(self.dz)
+        red = self.reducer
+        scale = 1.0
+        if red is not None:
+            red.start(self.unary.group.grad)
+            red.finish()
+            scale = 1.0 / red.world_size
+        self.unary.group.apply_sgd(scale)                                                 # :198-200
+        self.global_step += 1
+        return {'mean_loss': self.loss}
+
+    def summary_scalars(self, out):
+        return {'loss/mean_loss': float(out['mean_loss'])}                                # src/models.py:174
+
+    def summary_images(self):
+        """src/models.py:187-196; max_outputs=1."""
+        ops.resize_bilinear_tf1(self.unary.z.view(self.B, self.rows, self.cols, 1), self.output)
+        return [('summaries/Output', self.output, 1), ('summaries/Input', self.unary.resized, 1),
+                ('summaries/Target', self.depths240, 1)]
+
+    def broadcast_state(self, dist, src=0):
+        for g in self.groups.values():
+            dist.broadcast(g.var, src)
+        st = torch.tensor([self.global_step], dtype=torch.float64, device=self.device)
+        dist.broadcast(st, src)
+        self.global_step = int(st[0].item())
+
+    def state_dict(self):
+        sd = collections.OrderedDict()
+        for g in self.groups.values():
+            for n in g.offsets:
+                sd[n] = g.view(g.var, n)
+        sd['global_step'] = torch.tensor(self.global_step, dtype=torch.int64)
+        return sd
+
+    def load_state_dict(self, sd):
+        for g in self.groups.values():
+            for n in g.offsets:
+                g.view(g.var, n).copy_(sd[n])
+        self.global_step = int(sd['global_step'].item())
+
+
 # =====================================================================================================
 # plugin surface: models.msdn / models.dcnf  (src/models.py:370-371)
 # =====================================================================================================
@@ -455,7 +600,7 @@ class TrainOp:
     def __init__(self, replica, pipeline, seed=0):
         self.replica, self.pipeline, self.seed = replica, pipeline, seed
         dev = replica.device
-        self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=dev)
+        self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=dev) if replica.uses_dropout else None
         pipeline.allocate(lambda shape: torch.empty(shape, dtype=torch.float32).pin_memory().numpy())
         self.pool = (torch.from_numpy(pipeline.images), torch.from_numpy(pipeline.depths))      # pinned views
         self.dev = [tuple(torch.empty((replica.B,) + tuple(p.shape[1:]), device=dev) for p in self.pool)
@@ -498,7 +643,8 @@ class TrainOp:
             raise self.end[1]
         cur = torch.cuda.current_stream()
         cur.wait_event(self.copied[i])
-        ops.dropout_keep_mask(self.keep, self.seed, r.global_step)
+        if self.keep is not None:
+            ops.dropout_keep_mask(self.keep, self.seed, r.global_step)
         self.last = r.step(self.dev[i][0], self.dev[i][1], self.keep)
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -534,14 +680,23 @@ class _MultiScaleDeepNetwork:
 
 
 class _DistributedConvolutionalNeuralFields:
-    """Liu et al. (2015).  Only the unary conv stack (src/models.py:50-89) is on this build's path; the pairwise
-    part and the CRF negative log-likelihood (src/models.py:91-177) are not implemented, so the plugin cannot be
-    trained with `make train` yet (the reference's own version cannot either: it pins layers to
-    /job:worker/task:{1,2,3}, src/models.py:63-79)."""
+    """Liu et al. (2015) — plugin wrapper around DCNFReplica (src/models.py:13-200).  The reference pins its layers
+    to /job:worker/task:{1,2,3} (src/models.py:63-79); here every replica holds the whole model and replicas are
+    data-parallel, like msdn."""
+    reducer = None
+    seed = 3000
+    precision = 'fp32'
+    beta2 = None         # accepted for symmetry with msdn; gradient descent has no beta
 
     def __call__(self, images, depths, train=True):
-        raise NotImplementedError('dcnf: only the unary stack (models.DCNFUnary) is implemented; the CRF loss of '
-                                  'src/models.py:129-177 is outside this build\'s hot path')
+        assert images.pipeline is depths.pipeline, 'inputs and targets must come from the same data.inputs() call'
+        self.train = train
+        replica = DCNFReplica(images.pipeline.B, device=torch.device('cuda', torch.cuda.current_device()),
+                              seed=self.seed, reducer=self.reducer, precision=self.precision)
+        if self.reducer is not None:
+            for g in replica.groups.values():
+                self.reducer.broadcast(g.var)
+        return TrainOp(replica, images.pipeline, seed=self.seed)
 
 
 dcnf = _DistributedConvolutionalNeuralFields()

@@ -173,6 +173,50 @@ def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power
                                          beta1_power, beta2_power, grad_scale, _stream()), 'a3d_adam_apply_tf1')
 
 
+def sgd_apply(var, g, lr):
+    """tf.train.GradientDescentOptimizer (src/models.py:198)."""
+    check(_lib.load().a3d_sgd_apply(var.numel(), _ptr(var), _ptr(g), lr, _stream()), 'a3d_sgd_apply')
+
+
+def superpixel_mean(x, sp, out=None):
+    """[n,h,w,c] -> [n,(h/sp)*(w/sp),c] block means (src/models.py:110,132)."""
+    n, h, w, c = x.shape
+    out = out if out is not None else torch.empty((n, (h // sp) * (w // sp), c), dtype=torch.float32, device=x.device)
+    check(_lib.load().a3d_superpixel_mean(n, h, w, c, _ptr(x), sp, _ptr(out), _stream()), 'a3d_superpixel_mean')
+    return out
+
+
+def superpixel_hist(x, sp, out=None):
+    """color_histogram of every superpixel (src/models.py:95-100): [n,h,w,3] -> [n,P,256]."""
+    n, h, w, c = x.shape
+    assert c == 3
+    out = out if out is not None else torch.empty((n, (h // sp) * (w // sp), 256), dtype=torch.float32, device=x.device)
+    check(_lib.load().a3d_superpixel_hist(n, h, w, _ptr(x), sp, _ptr(out), _stream()), 'a3d_superpixel_hist')
+    return out
+
+
+def pair_similarity(x, sp, hist, left, right, dense_w, dense_b, gamma=1.0):
+    """pairwise_part (src/models.py:108-127): returns (sims [n,Q,2], r [n,Q])."""
+    n, h, w, _ = x.shape
+    q = left.numel()
+    sims = torch.empty((n, q, 2), dtype=torch.float32, device=x.device)
+    r = torch.empty((n, q), dtype=torch.float32, device=x.device)
+    check(_lib.load().a3d_pair_similarity(n, h, w, _ptr(x), sp, _ptr(hist), _ptr(left), _ptr(right), q, _ptr(dense_w),
+                                          _ptr(dense_b), gamma, _ptr(sims), _ptr(r), _stream()), 'a3d_pair_similarity')
+    return sims, r
+
+
+def crf_loss(z, y, r, left, right, eps=1e-7):
+    """loss_part (src/models.py:129-177): returns (mean loss [1], per-image loss [n], d mean / d z [n,P])."""
+    n, nsp = z.shape[0], z.shape[1]
+    per = torch.empty((n,), dtype=torch.float32, device=z.device)
+    mean = torch.empty((1,), dtype=torch.float32, device=z.device)
+    dz = torch.empty((n, nsp), dtype=torch.float32, device=z.device)
+    check(_lib.load().a3d_crf_loss(n, nsp, _ptr(z), _ptr(y), _ptr(r), _ptr(left), _ptr(right), left.numel(), eps,
+                                   _ptr(per), _ptr(mean), _ptr(dz), _stream()), 'a3d_crf_loss')
+    return mean, per, dz
+
+
 def dropout_keep_mask(keep, seed, step, rate=0.5):
     """Fill the uint8 tensor `keep` with the Bernoulli(1-rate) keep mask of training step `step`."""
     check(_lib.load().a3d_dropout_keep_mask(keep.numel(), seed, step, rate, _ptr(keep), _stream()),

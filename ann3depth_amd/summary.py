@@ -88,13 +88,15 @@ class EventFileWriter:
         self._event(step, _ld(5, values))
 
     def add_images(self, step, tag, batch, max_outputs=3):
-        """batch [N,H,W,C] float (C = 1 or 3): tags `<tag>/image/<i>` like tf.summary.image."""
+        """batch [N,H,W,C] float (C = 1 or 3): tags `<tag>/image/<i>` (`<tag>/image` when max_outputs == 1) like
+        tf.summary.image."""
         values = b''
         for i in range(min(max_outputs, len(batch))):
             u8 = to_uint8(batch[i])
             h, w, c = u8.shape
             image = (b'\x08' + _varint(h) + b'\x10' + _varint(w) + b'\x18' + _varint(c) + _ld(4, encode_png(u8)))
-            values += _ld(1, _ld(1, f'{tag}/image/{i}'.encode()) + _ld(4, image))
+            name = f'{tag}/image' if max_outputs == 1 else f'{tag}/image/{i}'
+            values += _ld(1, _ld(1, name.encode()) + _ld(4, image))
         self._event(step, _ld(5, values))
 
     def flush(self):

@@ -123,6 +123,34 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
                        float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
                        void* stream);
 
+/* ---- DCNF pairwise part + CRF negative log-likelihood (src/models.py:20-48,91-177,185-200) ----
+ * Superpixels are the sp x sp (40 x 40) non-overlapping blocks of the 240x320 image, row-major (src/models.py:37-48). */
+
+/* tf.reduce_mean(superpixels, axis=2) (src/models.py:110,132): x [n,h,w,c] -> out [n,(h/sp)*(w/sp),c]. */
+int a3d_superpixel_mean(int n, int h, int w, int c, const float* x, int sp, float* out, void* stream);
+
+/* color_histogram (src/models.py:95-100): 256-bin tf.histogram_fixed_width of r*2^24+g*2^16+b*2^8 over [0,2^24) per
+ * superpixel: x [n,h,w,3] -> hist [n,(h/sp)*(w/sp),256] (float counts). */
+int a3d_superpixel_hist(int n, int h, int w, const float* x, int sp, float* hist, void* stream);
+
+/* similarity() of the grayscale superpixels and of the histograms for every (left,right) pair (src/models.py:102-119)
+ * and the pairwise dense layer 2->1 (src/models.py:121-127): sims [n,npairs,2], r [n,npairs].
+ * left/right: device int32 superpixel indices (src/models.py:20-30). */
+int a3d_pair_similarity(int n, int h, int w, const float* x, int sp, const float* hist, const int32_t* left,
+                        const int32_t* right, int npairs, const float* dense_w, const float* dense_b, float gamma,
+                        float* sims, float* r, void* stream);
+
+/* loss_part (src/models.py:129-177): per image A = I + D - R (get_A, :136-143), energy, partition function
+ * (matrix_determinant + matrix_inverse, here one LU with partial pivoting), loss_b = -log(exp(-E)/Z + eps);
+ * loss_mean = mean_b; dz = d loss_mean / d z with A held constant (TF 1.3 has no gradient for scatter_nd_update).
+ * z, y, dz: [n,nsp]; r: [n,npairs]; nsp <= 64. */
+int a3d_crf_loss(int n, int nsp, const float* z, const float* y, const float* r, const int32_t* left,
+                 const int32_t* right, int npairs, float eps, float* loss_per_image, float* loss_mean, float* dz,
+                 void* stream);
+
+/* tf.train.GradientDescentOptimizer (src/models.py:198): var -= lr * g. */
+int a3d_sgd_apply(size_t count, float* var, const float* g, float lr, void* stream);
+
 /* ---- opt-in kernel timing for bench.py's roofline line (the only process-global state in the library) ----
  * While enabled, every implicit-GEMM launch (conv / dense, any direction) is bracketed by a hipEvent pair recorded
  * on the launch stream.  a3d_timing_collect() synchronises those events, returns up to `cap` records (oldest first),

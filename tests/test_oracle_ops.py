@@ -223,3 +223,47 @@ def test_glorot_limits():
     w = T.glorot_uniform(np.random.default_rng(0), (12288, 4096))
     lim = np.sqrt(6 / (12288 + 4096))
     assert abs(w).max() <= lim * (1 + 1e-6) and abs(w).max() > 0.999 * lim
+
+
+def test_dcnf_crf_oracle_against_autograd():
+    """oracle.dcnf pairwise + CRF loss: structure checks and d loss / d z against torch float64 autograd of the same
+    expression with A detached (the assumed TF-1.3 behaviour, see oracle/dcnf.py)."""
+    from oracle import dcnf as D
+    left, right = D.pair_indices()
+    assert len(left) == 48 and D.N_SP == 48
+    assert set(left) == {9, 11, 13, 18, 20, 22, 25, 27, 29, 34, 36, 38}          # interior checkerboard
+    assert len({tuple(sorted(e)) for e in zip(left, right)}) == 48                # no duplicated edge
+    rng = np.random.default_rng(1)
+    B = 2
+    img = (rng.integers(0, 256, (B, 240, 320, 3)) / 255)
+    dep = (rng.integers(0, 256, (B, 240, 320, 1)) / 255)
+    sp = D.superpixels(img)
+    np.testing.assert_array_equal(sp[1, 9, 41, :], img[1, 40 + 1, 40 + 1, :])      # superpixel 9 = (row 1, col 1)
+    hist = D.color_histogram(sp)
+    assert hist.shape == (B, 48, 256) and (hist.sum(-1) == 1600).all()
+    p = D.pairwise_init()
+    p = {k: v.astype(np.float64) for k, v in p.items()}
+    r, sims = D.pairwise_forward(p, img)
+    assert r.shape == (B, 48, 1) and (sims > 0).all() and (sims <= 1).all()
+    A = D.crf_matrix(r[0, :, 0])
+    np.testing.assert_allclose(A, A.T)
+    np.testing.assert_allclose(A.sum(axis=1), 1.0, atol=1e-12)                     # I + D - R: rows sum to 1
+    z = rng.random((B, 48, 1)) * 0.2
+    # keep the energies small so that the gradient is not lost in the + 1e-7 of the reference's log
+    y = D.superpixels(dep).mean(axis=2)
+    z = y + 0.05 * rng.standard_normal(y.shape)
+    loss, losses, dz = D.crf_loss(dep, z, r)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    tot = 0
+    for b in range(B):
+        At = torch.from_numpy(D.crf_matrix(r[b, :, 0]))
+        zb, yb = zt[b, :, 0], torch.from_numpy(y[b, :, 0])
+        E = yb @ At @ yb - 2 * zb @ yb + zb @ zb
+        fac = np.pi ** 24 / (torch.sqrt(torch.det(At)) + 1e-7)
+        g = zb @ (torch.inverse(At) + 1e-7) @ zb - zb @ zb
+        Z = fac * torch.exp(g) + 1e-7
+        tot = tot + -torch.log(torch.exp(-E) / Z + 1e-7)
+    (tot / B).backward()
+    assert abs(loss - (tot / B).item()) < 1e-9
+    np.testing.assert_allclose(dz, zt.grad.numpy(), rtol=1e-6, atol=1e-18)
+    assert abs(loss - 16.118) < 0.01         # exp(-E)/Z ~ 1e-13 drowns in the + epsilon: loss ~ -log(1e-7)
