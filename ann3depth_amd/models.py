@@ -532,14 +532,18 @@ class DCNFReplica:
 
     def forward(self, images, depths):
         """z, r and the loss; leaves d loss / d z in self.dz."""
+        self.unary.forward(images)                                                        # src/models.py:180,183
+        return self.forward_crf(depths)
+
+    def forward_crf(self, depths):
+        """Everything after the unary stack: target superpixels, pairwise r, CRF loss and d loss / d z."""
         u = self.unary
         ops.resize_bilinear_tf1(depths, self.depths240)                                   # src/models.py:181
-        z = u.forward(images)                                                             # :180,183
         ops.superpixel_hist(u.resized, DCNF_SP, self.hist)                                # :112-113
         self.sims, self.r = ops.pair_similarity(u.resized, DCNF_SP, self.hist, self.left, self.right,
                                                 self.pair_var('kernel'), self.pair_var('bias'), DCNF_GAMMA)  # :115-127
         ops.superpixel_mean(self.depths240, DCNF_SP, self.y)                              # :131-132
-        self.loss, self.loss_per_image, self.dz = ops.crf_loss(z.view(self.B, self.nsp), self.y.view(self.B, self.nsp),
+        self.loss, self.loss_per_image, self.dz = ops.crf_loss(u.z.view(self.B, self.nsp), self.y.view(self.B, self.nsp),
                                                                self.r, self.left, self.right, DCNF_EPSILON)  # :129-177
         return self.loss
 

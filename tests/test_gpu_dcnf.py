@@ -31,11 +31,17 @@ def test_pair_indices_match_oracle():
 def test_superpixel_statistics_and_pairwise_match_oracle():
     from ann3depth_amd import ops
     rng = np.random.default_rng(11)
-    # smooth + noisy image so that neighbouring superpixels are similar enough for exp(-||.||) not to underflow
-    base = rng.random((3, 6, 8, 3)).astype(np.float32)
-    img = np.kron(base, np.ones((1, 40, 40, 1), np.float32)) * np.float32(0.02) + np.float32(0.4)
-    img += (rng.random(img.shape).astype(np.float32) - np.float32(0.5)) * np.float32(0.004)
-    img[2] = rng.random((240, 320, 3)).astype(np.float32)                     # and one fully random image
+    # image 0: every superpixel is the same random tile except for a few dozen changed pixels, so both similarities
+    # are well inside (0, 1); image 1: smooth (colour similarity in range, histogram similarity underflows to 0, as
+    # on real photographs); image 2: white noise
+    img = np.empty((3, 240, 320, 3), np.float32)
+    img[0] = np.tile(rng.random((40, 40, 3)).astype(np.float32), (6, 8, 1))
+    for _ in range(60):
+        img[0, rng.integers(240), rng.integers(320)] = rng.random(3).astype(np.float32)
+    base = rng.random((6, 8, 3)).astype(np.float32)
+    img[1] = np.kron(base, np.ones((40, 40, 1), np.float32)) * np.float32(0.02) + np.float32(0.4)
+    img[1] += (rng.random(img[1].shape).astype(np.float32) - np.float32(0.5)) * np.float32(0.004)
+    img[2] = rng.random((240, 320, 3)).astype(np.float32)
     x = torch.from_numpy(img).cuda()
     hist = ops.superpixel_hist(x, 40)
     sp = OD.superpixels(img)
@@ -48,7 +54,7 @@ def test_superpixel_statistics_and_pairwise_match_oracle():
     sims, r = ops.pair_similarity(x, 40, hist, left, right, torch.from_numpy(p[OD.PAIR_PREFIX + 'kernel']).cuda(),
                                   torch.from_numpy(p[OD.PAIR_PREFIX + 'bias']).cuda(), 1.0)
     r_ref, sims_ref = OD.pairwise_forward(p, img.astype(np.float64))
-    assert sims_ref[:2].min() > 1e-3                                              # the smooth images exercise exp()
+    assert sims_ref[0].min() > 1e-3 and sims_ref[0].max() < 1 and sims_ref[1, :, 0].min() > 1e-3
     np.testing.assert_allclose(sims.cpu().numpy(), sims_ref, rtol=2e-4, atol=1e-30)
     np.testing.assert_allclose(r.cpu().numpy(), r_ref[..., 0], rtol=2e-4, atol=1e-7)
 
@@ -75,9 +81,9 @@ def test_crf_loss_and_gradient_match_oracle(regime):
     np.testing.assert_allclose(per.cpu().numpy(), per_ref, rtol=2e-5)
     np.testing.assert_allclose(float(mean), m_ref, rtol=2e-5)
     if regime == 'unsaturated':
-        assert np.all(per_ref < 15.0)                       # really away from -log(eps)
+        assert np.all(per_ref < 15.5) and per_ref.min() < 12.0      # really away from -log(eps) = 16.118
     else:
-        assert np.allclose(per_ref, -np.log(OD.EPSILON), atol=1e-3)
+        assert np.allclose(per_ref, -np.log(OD.EPSILON), atol=0.05)
     assert rel(dz.cpu().numpy(), dz_ref[..., 0]) < 2e-3
     # the 32-bit oracle (what TF would run) agrees too
     m32, per32, dz32 = OD.crf_loss(depths.astype(np.float32), z[..., None], r[..., None])
