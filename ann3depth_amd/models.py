@@ -8,7 +8,9 @@ optimizer group, activations) and ``step()`` enqueues the fixed sequence of HIP 
 optimizer on the current stream.  Variable names are the reference's TF variable names.
 """
 import collections
+import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -115,6 +117,12 @@ class MSDNReplica:
         self.global_step = global_step
         self.reducer = reducer
         dev = self.device
+        # Opt-in (A3D_OVERLAP=1) second HIP stream: the fine network's forward (needed only for its loss in the coarse
+        # phase) and every backward-filter GEMM (off the dz chain) run beside the main chain, filling the tails of its
+        # launches.  Measured on one MI355X at B = 32: coarse phase +3 % (8.13 k -> 8.39 k images/s), fine phase -6.5 %,
+        # and every co-running GEMM stretches by 1.3-2x, so it is off by default and never on in bench.py's line.
+        self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
+        self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
         shapes = collections.OrderedDict()
         for c in MSDN_CONVS:
             shapes[c.name + '/kernel'] = (c.k, c.k, c.cin, c.cout)
@@ -250,11 +258,28 @@ class MSDNReplica:
         w, b = self._kb(name)
         ops.conv2d_fwd(self.d[name], x, w, b, y, 'relu' if self.conv[name].relu else None)
 
+    @contextlib.contextmanager
+    def _beside(self):
+        """Enqueue the body on the side stream, ordered after everything enqueued on the current stream so far."""
+        if self.side is None:
+            yield
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            yield
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
     # ---- forward: src/models.py:277-290 ----
-    def forward(self, images, depths, keep_mask):
+    def forward(self, images, depths, keep_mask, join=True):
+        """join=False leaves the fine network's forward in flight on the side stream (step() joins later)."""
         ops.resize_bilinear_tf1(images, self.x)
         ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
+        with self._beside():
+            self._conv('fine/first/conv2d', self.x, self.f1)
         self._conv('coarse/conv/conv2d_0', self.x, self.c0)
         ops.maxpool2x2_fwd(self.c0, self.p0)
         self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
@@ -266,58 +291,69 @@ class MSDNReplica:
         ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
         ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
-        self._conv('fine/first/conv2d', self.x, self.f1)
-        ops.maxpool2x2_fwd(self.f1, self.cat, extra=self.coarse)                              # pool + concat fused
-        self._conv('fine/second/conv2d', self.cat, self.f2)
-        self._conv('fine/third', self.f2, self.fine)
+        with self._beside():
+            ops.maxpool2x2_fwd(self.f1, self.cat, extra=self.coarse)                          # pool + concat fused
+            self._conv('fine/second/conv2d', self.cat, self.f2)
+            self._conv('fine/third', self.f2, self.fine)
+            ops.silog_loss_fwd(self.fine, self.t, self.loss_fine, self.ws_f)
         ops.silog_loss_fwd(self.coarse, self.t, self.loss_coarse, self.ws_c)
-        ops.silog_loss_fwd(self.fine, self.t, self.loss_fine, self.ws_f)
+        if join:
+            self._join()
+
+    def _bwd_filter(self, name, x, dz):
+        with self._beside():
+            if name in self.d:
+                ops.conv2d_bwd_filter(self.d[name], x, dz, self.grad(name + '/kernel'), self.grad(name + '/bias'))
+            else:
+                ops.dense_bwd_filter(x, dz, self.grad(name + '/kernel'), self.grad(name + '/bias'))
 
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
     def backward_coarse(self, after_dense=None):
         B = self.B
-        G = self.grad
         ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1))
         n = 'coarse/dense/dense_1'
-        ops.dense_bwd_filter(self.drop, self.dz1, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.drop, self.dz1)
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
         ops.dense_bwd_data(self.dz1, self.var(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
         n = 'coarse/dense/dense_0'
         flat = self.c4.view(B, -1)
-        ops.dense_bwd_filter(flat, self.dz0, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, flat, self.dz0)
         ops.dense_bwd_data(self.dz0, self.var(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:
+            self._join()
             after_dense()          # dense gradients are complete: their all-reduce can overlap the conv backward
         n = 'coarse/conv/conv2d_4'
-        ops.conv2d_bwd_filter(self.d[n], self.c3, self.dc4, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.c3, self.dc4)
         ops.conv2d_bwd_data(self.d[n], self.dc4, self.var(n + '/kernel'), self.dc3, relu_mask=self.c3)
         n = 'coarse/conv/conv2d_3'
-        ops.conv2d_bwd_filter(self.d[n], self.c2, self.dc3, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.c2, self.dc3)
         ops.conv2d_bwd_data(self.d[n], self.dc3, self.var(n + '/kernel'), self.dc2, relu_mask=self.c2)
         n = 'coarse/conv/conv2d_2'
-        ops.conv2d_bwd_filter(self.d[n], self.p1, self.dc2, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.p1, self.dc2)
         ops.conv2d_bwd_data(self.d[n], self.dc2, self.var(n + '/kernel'), self.dp1)
         ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
         n = 'coarse/conv/conv2d_1'
-        ops.conv2d_bwd_filter(self.d[n], self.p0, self.dc1, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.p0, self.dc1)
         ops.conv2d_bwd_data(self.d[n], self.dc1, self.var(n + '/kernel'), self.dp0)
         ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
         n = 'coarse/conv/conv2d_0'
-        ops.conv2d_bwd_filter(self.d[n], self.x, self.dc0, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.x, self.dc0)
+        self._join()
 
     # ---- backward of loss_fine wrt fine/* : src/models.py:333-338 ----
     def backward_fine(self):
-        G = self.grad
+        self._join()                                                          # the fine forward ran on the side stream
         ops.silog_loss_bwd(self.fine, self.t, self.ws_f, self.dfine)
         n = 'fine/third'
-        ops.conv2d_bwd_filter(self.d[n], self.f2, self.dfine, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.f2, self.dfine)
         ops.conv2d_bwd_data(self.d[n], self.dfine, self.var(n + '/kernel'), self.df2, relu_mask=self.f2)
         n = 'fine/second/conv2d'
-        ops.conv2d_bwd_filter(self.d[n], self.cat, self.df2, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.cat, self.df2)
         ops.conv2d_bwd_data(self.d[n], self.df2, self.var(n + '/kernel'), self.dcat)
         ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)      # reads channels 0..62 of dcat
         n = 'fine/first/conv2d'
-        ops.conv2d_bwd_filter(self.d[n], self.x, self.df1, G(n + '/kernel'), G(n + '/bias'))
+        self._bwd_filter(n, self.x, self.df1)
+        self._join()
 
     # ---- one session.run(train_op) ----
     def step(self, images, depths, keep_mask):
@@ -326,7 +362,7 @@ class MSDNReplica:
         global_step += 1 always (src/models.py:329,343,356)."""
         if keep_mask.dtype != torch.uint8:
             keep_mask = keep_mask.to(torch.uint8)
-        self.forward(images, depths, keep_mask)
+        self.forward(images, depths, keep_mask, join=False)
         phase = phase_of(self.global_step, self.B)
         red = self.reducer
         scale = 1.0 / red.world_size if red is not None else 1.0
@@ -347,6 +383,7 @@ class MSDNReplica:
                 red.finish()
             ga.apply(scale)
             gb.apply(scale)
+        self._join()
         self.global_step += 1
         return {'coarse_loss': self.loss_coarse, 'fine_loss': self.loss_fine, 'phase': phase}
 

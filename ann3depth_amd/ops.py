@@ -23,7 +23,7 @@ def _stream():
 
 
 class Workspace:
-    """Scratch for split-K slabs and partial reductions.  One per device; grows on demand (never inside a graph
+    """Scratch for split-K slabs and partial reductions.  One per stream; grows on demand (never inside a graph
     capture: call reserve() with the largest need first)."""
 
     def __init__(self):
@@ -41,7 +41,16 @@ class Workspace:
         return ctypes.c_void_p(buf.data_ptr()), buf.numel()
 
 
-_WS = Workspace()
+_WS = {}
+
+
+def _ws():
+    """The workspace of the current stream (kernels of different streams may run concurrently)."""
+    key = torch.cuda.current_stream().cuda_stream
+    w = _WS.get(key)
+    if w is None:
+        w = _WS[key] = Workspace()
+    return w
 
 
 def same_pad(in_size, k, stride):
@@ -68,7 +77,7 @@ def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precisio
 
 def conv2d_fwd(d, x, w, bias, y, act=None):
     lib = _lib.load()
-    ws, n = _WS.get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
+    ws, n = _ws().get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
     check(lib.a3d_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], ws, n, _stream()),
           'a3d_conv2d_fwd')
     return y
@@ -76,7 +85,7 @@ def conv2d_fwd(d, x, w, bias, y, act=None):
 
 def conv2d_bwd_data(d, dz, w, dx, relu_mask=None):
     lib = _lib.load()
-    ws, n = _WS.get(lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)), dz.device)
+    ws, n = _ws().get(lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)), dz.device)
     check(lib.a3d_conv2d_bwd_data(ctypes.byref(d), _ptr(dz), _ptr(w), _ptr(dx), _ptr(relu_mask), ws, n, _stream()),
           'a3d_conv2d_bwd_data')
     return dx
@@ -84,7 +93,7 @@ def conv2d_bwd_data(d, dz, w, dx, relu_mask=None):
 
 def conv2d_bwd_filter(d, x, dz, dw, db=None):
     lib = _lib.load()
-    ws, n = _WS.get(lib.a3d_conv2d_bwd_filter_ws_bytes(ctypes.byref(d)), x.device)
+    ws, n = _ws().get(lib.a3d_conv2d_bwd_filter_ws_bytes(ctypes.byref(d)), x.device)
     check(lib.a3d_conv2d_bwd_filter(ctypes.byref(d), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), ws, n, _stream()),
           'a3d_conv2d_bwd_filter')
     return dw, db
@@ -94,7 +103,7 @@ def dense_fwd(x, w, bias, y, act=None, drop_keep=None):
     m, k = x.shape
     n = w.shape[1]
     lib = _lib.load()
-    ws, nb = _WS.get(lib.a3d_dense_fwd_ws_bytes(m, k, n), x.device)
+    ws, nb = _ws().get(lib.a3d_dense_fwd_ws_bytes(m, k, n), x.device)
     check(lib.a3d_dense_fwd(m, k, n, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], _ptr(drop_keep), ws, nb,
                             _stream()), 'a3d_dense_fwd')
     return y
@@ -105,7 +114,7 @@ def dense_bwd_data(dz, w, dx, mask=None, scale=1.0, mask_act='relu'):
     m, n = dz.shape
     k = w.shape[0]
     lib = _lib.load()
-    ws, nb = _WS.get(lib.a3d_dense_bwd_data_ws_bytes(m, k, n), dz.device)
+    ws, nb = _ws().get(lib.a3d_dense_bwd_data_ws_bytes(m, k, n), dz.device)
     check(lib.a3d_dense_bwd_data(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), ACT[mask_act], scale, ws, nb,
                                  _stream()),
           'a3d_dense_bwd_data')
@@ -116,7 +125,7 @@ def dense_bwd_filter(x, dz, dw, db=None):
     m, k = x.shape
     n = dz.shape[1]
     lib = _lib.load()
-    ws, nb = _WS.get(lib.a3d_dense_bwd_filter_ws_bytes(m, k, n), x.device)
+    ws, nb = _ws().get(lib.a3d_dense_bwd_filter_ws_bytes(m, k, n), x.device)
     check(lib.a3d_dense_bwd_filter(m, k, n, _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), ws, nb, _stream()),
           'a3d_dense_bwd_filter')
     return dw, db

@@ -169,3 +169,25 @@ def test_msdn_odd_batch_sizes(models, B):
     a_gpu['keep_mask'] = keep
     for n, gref in O.backward_coarse(params, a_gpu).items():
         assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
+
+
+@pytest.mark.parametrize('global_step', [0, 2000000 // 2])
+def test_two_stream_schedule_is_bit_identical(models, monkeypatch, global_step):
+    """A3D_OVERLAP=1 runs the fine forward and every backward-filter GEMM on a second stream: same kernels, same
+    operands, so every output, gradient and slot must equal the one-stream schedule bit for bit (3 steps, beta2 < 1 so
+    that the weights move and a race would propagate)."""
+    B = 2
+    params = O.init_params(3000)
+    state = []
+    for overlap in ('0', '1'):
+        monkeypatch.setenv('A3D_OVERLAP', overlap)
+        net = models.MSDNReplica(B, params=params, global_step=global_step, beta2=0.999)
+        assert (net.side is not None) == (overlap == '1')
+        for s in range(3):
+            img, dep, keep = synth(B, 1000 + s)
+            net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+        torch.cuda.synchronize()
+        state.append({k: v.clone() for k, v in net.state_dict().items()} | {'fine': net.fine.clone(),
+                                                                             'coarse': net.coarse.clone()})
+    for k in state[0]:
+        assert torch.equal(state[0][k], state[1][k]), k
