@@ -111,7 +111,7 @@ def test_msdn_learning_mode_multi_step(models):
 
 
 def test_msdn_full_batch_properties(models):
-    """B=32 (BASELINE config 2) is too slow for the oracle inside the GPU suite; check size-independent properties:
+    """B=32 (BASELINE config 2), size-independent properties:
     per-sample independence (sample i of the batch == the same sample run in a batch of 2) and determinism."""
     B = 32
     img, dep, keep = synth(B, 1234, 120, 160)
@@ -130,6 +130,33 @@ def test_msdn_full_batch_properties(models):
     torch.cuda.synchronize()
     assert rel(small.coarse.cpu().numpy(), coarse[5:7].cpu().numpy()) < 1e-5
     assert rel(small.fine.cpu().numpy(), fine[5:7].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('phase,global_step', [(1, 0), (2, 2000000 // 32)])
+def test_msdn_full_batch_matches_oracle(models, phase, global_step):
+    """BASELINE config 2 itself (B = 32, 640x480 stored): the tile configs, LDS-DMA kernels and split-K factors the
+    planner picks at this size against the oracle at the same size — depth maps within the north-star tolerance, and
+    the whole backward chain fed with the GPU's activations.  ~10 s of numpy on the GPU box's host cores."""
+    B = 32
+    img, dep, keep = synth(B, 4321)
+    params = O.init_params(3000)
+    net = models.MSDNReplica(B, params=params, global_step=global_step)
+    out = net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    torch.cuda.synchronize()
+    assert out['phase'] == phase
+    a = O.forward(params, img, dep, keep)
+    np.testing.assert_array_equal(net.x.cpu().numpy(), a['images'])
+    assert rel(net.coarse.cpu().numpy(), a['coarse']) < DEPTH_TOL
+    assert rel(net.fine.cpu().numpy(), a['fine']) < DEPTH_TOL
+    for name in ('c0', 'c1', 'c2', 'c3', 'c4', 'drop', 'f1', 'cat', 'f2'):
+        assert rel(getattr(net, name).cpu().numpy(), a[name]) < 1e-4, name
+    assert abs(out['coarse_loss'].item() - a['loss_coarse']) < LOSS_TOL * abs(a['loss_coarse'])
+    assert abs(out['fine_loss'].item() - a['loss_fine']) < LOSS_TOL * abs(a['loss_fine'])
+    a_gpu = gpu_activations(net)
+    a_gpu['keep_mask'] = keep
+    g_chain = (O.backward_coarse if phase == 1 else O.backward_fine)(params, a_gpu)
+    for n, gref in g_chain.items():
+        assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
 
 
 @pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 5e-2)])
