@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import _lib, data, dp, models, summary
+from . import _lib, data, dp, models, summary, tfckpt
 
 
 def main(argv=None):
@@ -69,7 +69,8 @@ def main(argv=None):
     logger.info('Starting session.')
     with Session(model_op, ckptdir if chief else None, last_step=args.steps, stop_at_signal=stop_at_signal,
                  save_checkpoint_secs=args.ckptfreq, save_summaries_steps=args.sumfreq,
-                 trace_every=args.trace_every, logger=logger, world=world) as session:
+                 trace_every=args.trace_every, logger=logger, world=world,
+                 tf_checkpoints=args.tf_checkpoints) as session:
         while not session.should_stop():
             session.run(model_op)
     logger.info('Session stopped.')
@@ -110,10 +111,11 @@ class Session:
     pipeline runs dry."""
 
     def __init__(self, train_op, checkpoint_dir, last_step, stop_at_signal, save_checkpoint_secs, save_summaries_steps,
-                 trace_every, logger, world=1):
+                 trace_every, logger, world=1, tf_checkpoints=False):
         self.op, self.dir, self.last_step, self.sig = train_op, checkpoint_dir, last_step, stop_at_signal
         self.ckpt_secs, self.sum_steps, self.trace_every = save_checkpoint_secs, save_summaries_steps, trace_every
         self.log, self.world = logger, world
+        self.tf_checkpoints = tf_checkpoints
         self.stop = False
         self.trace_next = True               # TraceHook: the first step after every (re)start is traced
         self.t_last_ckpt = time.time()
@@ -126,7 +128,10 @@ class Session:
         latest = latest_checkpoint(self.dir) if self.dir else None
         if latest:
             self.log.info(f'Restoring {latest}')
-            rep.load_state_dict(torch.load(latest, map_location=rep.device))
+            if tfckpt.is_bundle(latest):                      # a checkpoint written by TensorFlow (or --tf-checkpoints)
+                rep.load_tf_variables(tfckpt.read_bundle(latest))
+            else:
+                rep.load_state_dict(torch.load(latest, map_location=rep.device))
         if self.world > 1:                                    # non-chief replicas take the chief's state
             import torch.distributed as dist
             rep.broadcast_state(dist, 0)
@@ -198,6 +203,8 @@ class Session:
         tmp = path + '.tmp'
         torch.save({k: v.detach().cpu() for k, v in rep.state_dict().items()}, tmp)
         os.replace(tmp, path)
+        if self.tf_checkpoints:                               # the same state as a TensorFlow V2 checkpoint
+            tfckpt.write_bundle(os.path.join(self.dir, f'model.ckpt-{rep.global_step}'), rep.tf_variables())
         with open(os.path.join(self.dir, 'checkpoint'), 'w') as f:
             f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
         self.t_last_ckpt = time.time()
@@ -221,8 +228,10 @@ def latest_checkpoint(ckptdir):
     with open(index) as f:
         line = f.readline()
     name = line.split('"')[1] if '"' in line else ''
-    path = os.path.join(ckptdir, name)
-    return path if name and os.path.exists(path) else None
+    path = name if os.path.isabs(name) else os.path.join(ckptdir, name)
+    if name and (os.path.exists(path) or tfckpt.is_bundle(path)):    # ours (.pt file) or TensorFlow's (bundle prefix)
+        return path
+    return None
 
 
 def parse_args(argv=None):
@@ -248,6 +257,8 @@ def parse_args(argv=None):
     parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                         help='NON-REFERENCE unless fp32: arithmetic of the conv contractions.')
     parser.add_argument('--seed', default=0, type=int, help='Shuffle-queue seed.')
+    parser.add_argument('--tf-checkpoints', action='store_true',
+                        help='Also write every checkpoint as a TensorFlow V2 bundle (model.ckpt-N.index/.data-*).')
     parser.add_argument('--trace-every', default=5000, type=int,
                         help='TraceHook period (src/ann3depth.py:105); traces are taken with rocprofv3 externally.')
     return parser.parse_args(argv)

@@ -228,6 +228,44 @@ class MSDNReplica:
 
     uses_dropout = True
 
+    def load_tf_variables(self, tensors):
+        """Restore from the tensors of a TensorFlow checkpoint (tfckpt.read_bundle): every model variable by its TF
+        name; Adam slots `<var>/<Optimizer>` / `<var>/<Optimizer>_1`, `<Optimizer>/beta{1,2}_power` and `global_step`
+        when present.  Beta powers that are absent are rebuilt from global_step and the phase schedule."""
+        missing = [n for n in self.shapes if n not in tensors]
+        if missing:
+            raise KeyError(f'TensorFlow checkpoint lacks {len(missing)} model variables, e.g. {missing[:3]}')
+        self.load_params(tensors)
+        for n in self.shapes:
+            for which, suffix in (('m', ''), ('v', '_1')):
+                key = n + '/' + self.group_of[n] + suffix
+                if key in tensors:
+                    self.slot(n, which).copy_(torch.from_numpy(np.ascontiguousarray(tensors[key], np.float32)))
+        if 'global_step' in tensors:
+            self.global_step = int(np.asarray(tensors['global_step']).reshape(-1)[0])
+        steps_coarse, steps_fine = SAMPLES_COARSE // self.B, SAMPLES_FINE // self.B
+        applied = {'CoarseConv': min(self.global_step, steps_coarse), 'CoarseDense': min(self.global_step, steps_coarse),
+                   'FineA': min(max(self.global_step - steps_coarse, 0), steps_fine),
+                   'FineB': min(max(self.global_step - steps_coarse, 0), steps_fine)}
+        for gname, g in self.groups.items():
+            for attr, beta in (('beta1_power', g.beta1), ('beta2_power', g.beta2)):
+                key = f'{gname}/{attr}'
+                if key in tensors:
+                    setattr(g, attr, np.float32(np.asarray(tensors[key]).reshape(-1)[0]))
+                else:
+                    power = np.float32(beta)
+                    for _ in range(min(applied[gname], 4096)):       # beta^(t+1); underflows to its limit long before
+                        power = power * np.float32(beta)
+                    setattr(g, attr, power)
+
+    def tf_variables(self):
+        """name -> ndarray in TensorFlow's naming, for tfckpt.write_bundle."""
+        out = {}
+        for k, v in self.state_dict().items():
+            a = v.detach().cpu().numpy()
+            out[k] = a.astype(np.int64) if k == 'global_step' else a.astype(np.float32)
+        return out
+
     def summary_scalars(self, out):
         """Tags as the reference's name scopes 'loss' (src/models.py:288) and 'optimizers' (:347)."""
         return {'loss/coarse_loss': float(out['coarse_loss']), 'loss/fine_loss': float(out['fine_loss']),
@@ -626,6 +664,22 @@ class DCNFReplica:
             for n in g.offsets:
                 g.view(g.var, n).copy_(sd[n])
         self.global_step = int(sd['global_step'].item())
+
+    def load_tf_variables(self, tensors):
+        """Restore from a TensorFlow checkpoint's whole tensors (the reference's dcnf partitions its variables, which
+        tfckpt.read_bundle refuses; a bundle written by this build loads)."""
+        for g in self.groups.values():
+            for n in g.offsets:
+                g.view(g.var, n).copy_(torch.from_numpy(np.ascontiguousarray(tensors[n], np.float32)))
+        if 'global_step' in tensors:
+            self.global_step = int(np.asarray(tensors['global_step']).reshape(-1)[0])
+
+    def tf_variables(self):
+        out = {}
+        for k, v in self.state_dict().items():
+            a = v.detach().cpu().numpy()
+            out[k] = a.astype(np.int64) if k == 'global_step' else a.astype(np.float32)
+        return out
 
 
 # =====================================================================================================

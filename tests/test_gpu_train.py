@@ -94,6 +94,56 @@ def test_make_train_drop_in(tmp_path):
     assert ann3depth.main(base + ['--job-name', 'ps', 'nyu']) == 0
 
 
+def test_continue_from_a_tensorflow_checkpoint(tmp_path):
+    """A checkpoint directory as tf.train.Saver leaves it (`checkpoint` naming a bundle prefix, .index + .data files,
+    model variables and Adam slots under their TF names) is picked up by `make train`; --tf-checkpoints writes one."""
+    from ann3depth_amd import ann3depth, tfckpt
+    write_shard(str(tmp_path))
+    ck = str(tmp_path / 'ckpt')
+    d = os.path.join(ck, 'msdn')
+    os.makedirs(d)
+    rng = np.random.default_rng(9)
+    params = O.init_params(77)
+    tensors = dict(params)
+    tensors['coarse/dense/dense_1/kernel/CoarseDense'] = rng.standard_normal(params['coarse/dense/dense_1/kernel'].shape
+                                                                             ).astype(np.float32)
+    tensors['global_step'] = np.int64(40)
+    tfckpt.write_bundle(os.path.join(d, 'model.ckpt-40'), tensors)
+    with open(os.path.join(d, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model.ckpt-40"\nall_model_checkpoint_paths: "model.ckpt-40"\n')
+    assert ann3depth.latest_checkpoint(d).endswith('model.ckpt-40')
+    base = ['--model', 'msdn', '--batchsize', '4', '--ckptdir', ck, '--datadir', str(tmp_path), '--sumfreq', '1',
+            '--tf-checkpoints']
+    # nothing left to do at --steps 40: the session restores, and saves what it restored
+    assert ann3depth.main(base + ['--steps', '40', 'nyu']) == 0
+    sd = torch.load(os.path.join(d, 'model.ckpt-40.pt'))
+    for n, a in params.items():
+        np.testing.assert_array_equal(sd[n].numpy(), a)
+    np.testing.assert_array_equal(sd['coarse/dense/dense_1/kernel/CoarseDense'].numpy(),
+                                  tensors['coarse/dense/dense_1/kernel/CoarseDense'])
+    assert float(sd['coarse/dense/dense_0/kernel/CoarseDense'].abs().max()) == 0          # absent slot: stays zero
+    assert abs(float(sd['CoarseConv/beta1_power']) - 0.9 ** 41) < 1e-6 and float(sd['FineA/beta1_power']) == np.float32(0.9)
+    # back to the TensorFlow-only directory, and train on
+    os.remove(os.path.join(d, 'model.ckpt-40.pt'))
+    with open(os.path.join(d, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model.ckpt-40"\n')
+    os.remove(os.path.join(d, 'summaries.jsonl'))
+    assert ann3depth.main(base + ['--steps', '42', 'nyu']) == 0
+    sums = [json.loads(l) for l in open(os.path.join(d, 'summaries.jsonl'))]
+    assert [s['global_step'] for s in sums] == [41, 42]                                   # continued from step 40
+    sd = torch.load(os.path.join(d, 'model.ckpt-42.pt'))
+    np.testing.assert_array_equal(sd['fine/third/kernel'].numpy(), params['fine/third/kernel'])
+    # beta powers rebuilt from global_step: beta1^(40 + 1) restored, two more applies since
+    assert abs(float(sd['CoarseConv/beta1_power']) - 0.9 ** 43) < 1e-6
+    # and the bundle written next to the .pt file holds the same state
+    back = tfckpt.read_bundle(os.path.join(d, 'model.ckpt-42'))
+    assert int(back['global_step']) == 42 and back['global_step'].dtype == np.int64
+    for k, v in sd.items():
+        np.testing.assert_array_equal(back[k], v.numpy())
+    for s in (signal.SIGUSR1, signal.SIGUSR2, signal.SIGALRM, signal.SIGINT, signal.SIGTERM):
+        signal.signal(s, signal.SIG_DFL)
+
+
 def test_golden_vectors_on_gpu():
     from ann3depth_amd import models, ops
     g = np.load(os.path.join(GOLD, 'msdn_b2.npz'))
