@@ -48,6 +48,11 @@ endif
 train: ${DATA_DIR}
 	${SCRIPT} ${SCRIPT_PARAMETERS} ${DATASET}
 
+# convert preprocessed PNG pairs to TFRecord shards (the reference's `make convert`, Makefile:123-126), TF-free
+.PHONY: convert
+convert: ${DATA_DIR}
+	DATA_DIR=${DATA_DIR} python3 tools/data_tf_converter.py $(DATASET) --del_raw
+
 .PHONY: help
 help:
 	${SCRIPT} --help

@@ -16,6 +16,7 @@ import zlib
 import numpy as np
 
 from . import tfrecord
+from .png import encode_png  # noqa: F401  (re-exported; tests and the driver use summary.encode_png)
 
 
 def _varint(v):
@@ -39,22 +40,6 @@ def _frame(payload):
     head = struct.pack('<Q', len(payload))
     return (head + struct.pack('<I', tfrecord.masked_crc32c(head)) + payload +
             struct.pack('<I', tfrecord.masked_crc32c(payload)))
-
-
-def encode_png(img):
-    """img uint8 [H,W] / [H,W,1] (grey) or [H,W,3] (RGB) -> PNG bytes (filter 0, zlib)."""
-    img = np.ascontiguousarray(img, np.uint8)
-    if img.ndim == 2:
-        img = img[..., None]
-    h, w, c = img.shape
-    color_type = {1: 0, 3: 2}[c]
-
-    def chunk(kind, data):
-        body = kind + data
-        return struct.pack('>I', len(data)) + body + struct.pack('>I', zlib.crc32(body) & 0xFFFFFFFF)
-    raw = b''.join(b'\x00' + img[y].tobytes() for y in range(h))
-    return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, color_type, 0, 0, 0)) +
-            chunk(b'IDAT', zlib.compress(raw, 6)) + chunk(b'IEND', b''))
 
 
 def to_uint8(image):
