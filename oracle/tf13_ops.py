@@ -9,8 +9,9 @@ this path, and its arithmetic lives in the un-vendored dependency ``tensorflow==
 (``/root/reference/requirements-cpu.txt:1``), which cannot be installed or imported here.  Every
 function below restates the published TF-1.3 kernel semantics for one call site in
 ``/root/reference/src/models.py`` / ``src/data.py`` and is cross-checked in ``tests/`` against an
-independent implementation (torch-CPU float64 with explicit padding) and hand-computed known answers,
-but not against output of TensorFlow itself.
+independent implementation (torch-CPU float64 with explicit padding), hand-computed known answers and the
+known-answer vectors of TensorFlow 1.3's own unit tests for conv2d / its two gradients / max-pool / bilinear
+resize (``tests/golden/tf13_published_vectors.py``), but not against output of TensorFlow run here.
 
 Layouts are TensorFlow's: activations NHWC, conv filters HWIO, dense kernels [in, out].
 All functions are pure numpy and work in the dtype of their inputs (float32 to mirror the reference,

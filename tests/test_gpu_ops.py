@@ -321,3 +321,46 @@ def test_bad_arguments_fail_loudly(ops):
     d.stride = 3
     with pytest.raises(A3dError, match='stride'):
         ops.conv2d_fwd(d, x, w, None, y)
+
+
+def test_tensorflow_published_vectors_through_the_c_abi(ops):
+    """The HIP kernels on the known-answer vectors of TensorFlow's own unit tests (exact small integers: every fp32
+    sum is exact, so equality is bit-exact whatever the accumulation order)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf13_published_vectors as V
+
+    def seq(shape):
+        return np.arange(1, int(np.prod(shape)) + 1, dtype=np.float32).reshape(shape)
+
+    from ann3depth_amd._lib import A3dError
+    for name, xs, ws, stride, pad, want in V.CONV2D_FWD:
+        d = ops.conv_desc(xs[0], xs[1], xs[2], xs[3], ws[3], ws[0], ws[1], stride, pad)
+        y = torch.empty((xs[0], d.ho, d.wo, ws[3]), device='cuda')
+        if stride == 3:            # the library serves the strides the reference uses (1, 2, 4) and says so
+            with pytest.raises(A3dError, match='stride 3 unsupported'):
+                ops.conv2d_fwd(d, dev(seq(xs)), dev(seq(ws)), None, y, None)
+            continue
+        ops.conv2d_fwd(d, dev(seq(xs)), dev(seq(ws)), None, y, None)
+        np.testing.assert_array_equal(y.cpu().numpy().ravel(), np.array(want, np.float32), err_msg=name)
+    for name, xs, ws, os_, stride, pad, want in V.CONV2D_BACKPROP_INPUT:
+        d = ops.conv_desc(xs[0], xs[1], xs[2], xs[3], ws[3], ws[0], ws[1], stride, pad)
+        dx = torch.full(xs, float('nan'), device='cuda')
+        ops.conv2d_bwd_data(d, dev(seq(os_)), dev(seq(ws)), dx)
+        np.testing.assert_array_equal(dx.cpu().numpy().ravel(), np.array(want, np.float32), err_msg=name)
+    for name, xs, ws, os_, stride, pad, want in V.CONV2D_BACKPROP_FILTER:
+        d = ops.conv_desc(xs[0], xs[1], xs[2], xs[3], ws[3], ws[0], ws[1], stride, pad)
+        dw = torch.full(ws, float('nan'), device='cuda')
+        db = torch.full((ws[3],), float('nan'), device='cuda')
+        ops.conv2d_bwd_filter(d, dev(seq(xs)), dev(seq(os_)), dw, db)
+        np.testing.assert_array_equal(dw.cpu().numpy().ravel(), np.array(want, np.float32), err_msg=name)
+        np.testing.assert_array_equal(db.cpu().numpy(), seq(os_).sum(axis=(0, 1, 2)), err_msg=name)
+    xs, want = V.MAXPOOL_VALID
+    y = torch.empty((1, 1, 1, 3), device='cuda')
+    ops.maxpool2x2_fwd(dev(seq(xs)), y)
+    np.testing.assert_array_equal(y.cpu().numpy().ravel(), np.array(want, np.float32))
+    for name, xs, data, h, w, want in V.RESIZE_BILINEAR:
+        y = torch.empty((xs[0], h, w, xs[3]), device='cuda')
+        ops.resize_bilinear_tf1(dev(np.array(data, np.float32).reshape(xs)), y)
+        np.testing.assert_array_equal(y.cpu().numpy().ravel(), np.array(want, np.float32), err_msg=name)
