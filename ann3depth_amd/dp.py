@@ -5,7 +5,9 @@ parameter servers over gRPC (src/ann3depth.py:77-92).  Each optimi
 flat buffer (models.ParamGroup), so a bucket is one `all_reduce(sum)`; the 1/world mean is folded into the Adam
 kernel's grad_scale.  `start()` is asynchronous: the process group's own stream waits for the kernels already
 enqueued on the compute stream, so the dense-layer bucket (268 MB, produced first in backward) is reduced while
-the conv backward kernels still run; `finish()` makes the compute stream wait for all pending buckets.
+the conv backward kernels still run; `wait()` / `finish()` make the compute stream wait for one / all pending buckets.
+MSDNReplica keeps the dense bucket in flight across the step boundary: its ApplyAdam is only due before the next
+step's first dense layer, so the 268 MB reduction also overlaps the next step's conv forward.
 On CPU (tests) the same code runs over the gloo backend.
 """
 import os
@@ -22,7 +24,15 @@ class GradReducer:
         self.pending = []
 
     def start(self, flat_grad):
-        self.pending.append(dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        """Begin the all-reduce of one bucket; returns its handle (see wait())."""
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append(work)
+        return work
+
+    def wait(self, work):
+        """Make the compute stream wait for ONE bucket (the others stay in flight)."""
+        work.wait()
+        self.pending = [w for w in self.pending if w is not work]
 
     def finish(self):
         for w in self.pending:

@@ -122,6 +122,7 @@ class MSDNReplica:
         # launches.  Measured on one MI355X at B = 32: coarse phase +3 % (8.13 k -> 8.39 k images/s), fine phase -6.5 %,
         # and every co-running GEMM stretches by 1.3-2x, so it is off by default and never on in bench.py's line.
         self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
+        self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
         shapes = collections.OrderedDict()
         for c in MSDN_CONVS:
@@ -184,27 +185,47 @@ class MSDNReplica:
         }
 
     # ---- variables ----
+    def settle(self):
+        """Finish what step() left in flight across the step boundary (the CoarseDense all-reduce and its ApplyAdam).
+        Every accessor below and the next forward call it; call it yourself before touching `groups[...]` directly."""
+        if self._deferred is not None:
+            work, group, scale = self._deferred
+            self._deferred = None
+            self.reducer.wait(work)
+            group.apply(scale)
+
     def load_params(self, params):
+        self.settle()
         for n, shp in self.shapes.items():
             g = self.groups[self.group_of[n]]
             a = np.asarray(params[n], np.float32)
             assert a.shape == tuple(shp), (n, a.shape, shp)
             g.view(g.var, n).copy_(torch.from_numpy(np.ascontiguousarray(a)))
 
-    def var(self, name):
+    def _v(self, name):
         g = self.groups[self.group_of[name]]
         return g.view(g.var, name)
 
-    def grad(self, name):
+    def _g(self, name):
         g = self.groups[self.group_of[name]]
         return g.view(g.grad, name)
 
+    def var(self, name):
+        self.settle()
+        return self._v(name)
+
+    def grad(self, name):
+        self.settle()
+        return self._g(name)
+
     def slot(self, name, which):
+        self.settle()
         g = self.groups[self.group_of[name]]
         return g.view(g.m if which == 'm' else g.v, name)
 
     def state_dict(self):
         """name -> tensor for every variable, Adam slot (TF slot naming '<var>/<Optimizer>[_1]') and global_step."""
+        self.settle()
         sd = collections.OrderedDict()
         for n in self.shapes:
             sd[n] = self.var(n)
@@ -217,6 +238,7 @@ class MSDNReplica:
         return sd
 
     def load_state_dict(self, sd):
+        self.settle()
         for n in self.shapes:
             self.var(n).copy_(sd[n])
             self.slot(n, 'm').copy_(sd[n + '/' + self.group_of[n]])
@@ -278,6 +300,7 @@ class MSDNReplica:
 
     def broadcast_state(self, dist, src=0):
         """Non-chief replicas take the chief's variables, slots, beta powers and global_step."""
+        self.settle()
         for g in self.groups.values():
             for buf in (g.var, g.m, g.v):
                 dist.broadcast(buf, src)
@@ -290,7 +313,7 @@ class MSDNReplica:
             g.beta1_power, g.beta2_power = np.float32(st[1 + 2 * i].item()), np.float32(st[2 + 2 * i].item())
 
     def _kb(self, name):
-        return self.var(name + '/kernel'), self.var(name + '/bias')
+        return self._v(name + '/kernel'), self._v(name + '/bias')
 
     def _conv(self, name, x, y):
         w, b = self._kb(name)
@@ -325,6 +348,7 @@ class MSDNReplica:
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
+        self.settle()               # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
         ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
@@ -341,9 +365,9 @@ class MSDNReplica:
     def _bwd_filter(self, name, x, dz):
         with self._beside():
             if name in self.d:
-                ops.conv2d_bwd_filter(self.d[name], x, dz, self.grad(name + '/kernel'), self.grad(name + '/bias'))
+                ops.conv2d_bwd_filter(self.d[name], x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
             else:
-                ops.dense_bwd_filter(x, dz, self.grad(name + '/kernel'), self.grad(name + '/bias'))
+                ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
     def backward_coarse(self, after_dense=None):
@@ -352,27 +376,27 @@ class MSDNReplica:
         n = 'coarse/dense/dense_1'
         self._bwd_filter(n, self.drop, self.dz1)
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
-        ops.dense_bwd_data(self.dz1, self.var(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
+        ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
         n = 'coarse/dense/dense_0'
         flat = self.c4.view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
-        ops.dense_bwd_data(self.dz0, self.var(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
+        ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:
             self._join()
             after_dense()          # dense gradients are complete: their all-reduce can overlap the conv backward
         n = 'coarse/conv/conv2d_4'
         self._bwd_filter(n, self.c3, self.dc4)
-        ops.conv2d_bwd_data(self.d[n], self.dc4, self.var(n + '/kernel'), self.dc3, relu_mask=self.c3)
+        ops.conv2d_bwd_data(self.d[n], self.dc4, self._v(n + '/kernel'), self.dc3, relu_mask=self.c3)
         n = 'coarse/conv/conv2d_3'
         self._bwd_filter(n, self.c2, self.dc3)
-        ops.conv2d_bwd_data(self.d[n], self.dc3, self.var(n + '/kernel'), self.dc2, relu_mask=self.c2)
+        ops.conv2d_bwd_data(self.d[n], self.dc3, self._v(n + '/kernel'), self.dc2, relu_mask=self.c2)
         n = 'coarse/conv/conv2d_2'
         self._bwd_filter(n, self.p1, self.dc2)
-        ops.conv2d_bwd_data(self.d[n], self.dc2, self.var(n + '/kernel'), self.dp1)
+        ops.conv2d_bwd_data(self.d[n], self.dc2, self._v(n + '/kernel'), self.dp1)
         ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
         n = 'coarse/conv/conv2d_1'
         self._bwd_filter(n, self.p0, self.dc1)
-        ops.conv2d_bwd_data(self.d[n], self.dc1, self.var(n + '/kernel'), self.dp0)
+        ops.conv2d_bwd_data(self.d[n], self.dc1, self._v(n + '/kernel'), self.dp0)
         ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
         n = 'coarse/conv/conv2d_0'
         self._bwd_filter(n, self.x, self.dc0)
@@ -384,10 +408,10 @@ class MSDNReplica:
         ops.silog_loss_bwd(self.fine, self.t, self.ws_f, self.dfine)
         n = 'fine/third'
         self._bwd_filter(n, self.f2, self.dfine)
-        ops.conv2d_bwd_data(self.d[n], self.dfine, self.var(n + '/kernel'), self.df2, relu_mask=self.f2)
+        ops.conv2d_bwd_data(self.d[n], self.dfine, self._v(n + '/kernel'), self.df2, relu_mask=self.f2)
         n = 'fine/second/conv2d'
         self._bwd_filter(n, self.cat, self.df2)
-        ops.conv2d_bwd_data(self.d[n], self.df2, self.var(n + '/kernel'), self.dcat)
+        ops.conv2d_bwd_data(self.d[n], self.df2, self._v(n + '/kernel'), self.dcat)
         ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)      # reads channels 0..62 of dcat
         n = 'fine/first/conv2d'
         self._bwd_filter(n, self.x, self.df1)
@@ -406,12 +430,18 @@ class MSDNReplica:
         scale = 1.0 / red.world_size if red is not None else 1.0
         if phase == 1:
             gc, gd = self.groups['CoarseConv'], self.groups['CoarseDense']
-            self.backward_coarse(after_dense=(lambda: red.start(gd.grad)) if red is not None else None)
-            if red is not None:
-                red.start(gc.grad)
-                red.finish()
-            gc.apply(scale)
-            gd.apply(scale)
+            if red is None:
+                self.backward_coarse()
+                gc.apply(scale)
+                gd.apply(scale)
+            else:
+                # dense bucket (268 MB): reduced while the conv backward runs AND, being due only before the next
+                # step's dense_0, while that step's conv forward runs (settle()); conv bucket (15 MB): waited for here
+                handle = []
+                self.backward_coarse(after_dense=lambda: handle.append(red.start(gd.grad)))
+                red.wait(red.start(gc.grad))
+                gc.apply(scale)
+                self._deferred = (handle[0], gd, scale)
         elif phase == 2:
             ga, gb = self.groups['FineA'], self.groups['FineB']
             self.backward_fine()

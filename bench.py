@@ -75,6 +75,7 @@ def run_phase(net, img, dep, masks, steps, warmup, global_step, lib, world, time
     t0 = time.perf_counter()
     for i in range(steps):
         net.step(img, dep, masks[(warmup + i) % len(masks)])
+    net.settle()        # N > 1: the last step's dense-bucket all-reduce + ApplyAdam belong inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

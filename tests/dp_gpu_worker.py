@@ -30,6 +30,10 @@ def main(out_path):
         solo.step(ti, td, tk)
         net = models.MSDNReplica(B, seed=3000, global_step=gstep, reducer=dp.GradReducer())
         net.step(ti, td, tk)
+        if gstep == 0:
+            assert net._deferred is not None          # the dense bucket rides across the step boundary ...
+        net.settle()                                   # ... until someone needs it
+        assert net._deferred is None
         torch.cuda.synchronize()
         for gn in gnames:
             local = solo.groups[gn].grad.clone()

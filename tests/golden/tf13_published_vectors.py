@@ -3,6 +3,7 @@ tensorflow==1.3.0, requirements-cpu.txt:1).  Transcribed offline from
   tensorflow/python/kernel_tests/conv_ops_test.py     (Conv2DTest: testConv2D*, *BackpropInput, *BackpropFilter)
   tensorflow/python/kernel_tests/pooling_ops_test.py  (_testMaxPoolValidPadding)
   tensorflow/python/ops/image_ops_test.py             (ResizeImagesTest.testResizeUp / testResizeDown, BILINEAR)
+  tensorflow/python/kernel_tests/extract_image_patches_op_test.py (testKsize2x2Stride1x1Rate1x1Valid / ...Same)
 In those tests every operand is filled with 1, 2, 3, ... in row-major order (`x = [f * 1.0 for f in range(1, n + 1)]`)
 unless data is given.  These are DATA (inputs by rule + expected outputs), not source; they pin the oracle's conv2d
 (VALID / SAME incl. the odd SAME split, stride > kernel), both conv gradients, max-pool and the legacy bilinear resize
@@ -53,4 +54,10 @@ RESIZE_BILINEAR = [
     ('testResizeDown', (1, 6, 4, 1),
      [128, 128, 64, 64, 128, 128, 64, 64, 64, 64, 128, 128, 64, 64, 128, 128, 50, 50, 100, 100, 50, 50, 100, 100], 3, 2,
      [128.0, 64.0, 64.0, 128.0, 50.0, 100.0]),
+]
+
+# tf.extract_image_patches of image [[1, 2], [3, 4]] (1,2,2,1), ksize 2x2, stride 1: (padding, expected [1,rows,cols,4])
+EXTRACT_PATCHES_2X2 = [
+    ('VALID', [[[[1, 2, 3, 4]]]]),
+    ('SAME', [[[[1, 2, 3, 4], [2, 0, 4, 0]], [[3, 4, 0, 0], [4, 0, 0, 0]]]]),
 ]

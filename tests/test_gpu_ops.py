@@ -364,3 +364,10 @@ def test_tensorflow_published_vectors_through_the_c_abi(ops):
         y = torch.empty((xs[0], h, w, xs[3]), device='cuda')
         ops.resize_bilinear_tf1(dev(np.array(data, np.float32).reshape(xs)), y)
         np.testing.assert_array_equal(y.cpu().numpy().ravel(), np.array(want, np.float32), err_msg=name)
+    for pad, want in V.EXTRACT_PATCHES_2X2:
+        if pad != 'SAME':
+            continue                                   # the C ABI serves the reference's call (SAME, src/models.py:50-59)
+        want = np.array(want, np.float32)
+        y = torch.empty((want.shape[1] * want.shape[2], 2, 2, 1), device='cuda')
+        ops.extract_patches(dev(np.array([1, 2, 3, 4], np.float32).reshape(1, 2, 2, 1)), 2, 1, y)
+        np.testing.assert_array_equal(y.cpu().numpy().reshape(want.shape), want)

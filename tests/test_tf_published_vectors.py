@@ -47,3 +47,11 @@ def test_resize_bilinear(case):
     _, xs, data, h, w, want = case
     y = T.resize_bilinear_tf1(np.array(data, np.float32).reshape(xs), h, w)
     np.testing.assert_array_equal(y.ravel(), np.array(want, np.float32))
+
+
+@pytest.mark.parametrize('case', V.EXTRACT_PATCHES_2X2, ids=lambda c: c[0])
+def test_extract_image_patches(case):
+    pad, want = case
+    x = np.array([1, 2, 3, 4], np.float32).reshape(1, 2, 2, 1)
+    want = np.array(want, np.float32)
+    np.testing.assert_array_equal(T.extract_patches(x, 2, 1, pad).reshape(want.shape), want)
