@@ -157,8 +157,8 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 2/3: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
