@@ -117,10 +117,13 @@ class MSDNReplica:
         self.global_step = global_step
         self.reducer = reducer
         dev = self.device
-        # Opt-in (A3D_OVERLAP=1) second HIP stream: the fine network's forward (needed only for its loss in the coarse
-        # phase) and every backward-filter GEMM (off the dz chain) run beside the main chain, filling the tails of its
-        # launches.  Measured on one MI355X at B = 32: coarse phase +3 % (8.13 k -> 8.39 k images/s), fine phase -6.5 %,
-        # and every co-running GEMM stretches by 1.3-2x, so it is off by default and never on in bench.py's line.
+        # Opt-in second HIP stream (A3D_OVERLAP=1): the fine network's forward — MFMA-bound, and in the coarse phase
+        # needed only for its loss — runs beside the stretch of the coarse chain that is HBM- or launch-bound (dense
+        # forward, loss, dense backward, conv2d_4 backward) and is joined before the large conv backward GEMMs start.
+        # Measured on one MI355X at B = 32: +1.6 % in the coarse phase (8.18 k -> 8.31 k images/s), -0.3 % in the fine
+        # phase; co-running kernels stretch each other by 1.3-2x (the weight-streaming dense GEMMs and the MFMA-bound
+        # convs contend for the same CUs), so per-kernel timings stop being meaningful.  Off by default, never on in
+        # bench.py's line.  (Running every backward-filter GEMM beside the backward-data chain instead: +3 % / -6.5 %.)
         self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
@@ -339,8 +342,6 @@ class MSDNReplica:
         ops.resize_bilinear_tf1(images, self.x)
         ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
-        with self._beside():
-            self._conv('fine/first/conv2d', self.x, self.f1)
         self._conv('coarse/conv/conv2d_0', self.x, self.c0)
         ops.maxpool2x2_fwd(self.c0, self.p0)
         self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
@@ -348,6 +349,8 @@ class MSDNReplica:
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
+        with self._beside():        # beside the two weight-streaming dense layers
+            self._conv('fine/first/conv2d', self.x, self.f1)
         self.settle()               # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
         ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
@@ -363,11 +366,10 @@ class MSDNReplica:
             self._join()
 
     def _bwd_filter(self, name, x, dz):
-        with self._beside():
-            if name in self.d:
-                ops.conv2d_bwd_filter(self.d[name], x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
-            else:
-                ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
+        if name in self.d:
+            ops.conv2d_bwd_filter(self.d[name], x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
+        else:
+            ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
     def backward_coarse(self, after_dense=None):
@@ -382,11 +384,11 @@ class MSDNReplica:
         self._bwd_filter(n, flat, self.dz0)
         ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:
-            self._join()
             after_dense()          # dense gradients are complete: their all-reduce can overlap the conv backward
         n = 'coarse/conv/conv2d_4'
         self._bwd_filter(n, self.c3, self.dc4)
         ops.conv2d_bwd_data(self.d[n], self.dc4, self._v(n + '/kernel'), self.dc3, relu_mask=self.c3)
+        self._join()               # the fine forward has had the dense / conv2d_4 stretch; the big GEMMs below run alone
         n = 'coarse/conv/conv2d_3'
         self._bwd_filter(n, self.c2, self.dc3)
         ops.conv2d_bwd_data(self.d[n], self.dc3, self._v(n + '/kernel'), self.dc2, relu_mask=self.c2)
@@ -400,7 +402,6 @@ class MSDNReplica:
         ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
         n = 'coarse/conv/conv2d_0'
         self._bwd_filter(n, self.x, self.dc0)
-        self._join()
 
     # ---- backward of loss_fine wrt fine/* : src/models.py:333-338 ----
     def backward_fine(self):
@@ -415,7 +416,6 @@ class MSDNReplica:
         ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)      # reads channels 0..62 of dcat
         n = 'fine/first/conv2d'
         self._bwd_filter(n, self.x, self.df1)
-        self._join()
 
     # ---- one session.run(train_op) ----
     def step(self, images, depths, keep_mask):
