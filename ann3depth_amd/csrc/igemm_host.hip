@@ -100,13 +100,23 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
-    for (int want = 1; want <= 256; want *= 2) {
-      if (want > 1 && want > nk / 2) break;
-      if (want > 1 && (size_t)want * g.M * g.N * 4 > kMaxSlabBytes) break;
+    // split-K candidates: every small factor, coarser steps above, and the two factors that fill the chip's block
+    // slots exactly once or twice (tiles * splitk just below 512 / 1024: a kernel of 486 blocks beats one of 648)
+    int wants[48];
+    int nw = 0;
+    for (int w = 1; w <= 24; ++w) wants[nw++] = w;
+    for (int w = 32; w <= 256; w *= 2) { wants[nw++] = w; if (w < 256) wants[nw++] = w + w / 2; }
+    wants[nw++] = (int)std::max<long>(1, kSlots / tiles);
+    wants[nw++] = (int)std::max<long>(1, 2 * kSlots / tiles);
+    for (int wi = 0; wi < nw; ++wi) {
+      const int want = wants[wi];
+      if (want > 1 && want > nk / 2) continue;
+      if (want > 1 && (size_t)want * g.M * g.N * 4 > kMaxSlabBytes) continue;
       const int kps = (nk + want - 1) / want;
       const int splitk = (nk + kps - 1) / kps;
       const long blocks = tiles * splitk;
-      const double t_b = (double)bm * bn * kps * 32.0 / (96.5e3 * kCfgs[c].eff);          // us
+      double t_b = (double)bm * bn * kps * 32.0 / (96.5e3 * kCfgs[c].eff);                // us
+      if (c >= kFirstGldsCfg && kps < 40) t_b *= 1.08;     // LDS-DMA pays off on long K ranges only (conv2d_2: 158 vs 146 us)
       double f;      // kernel time in units of t_b: the slowest CU decides (tools/fit_planner.py)
       if (blocks <= 256) f = 0.62;
       else if (blocks <= kSlots) f = 1.0;

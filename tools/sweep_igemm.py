@@ -67,7 +67,7 @@ def main():
                 os.environ.pop('A3D_BF16_BN', None)
                 os.environ.pop('A3D_FORCE_SPLITK', None)
             for ci, cn in enumerate(CFGS if PREC == 'fp32' else []):
-                for sk in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+                for sk in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 40, 48, 64, 96, 128, 256):
                     os.environ['A3D_FORCE_CFG'] = str(ci)
                     os.environ['A3D_FORCE_SPLITK'] = str(sk)
                     try:
