@@ -212,14 +212,14 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   if (timed) {
     if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
       return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
-    hipEventRecord(slot.start, st);
+    (void)hipEventRecord(slot.start, st);
   }
   if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
   else if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
   else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
   else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
   if (timed) {
-    hipEventRecord(slot.stop, st);
+    (void)hipEventRecord(slot.stop, st);
     a3d_timing_record& r = slot.rec;
     r.mode = mode; r.prec = plan.prec;
     if (plan.prec != A3D_PREC_F32) {
@@ -390,13 +390,13 @@ int a3d_timing_collect(a3d_timing_record* out, int cap) {
   }
   int n = 0;
   for (TimingSlot& s : slots) {
-    hipEventSynchronize(s.stop);
+    (void)hipEventSynchronize(s.stop);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, s.start, s.stop);
+    (void)hipEventElapsedTime(&ms, s.start, s.stop);
     s.rec.ms = ms;
     if (out && n < cap) out[n++] = s.rec;
-    hipEventDestroy(s.start);
-    hipEventDestroy(s.stop);
+    (void)hipEventDestroy(s.start);
+    (void)hipEventDestroy(s.stop);
   }
   return n;
 }
