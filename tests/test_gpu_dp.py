@@ -24,3 +24,44 @@ def test_two_ranks_one_gpu(tmp_path):
     for p in procs:
         assert p.wait(timeout=300) == 0
     assert open(out).read() == '1'
+
+
+def test_make_train_two_replicas(tmp_path):
+    """`make train GPUS=2` as the driver runs it (two processes of ann3depth_amd.ann3depth; gloo because both ranks share
+    the one GPU of the test box): rank-sharded input, chief-only checkpoints and summaries, replicas bit-identical."""
+    import json
+
+    import numpy as np
+    import torch
+    from ann3depth_amd import tfrecord
+    root = str(tmp_path / 'data')
+    rng = np.random.default_rng(0)
+    os.makedirs(os.path.join(root, 'nyu'))
+    with tfrecord.TFRecordWriter(os.path.join(root, 'nyu', 'train.tfrecords')) as w:
+        for _ in range(48):
+            w.write_example(rng.random((48, 64, 3)).astype(np.float32) - np.float32(.5),
+                            rng.random((6, 8, 1)).astype(np.float32) - np.float32(.5))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ck = str(tmp_path / 'ckpt')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo', PYTHONPATH=os.path.dirname(HERE))
+        procs.append(subprocess.Popen(
+            [sys.executable, '-m', 'ann3depth_amd.ann3depth', '--model', 'msdn', '--batchsize', '4', '--steps', '5',
+             '--ckptdir', ck if rank == 0 else str(tmp_path / 'unused'), '--datadir', root, '--sumfreq', '1',
+             '--beta2', '0.999', '--job-name', 'worker', '--timeout', '600', 'nyu'],
+            env=env, cwd=os.path.dirname(HERE)))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    d = os.path.join(ck, 'msdn')
+    sums = [json.loads(l) for l in open(os.path.join(d, 'summaries.jsonl'))]
+    assert [s_['global_step'] for s_ in sums] == [1, 2, 3, 4, 5]
+    assert all(np.isfinite(s_['loss/coarse_loss']) for s_ in sums)
+    sd = torch.load(os.path.join(d, 'model.ckpt-5.pt'))
+    assert int(sd['global_step']) == 5
+    assert float(sd['coarse/dense/dense_1/kernel/CoarseDense'].abs().max()) > 0
+    assert not os.path.exists(str(tmp_path / 'unused'))                  # only the chief writes
