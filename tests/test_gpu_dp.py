@@ -28,7 +28,7 @@ def test_two_ranks_one_gpu(tmp_path):
 
 def test_make_train_two_replicas(tmp_path):
     """`make train GPUS=2` as the driver runs it (two processes of ann3depth_amd.ann3depth; gloo because both ranks share
-    the one GPU of the test box): rank-sharded input, chief-only checkpoints and summaries, replicas bit-identical."""
+    the one GPU of the test box): rank-sharded input, chief-only checkpoints and summaries."""
     import json
 
     import numpy as np
