@@ -301,8 +301,9 @@ struct FilterTTile {
   }
 };
 
+// The whole GEMM of one block: `nwg` blocks work on problem `p`, this one is number `bid_in`.
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
-__global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void igemm_kernel(const IgemmParams p) {
+__device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t nwg, const uint32_t bid_in) {
   using Cfg = IgemmCfg<MODE, BM, BN, WAVES_M, NWAVES, BKT, AVEC, BVEC>;
   constexpr int NT = Cfg::NT;
   constexpr int BK = Cfg::BK;
@@ -325,8 +326,7 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
 
   // ---- block -> (tile_m, tile_n, split): XCD-aware bijective remap of the linear id, tile_n fastest so the
   //      blocks that re-read one im2col panel share an XCD's L2 ----
-  const uint32_t nwg = gridDim.x;
-  uint32_t bid = blockIdx.x;
+  uint32_t bid = bid_in;
   {
     uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -493,6 +493,24 @@ __global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void
       }
     }
   }
+}
+
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
+__global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void igemm_kernel(const IgemmParams p) {
+  igemm_body<MODE, BM, BN, WAVES_M, NWAVES, BKT, AVEC, BVEC>(p, gridDim.x, blockIdx.x);
+}
+
+// Up to four independent problems of one tile configuration in ONE launch (blockIdx.y selects the problem): the
+// parity classes of a strided bwd-data are ~190-block GEMMs each, too small to fill the chip one after the other.
+struct IgemmMulti {
+  IgemmParams p[4];
+};
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
+__global__ __launch_bounds__(64 * NWAVES, (BKT == 16 ? 3 : 2) * NWAVES / 4) void igemm_multi_kernel(const IgemmMulti ps) {
+  const IgemmParams& p = ps.p[blockIdx.y];
+  const uint32_t nwg = (uint32_t)(p.tiles_m * p.tiles_n * p.splitk);
+  if (blockIdx.x >= nwg) return;
+  igemm_body<MODE, BM, BN, WAVES_M, NWAVES, BKT, AVEC, BVEC>(p, nwg, blockIdx.x);
 }
 
 // split-K slab reduction + the same epilogue

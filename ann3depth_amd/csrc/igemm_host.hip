@@ -15,6 +15,7 @@ int launch_igemm_mode0(int cfg, int avec, int bvec, IgemmParams& p, unsigned gri
 int launch_igemm_mode1(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
 
 struct TileCfg {
   int bm, bn;
@@ -498,6 +499,14 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   A3D_CHECK_ARG(dz && w && dx, "conv2d_bwd_data: null tensor");
   const bool vec_ok_a = aligned16(dz), vec_ok_b = aligned16(w);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // stride 2, fp32: the (up to) four classes as ONE launch of 64x64 tiles when that alone fills the chip
+  IgemmMulti multi;
+  int n_multi = 0, multi_avec = 4, multi_bvec = 4;
+  unsigned multi_grid = 0;
+  long multi_tiles = 0;
+  double multi_flops = 0;
+  const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !env_int("A3D_NO_MULTI", 0) &&
+                         env_int("A3D_FORCE_CFG", -1) < 0;
   for (int ph = 0; ph < d->stride; ++ph) {
     for (int pw = 0; pw < d->stride; ++pw) {
       BwdDClass c;
@@ -506,6 +515,11 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       if (!vec_ok_a) g.avec = 1;
       if (!vec_ok_b) g.bvec = 1;
       GemmPlan plan = plan_gemm(g, d->precision);
+      if (try_multi) {                                   // 64x64 tiles, no split-K
+        plan = GemmPlan{};
+        plan.cfg = 4; plan.splitk = 1; plan.ktiles_per_split = std::max(1, (g.K + 31) / 32);
+        plan.tiles_m = (g.M + 63) / 64; plan.tiles_n = (g.N + 63) / 64;
+      }
       if (plan.ws_bytes > ws_bytes)
         return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
       IgemmParams p;
@@ -520,9 +534,57 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       p.ldb = 0; p.ldc = d->ldx;
       p.sub_step = d->stride; p.sub_ph = ph; p.sub_pw = pw; p.tap_r0 = c.r0; p.tap_s0 = c.s0; p.S_full = d->s;
       p.outW = d->w; p.outHW = d->h * d->w;
+      if (try_multi) {
+        p.splitk = 1; p.ktiles_per_split = plan.ktiles_per_split; p.tiles_m = plan.tiles_m; p.tiles_n = plan.tiles_n;
+        p.slab = (size_t)p.M * p.N;
+        multi.p[n_multi++] = p;
+        multi_avec = std::min(multi_avec, g.avec); multi_bvec = std::min(multi_bvec, g.bvec);
+        multi_grid = std::max(multi_grid, (unsigned)((long)plan.tiles_m * plan.tiles_n));
+        multi_tiles += (long)plan.tiles_m * plan.tiles_n;
+        multi_flops += 2.0 * p.M * p.N * p.K;
+        continue;
+      }
       rc = launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, st);
       if (rc != A3D_OK) return rc;
     }
+  }
+  if (try_multi && n_multi > 0) {
+    if (multi_tiles < 256) {                 // too little work for 64x64 tiles without split-K: one launch per class
+      for (int i = 0; i < n_multi; ++i) {
+        IgemmParams& p = multi.p[i];
+        GemmProblem g = bwd_d_problem(d);
+        g.M = p.M; g.K = p.K; g.avec = multi_avec; g.bvec = multi_bvec;
+        GemmPlan plan = plan_gemm(g, d->precision);
+        if (plan.ws_bytes > ws_bytes)
+          return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
+        rc = launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, st);
+        if (rc != A3D_OK) return rc;
+      }
+      return A3D_OK;
+    }
+    TimingSlot slot{};
+    bool timed = false;
+    {
+      std::lock_guard<std::mutex> lk(g_timing_mu);
+      timed = g_timing_on;
+    }
+    if (timed) {
+      if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
+        return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
+      (void)hipEventRecord(slot.start, st);
+    }
+    rc = launch_igemm_multi_bwd_d(multi_avec, multi_bvec, multi, multi_grid, (unsigned)n_multi, st);
+    if (timed) {
+      (void)hipEventRecord(slot.stop, st);
+      a3d_timing_record& r = slot.rec;
+      r.mode = MODE_BWD_D; r.prec = A3D_PREC_F32; r.bm = 64; r.bn = 64; r.waves_m = 2; r.nwaves = 4; r.bk = 32;
+      r.avec = multi_avec; r.bvec = multi_bvec; r.splitk = 1; r.lds_dma = 0;
+      r.m = d->n * d->h * d->w; r.n = d->c; r.k = d->r * d->s * d->k; r.ms = 0.f;
+      r.flops = multi_flops;
+      std::lock_guard<std::mutex> lk(g_timing_mu);
+      g_timing.push_back(slot);
+    }
+    return rc;
   }
   return A3D_OK;
 }

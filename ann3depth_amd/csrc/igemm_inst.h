@@ -57,6 +57,31 @@ static int launch_glds(IgemmParams& p, unsigned grid, hipStream_t st) {
   return check_launch("igemm_glds");
 }
 
+#if A3D_MODE == 1
+// multi-problem launch (parity classes of a strided bwd-data): 64x64 4-wave tiles only
+template <int AVEC, int BVEC>
+static int launch_multi_one(IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st) {
+  using Cfg = IgemmCfg<MODE_BWD_D, 64, 64, 2, 4, 32, AVEC, BVEC>;
+  auto kern = igemm_multi_kernel<MODE_BWD_D, 64, 64, 2, 4, 32, AVEC, BVEC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  clear_stale_error();
+  hipLaunchKernelGGL(kern, dim3(grid_x, count), dim3(Cfg::NT), Cfg::LDS_BYTES, st, ps);
+  return check_launch("igemm_multi");
+}
+int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st) {
+  if (avec == 4 && bvec == 4) return launch_multi_one<4, 4>(ps, grid_x, count, st);
+  if (avec == 4 && bvec == 1) return launch_multi_one<4, 1>(ps, grid_x, count, st);
+  if (avec == 1 && bvec == 4) return launch_multi_one<1, 4>(ps, grid_x, count, st);
+  return launch_multi_one<1, 1>(ps, grid_x, count, st);
+}
+#endif
+
 #define A3D_CAT_(a, b) a##b
 #define A3D_CAT(a, b) A3D_CAT_(a, b)
 

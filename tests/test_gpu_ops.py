@@ -47,6 +47,9 @@ CONV_CASES = [
     (1, 1, 1, 16, 8, 1, 1, 'VALID'),         # degenerate 1x1
     (2, 13, 14, 4, 8, 3, 4, 'VALID'),        # stride 4 > kernel 3: some input pixels receive no gradient at all
     (2, 12, 16, 8, 8, 2, 2, 'SAME'),         # stride 2, kernel 2
+    (32, 13, 18, 384, 256, 3, 2, 'VALID'),   # conv2d_4 at batch 32: the four bwd-data parity classes as ONE launch
+    (20, 31, 33, 64, 48, 3, 2, 'SAME'),      # the same single-launch path with odd sizes, SAME padding, unequal classes
+    (24, 26, 30, 5, 7, 5, 2, 'SAME'),        # ... and with scalar operands (Cin, Cout not multiples of 4), 5x5 taps
 ]
 
 
