@@ -372,7 +372,7 @@ class MSDNReplica:
             ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
-    def backward_coarse(self, after_dense=None):
+    def backward_coarse(self, after_dense=None, after_conv2=None):
         B = self.B
         ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1))
         n = 'coarse/dense/dense_1'
@@ -394,6 +394,8 @@ class MSDNReplica:
         ops.conv2d_bwd_data(self.d[n], self.dc3, self._v(n + '/kernel'), self.dc2, relu_mask=self.c2)
         n = 'coarse/conv/conv2d_2'
         self._bwd_filter(n, self.p1, self.dc2)
+        if after_conv2 is not None:
+            after_conv2()          # gradients of conv2d_2..4 (the tail of the CoarseConv buffer) are complete
         ops.conv2d_bwd_data(self.d[n], self.dc2, self._v(n + '/kernel'), self.dp1)
         ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
         n = 'coarse/conv/conv2d_1'
@@ -437,9 +439,16 @@ class MSDNReplica:
             else:
                 # dense bucket (268 MB): reduced while the conv backward runs AND, being due only before the next
                 # step's dense_0, while that step's conv forward runs (settle()); conv bucket (15 MB): waited for here
-                handle = []
-                self.backward_coarse(after_dense=lambda: handle.append(red.start(gd.grad)))
-                red.wait(red.start(gc.grad))
+                # conv bucket in two pieces: conv2d_2..4 (12.4 of 15 MB, the tail of the flat buffer) goes out as
+                # soon as conv2d_2's filter gradient exists and rides under the conv2d_1 / conv2d_0 backward; only
+                # the 2.6 MB head is reduced on the critical path
+                handle, tail = [], []
+                cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
+                self.backward_coarse(after_dense=lambda: handle.append(red.start(gd.grad)),
+                                     after_conv2=lambda: tail.append(red.start(gc.grad[cut:])))
+                head = red.start(gc.grad[:cut])
+                red.wait(tail[0])
+                red.wait(head)
                 gc.apply(scale)
                 self._deferred = (handle[0], gd, scale)
         elif phase == 2:
