@@ -86,7 +86,10 @@ def test_msdn_step_matches_oracle(models, phase, global_step):
 
 
 def test_msdn_learning_mode_multi_step(models):
-    """beta2 = 0.999 (flagged non-reference mode): weights move, and keep tracking the oracle over several steps."""
+    """beta2 = 0.999 (flagged non-reference mode): weights move, and keep tracking the oracle over several steps.
+    Adam's m/sqrt(v) is ~ +-lr whatever |g| is, so an element whose tiny gradient changes sign under fp32 reordering
+    moves the other way, and from the second step on that feeds back into every gradient: the first step must match
+    element by element, later steps are held to the direction of the accumulated update."""
     B = 2
     params = O.init_params(3000)
     net = models.MSDNReplica(B, params=params, beta2=0.999)
@@ -95,19 +98,25 @@ def test_msdn_learning_mode_multi_step(models):
         img, dep, keep = synth(B, 1000 + step, 96, 128)
         net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
         tr.step(img, dep, keep)
-    torch.cuda.synchronize()
-    moved = 0
-    for n in params:
-        if n.startswith('coarse'):
-            # Adam's m/sqrt(v) is ~ +-lr whatever |g| is, so an element whose tiny gradient changes sign under
-            # fp32 reordering moves the other way: compare element-wise and allow a few such elements
+        if step not in (0, 2):
+            continue
+        moved = 0
+        for n in params:
             w, ref, w0 = net.var(n).cpu().numpy(), tr.p[n], params[n]
-            close = np.abs(w - ref) <= 0.05 * np.abs(ref - w0) + 1e-7
-            assert close.mean() > 0.8, (n, close.mean())
+            if not n.startswith('coarse'):
+                np.testing.assert_array_equal(w, w0)                        # fine/* frozen in the coarse phase
+                continue
             moved += int(np.abs(w - w0).max() > 0)
-        else:
-            np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])     # fine/* frozen in the coarse phase
-    assert moved >= 12
+            close = (np.abs(w - ref) <= 0.05 * np.abs(ref - w0) + 1e-7).mean()
+            if n.endswith('/kernel'):
+                corr = float(np.corrcoef((w - w0).ravel().astype(np.float64), (ref - w0).ravel().astype(np.float64))[0, 1])
+            else:
+                corr = 1.0                                                   # biases: too few elements for a correlation
+            if step == 0:
+                assert close > 0.99 and corr > 0.995, (n, close, corr)
+            else:
+                assert close > 0.6 and corr > 0.75, (n, close, corr)
+        assert moved >= 12
 
 
 def test_msdn_full_batch_properties(models):

@@ -31,7 +31,9 @@ def ops():
 CONV_CASES = [
     # n, h, w, c, k, ksize, stride, padding            (edge cases of SURVEY 8c golden plan + every MSDN/DCNF layer kind)
     (2, 35, 47, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind: Cin=3 scalar gather (odd row length), N=96 tile
-    (2, 35, 48, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind in window-run form: 16-byte runs of 33 -> 36 floats
+    (2, 35, 48, 3, 96, 11, 4, 'VALID'),      # conv2d_0 kind in window-run form: 8-byte runs of 33 -> 34 floats
+    (2, 20, 32, 3, 16, 4, 4, 'VALID'),       # window-run form with 16-byte runs (12 floats, no padding needed)
+    (2, 21, 32, 3, 24, 5, 4, 'VALID'),       # 16-byte runs of 15 -> 16 floats (8-byte runs would not save a tile)
     (1, 228, 304, 3, 96, 11, 4, 'VALID'),    # conv2d_0 itself (one image): last run ends exactly at the row end
     (2, 27, 37, 96, 256, 5, 1, 'SAME'),      # conv2d_1 at full spatial size
     (3, 13, 18, 256, 384, 3, 1, 'SAME'),     # conv2d_2
