@@ -1,0 +1,118 @@
+"""Randomised cross-check of the conv / dense entry points against torch float64 on the GPU box (not part of the test
+suite; the shapes that ever failed live in tests/test_gpu_ops.py).     python tools/fuzz_ops.py [seconds] [seed]
+Shapes are drawn to hit the planner's corners: odd sizes, K tails, split-K factors that are not powers of two, strides
+1/2/4, SAME and VALID, channel counts that are / are not multiples of 4, and problems big enough for every tile class."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ann3depth_amd import ops  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+TOL = 3e-6
+
+
+def rel(a, b, scale=None):
+    """||a - b|| relative to ||scale||, where `scale` is the same contraction over absolute values (no cancellation):
+    the yardstick fp32 accumulation error is proportional to.  Defaults to ||b||."""
+    return float((a.double() - b).norm() / max(float((b if scale is None else scale).norm()), 1e-30))
+
+
+def conv_case():
+    st = int(rng.choice([1, 1, 1, 2, 2, 4]))
+    ks = int(rng.choice([1, 2, 3, 3, 5, 7, 9, 11]))
+    pad = str(rng.choice(['SAME', 'VALID']))
+    c = int(rng.choice([1, 3, 3, 4, 5, 8, 16, 24, 63, 64, 96, 130]))
+    k = int(rng.choice([1, 2, 4, 7, 16, 48, 63, 64, 96, 128, 200]))
+    n = int(rng.integers(1, 40))
+    h = int(rng.integers(ks, 70))
+    w = int(rng.integers(ks, 70))
+    if n * h * w * max(c, k) > 3e7:
+        n = max(1, int(3e7 / (h * w * max(c, k))))
+    return n, h, w, c, k, ks, st, pad
+
+
+def run_conv(n, h, w, c, k, ks, st, pad):
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    if d.ho <= 0 or d.wo <= 0:
+        return 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, h, w, c), device='cuda', generator=g)
+    wt = torch.randn((ks, ks, c, k), device='cuda', generator=g) / np.sqrt(ks * ks * c)
+    b = torch.randn((k,), device='cuda', generator=g)
+    y = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda')
+    ops.conv2d_fwd(d, x, wt, b, y, None)
+    # torch float64 reference with TF padding
+    out_h, out_w = d.ho, d.wo
+    ph = max((out_h - 1) * st + ks - h, 0) if pad == 'SAME' else 0
+    pw = max((out_w - 1) * st + ks - w, 0) if pad == 'SAME' else 0
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = wt.double().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    xp = F.pad(xd, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    ref = F.conv2d(xp, wd, b.double(), stride=st)
+    assert ref.shape[2:] == (out_h, out_w), (ref.shape, out_h, out_w)
+    xa = x.double().abs().permute(0, 3, 1, 2).requires_grad_(True)
+    wa = wt.double().abs().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    ref_abs = F.conv2d(F.pad(xa, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wa, b.double().abs(), stride=st)
+    err = rel(y.permute(0, 3, 1, 2), ref.detach(), ref_abs.detach())
+    dz = torch.randn((n, d.ho, d.wo, k), device='cuda', generator=g)
+    gx, gw = torch.autograd.grad(ref, [xd, wd], dz.double().permute(0, 3, 1, 2))
+    gxa, gwa = torch.autograd.grad(ref_abs, [xa, wa], dz.double().abs().permute(0, 3, 1, 2))
+    dw = torch.full_like(wt, float('nan'))
+    db = torch.full_like(b, float('nan'))
+    ops.conv2d_bwd_filter(d, x, dz, dw, db)
+    err = max(err, rel(dw, gw.permute(2, 3, 1, 0), gwa.permute(2, 3, 1, 0)),
+              rel(db, dz.double().sum((0, 1, 2)), dz.double().abs().sum((0, 1, 2))))
+    dx = torch.full_like(x, float('nan'))
+    ops.conv2d_bwd_data(d, dz, wt, dx)
+    err = max(err, rel(dx, gx.permute(0, 2, 3, 1), gxa.permute(0, 2, 3, 1)) if float(gxa.norm()) > 0
+              else float(dx.abs().max()))
+    return err
+
+
+def run_dense():
+    m = int(rng.choice([1, 2, 5, 16, 32, 33, 64, 200]))
+    k = int(rng.choice([1, 3, 16, 100, 128, 1000, 4096, 12288]))
+    n = int(rng.choice([1, 2, 16, 63, 128, 1000, 4070, 4096]))
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((m, k), device='cuda', generator=g)
+    w = torch.randn((k, n), device='cuda', generator=g) / np.sqrt(k)
+    b = torch.randn((n,), device='cuda', generator=g)
+    y = torch.full((m, n), float('nan'), device='cuda')
+    ops.dense_fwd(x, w, b, y, 'relu')
+    xa, wa, za = x.double().abs(), w.double().abs(), None
+    err = rel(y, torch.relu(x.double() @ w.double() + b.double()), xa @ wa + b.double().abs())
+    dz = torch.randn((m, n), device='cuda', generator=g)
+    za = dz.double().abs()
+    dx = torch.full_like(x, float('nan'))
+    ops.dense_bwd_data(dz, w, dx)
+    err = max(err, rel(dx, dz.double() @ w.double().t(), za @ wa.t()))
+    dw = torch.full_like(w, float('nan'))
+    db = torch.full_like(b, float('nan'))
+    ops.dense_bwd_filter(x, dz, dw, db)
+    err = max(err, rel(dw, x.double().t() @ dz.double(), xa.t() @ za), rel(db, dz.double().sum(0), za.sum(0)))
+    return (m, k, n), err
+
+
+t_end = time.time() + budget
+count, worst = 0, (0.0, None)
+while time.time() < t_end:
+    if rng.random() < 0.25:
+        case, err = run_dense()
+        case = ('dense',) + case
+    else:
+        case = conv_case()
+        err = run_conv(*case)
+        case = ('conv',) + case
+    count += 1
+    if not (err <= TOL):
+        print('FAIL', case, err, flush=True)
+    if err > worst[0]:
+        worst = (err, case)
+print(f'{count} cases, worst rel-L2 {worst[0]:.2e} at {worst[1]}')
