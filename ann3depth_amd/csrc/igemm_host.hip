@@ -280,7 +280,7 @@ static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
   int vec = 0;
   if (step % 4 == 0 && row % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) vec = 4;
   else if (step % 2 == 0 && row % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) vec = 2;
-  if (vec == 4) {
+  if (vec == 4 && d->precision == A3D_PREC_F32) {      // (the bf16 kernels take 16-byte operands only)
     // 8-byte runs pad less (conv2d_0: 33 -> 34 instead of 36 floats per filter row).  Worth the narrower loads when it
     // saves a whole 128-row tile of the bwd-filter GEMM (374 vs 396 rows: 3 tiles instead of 4; 172 -> 148 us, and the
     // forward loses a k-tile: 135 -> 129 us)
