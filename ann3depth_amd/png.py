@@ -64,16 +64,16 @@ def decode_png(data):
             cur = line
         elif f == 2:                                              # Up
             cur = (line + prev) & 255
-        elif f in (1, 3, 4):                                      # Sub / Average / Paeth: serial along the row
+        elif f == 1:                                              # Sub: running sum per channel, modulo 256
+            cur = (np.cumsum(line.reshape(-1, c), axis=0) & 255).reshape(-1)
+        elif f in (3, 4):                                         # Average / Paeth: serial along the row
             cur = np.zeros(stride, np.int32)
             lv, pv = line.tolist(), prev.tolist()
             cv = [0] * stride
             for i in range(stride):
                 a = cv[i - c] if i >= c else 0
                 b = pv[i]
-                if f == 1:
-                    pred = a
-                elif f == 3:
+                if f == 3:
                     pred = (a + b) >> 1
                 else:
                     cc = pv[i - c] if i >= c else 0
@@ -94,8 +94,19 @@ def decode_png(data):
 
 
 def imread(path):
-    with open(path, 'rb') as f:
-        return decode_png(f.read())
+    """Image file -> uint8 array.  Pillow does it when it is installed (C speed; PNG is lossless, so the pixels are the
+    same); decode_png is the dependency-free fallback (Sub / Average / Paeth rows cost ~1 s per 480x640 RGB image)."""
+    try:
+        from PIL import Image
+    except ImportError:
+        with open(path, 'rb') as f:
+            return decode_png(f.read())
+    with Image.open(path) as im:
+        if im.mode == 'P':
+            im = im.convert('RGB')
+        elif im.mode not in ('L', 'LA', 'RGB', 'RGBA'):
+            raise ValueError(f'{path}: unsupported image mode {im.mode}')
+        return np.asarray(im).copy()
 
 
 def imsave(path, img):

@@ -63,8 +63,10 @@ def test_round_trip_and_pil_agreement(tmp_path):
     p = str(tmp_path / 'x.png')
     Image.fromarray(rgb).save(p, optimize=True)                    # PIL picks adaptive filters
     np.testing.assert_array_equal(png.imread(p), rgb)
+    np.testing.assert_array_equal(png.decode_png(open(p, 'rb').read()), rgb)          # own decoder on PIL's filters
     Image.fromarray(grey).convert('P').save(p)                     # palette image -> RGB, like smisc.imread
     np.testing.assert_array_equal(png.imread(p), np.asarray(Image.open(p).convert('RGB')))
+    np.testing.assert_array_equal(png.decode_png(open(p, 'rb').read()), np.asarray(Image.open(p).convert('RGB')))
     png.imsave(p, rgb)
     np.testing.assert_array_equal(np.asarray(Image.open(p)), rgb)
     bad = bytearray(png.encode_png(rgb))
