@@ -40,6 +40,7 @@ struct GemmProblem {
   int mode;          // MODE_*
   int M, N, K;
   int avec, bvec;    // 1 or 4
+  int plain = 0;     // 1: register-staged kernel without split-K only (fused-pool forward)
 };
 
 GemmPlan plan_gemm(const GemmProblem& g, int precision = 0);

@@ -105,6 +105,10 @@ struct IgemmParams {
   int splitk, ktiles_per_split;
   size_t slab;          // elements per split-K slab
   int tiles_m, tiles_n;
+  // FWD with the 2x2 / stride-2 max pool fused into the epilogue: rows are enumerated pool window by pool window
+  // (row = 4 * window + position), so the four conv outputs of a window sit in ONE lane's accumulator registers and
+  // only their maximum is written, to pooled pixel `row / 4`.  div_phw / div_pw then describe the POOLED grid.
+  int pool;
   // BWD_D with stride > 1 runs one launch per output-parity class (h % stride, w % stride): only the filter taps
   // r = tap_r0 + stride*r', s = tap_s0 + stride*s' reach such a pixel, so each class is a stride-1 problem over a
   // sub-sampled pixel grid and a sub-sampled filter.  sub_step == 1: plain launch.
@@ -152,8 +156,16 @@ __device__ __forceinline__ int4 make_pix(const IgemmParams& p, int pixel) {
   uint32_t m = valid ? (uint32_t)pixel : 0u;
   uint32_t n = fdiv(m, p.div_phw);
   uint32_t rem = m - n * p.div_phw.d;
-  uint32_t po = fdiv(rem, p.div_pw);
-  uint32_t qo = rem - po * p.div_pw.d;
+  uint32_t po, qo;
+  if (!TRANSPOSED && p.pool) {           // rem = 4 * (pooled pixel) + position in its 2x2 window
+    const uint32_t win = rem >> 2, sub = rem & 3u;
+    const uint32_t wy = fdiv(win, p.div_pw);
+    po = 2 * wy + (sub >> 1);
+    qo = 2 * (win - wy * p.div_pw.d) + (sub & 1u);
+  } else {
+    po = fdiv(rem, p.div_pw);
+    qo = rem - po * p.div_pw.d;
+  }
   e.x = (int)(n * (uint32_t)p.pHW);
   if (TRANSPOSED) {
     e.y = (int)po + p.pad_t;
@@ -462,6 +474,28 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     ldc = p.N;
   }
   if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
+  if (MODE == MODE_FWD && p.pool) {      // never split-K (host); the activations here are monotonic: act(max) == max(act)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * Cfg::WN + b * 32 + li;
+        if (col >= p.N) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = m0 + wm * Cfg::WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
+          if (row >= p.M) continue;
+          float val = fmaxf(fmaxf(acc[a][b][4 * g], acc[a][b][4 * g + 1]), fmaxf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]));
+          val += bias;
+          if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
+          else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
+          Cout[(size_t)(row >> 2) * ldc + col] = val;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll

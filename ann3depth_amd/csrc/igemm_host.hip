@@ -97,7 +97,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   // Model picks are within 1.15x (mostly 1.05x) of the best measured configuration for every MSDN layer/direction.
   for (int c = 0; c < kNumCfgs; ++c) {
     if (kCfgs[c].eff <= 0.f) continue;
-    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4)) continue;
+    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain)) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
@@ -111,6 +111,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
     wants[nw++] = (int)std::max<long>(1, 2 * kSlots / tiles);
     for (int wi = 0; wi < nw; ++wi) {
       const int want = wants[wi];
+      if (want > 1 && g.plain) continue;
       if (want > 1 && want > nk / 2) continue;
       if (want > 1 && (size_t)want * g.M * g.N * 4 > kMaxSlabBytes) continue;
       const int kps = (nk + want - 1) / want;
@@ -423,15 +424,28 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   return need;
 }
 
-int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                   void* ws, size_t ws_bytes, void* stream) {
+// conv2d forward; pool != 0: y is the 2x2 / stride-2 max pool of the activated conv output, [n, ho/2, wo/2, k] with
+// pixel stride ld_out, and the conv output itself is never written
+static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                         int pool, int ld_out, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
-  if (stencil1_applicable(d)) return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
+  if (pool) {
+    A3D_CHECK_ARG(d->precision == A3D_PREC_F32, "conv2d_pool_fwd: fp32 only");
+    A3D_CHECK_ARG(d->ho >= 2 && d->wo >= 2 && ld_out >= d->k, "conv2d_pool_fwd: output smaller than one pool window");
+    A3D_CHECK_ARG(!stencil1_applicable(d), "conv2d_pool_fwd: single-output-channel convs are not supported");
+  } else if (stencil1_applicable(d)) {
+    return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   GemmProblem g = fwd_problem(d);
+  const int ph = d->ho / 2, pw = d->wo / 2;
+  if (pool) {
+    g.M = d->n * ph * pw * 4;
+    g.plain = 1;
+  }
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
   RunForm rf{};
@@ -463,7 +477,22 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
   p.ldb = d->k; p.ldc = d->ldy;
+  if (pool) {
+    p.pool = 1;
+    p.div_phw = make_fastdiv(ph * pw * 4); p.div_pw = make_fastdiv(pw);
+    p.ldc = ld_out;
+  }
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
+}
+
+int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                   void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y, act, 0, 0, ws, ws_bytes, stream);
+}
+
+int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
+                        int ld_pooled, int act, void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y_pooled, act, 1, ld_pooled, ws, ws_bytes, stream);
 }
 
 // One parity class (ph, pw) of a strided bwd-data as a stride-1 problem; false if the class has no pixels.

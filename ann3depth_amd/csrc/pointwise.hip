@@ -305,6 +305,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 
 }  // namespace a3d
 
+namespace a3d {
+__global__ __launch_bounds__(256) void copy_channel_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           size_t npix, int ld_src, int c_src, int ld_dst, int c_dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
+    dst[i * ld_dst + c_dst] = src[i * ld_src + c_src];
+}
+}  // namespace a3d
+
 using namespace a3d;
 
 extern "C" {
@@ -403,6 +411,16 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
                      static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,
                      grad_scale);
   return check_launch("adam");
+}
+
+int a3d_copy_channel(size_t npix, const float* src, int ld_src, int c_src, float* dst, int ld_dst, int c_dst,
+                     void* stream) {
+  A3D_CHECK_ARG(npix > 0 && src && dst && c_src >= 0 && c_src < ld_src && c_dst >= 0 && c_dst < ld_dst,
+                "copy_channel: bad arguments");
+  clear_stale_error();
+  hipLaunchKernelGGL(copy_channel_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, npix, ld_src, c_src, ld_dst, c_dst);
+  return check_launch("copy_channel");
 }
 
 }  // extern "C"

@@ -126,6 +126,9 @@ class MSDNReplica:
         # bench.py's line.  (Running every backward-filter GEMM beside the backward-data chain instead: +3 % / -6.5 %.)
         self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
+        # conv + ReLU + max pool in one kernel for the network that is NOT trained in the current phase: its pre-pool
+        # activations (f1 in the coarse phase; c0, c1 in the fine phase) are read by no later kernel of the step
+        self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
         self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
         shapes = collections.OrderedDict()
         for c in MSDN_CONVS:
@@ -337,27 +340,45 @@ class MSDNReplica:
             torch.cuda.current_stream().wait_stream(self.side)
 
     # ---- forward: src/models.py:277-290 ----
-    def forward(self, images, depths, keep_mask, join=True):
-        """join=False leaves the fine network's forward in flight on the side stream (step() joins later)."""
+    def _conv_pool(self, name, x, y_pooled):
+        w, b = self._kb(name)
+        ops.conv2d_pool_fwd(self.d[name], x, w, b, y_pooled, 'relu')
+
+    def forward(self, images, depths, keep_mask, join=True, phase=None):
+        """join=False leaves the fine network's forward in flight on the side stream (step() joins later).
+        phase (1 coarse / 2 fine / 3 none trained; None = keep every activation): lets the network whose backward
+        will not run skip its pre-pool activations (c0, c1 resp. f1 are then NOT written)."""
         ops.resize_bilinear_tf1(images, self.x)
         ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
-        self._conv('coarse/conv/conv2d_0', self.x, self.c0)
-        ops.maxpool2x2_fwd(self.c0, self.p0)
-        self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
-        ops.maxpool2x2_fwd(self.c1, self.p1)
+        lean_coarse = self.fuse_pool and phase in (2, 3)
+        lean_fine = self.fuse_pool and phase in (1, 3)
+        if lean_coarse:
+            self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0)
+            self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1)
+        else:
+            self._conv('coarse/conv/conv2d_0', self.x, self.c0)
+            ops.maxpool2x2_fwd(self.c0, self.p0)
+            self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
+            ops.maxpool2x2_fwd(self.c1, self.p1)
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
         with self._beside():        # beside the two weight-streaming dense layers
-            self._conv('fine/first/conv2d', self.x, self.f1)
+            if lean_fine:
+                self._conv_pool('fine/first/conv2d', self.x, self.cat)                        # channels 0..62 of cat
+            else:
+                self._conv('fine/first/conv2d', self.x, self.f1)
         self.settle()               # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
         ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
         ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
         with self._beside():
-            ops.maxpool2x2_fwd(self.f1, self.cat, extra=self.coarse)                          # pool + concat fused
+            if lean_fine:
+                ops.copy_channel(self.coarse, 0, self.cat, 63)                                # tf.concat([pool, coarse])
+            else:
+                ops.maxpool2x2_fwd(self.f1, self.cat, extra=self.coarse)                      # pool + concat fused
             self._conv('fine/second/conv2d', self.cat, self.f2)
             self._conv('fine/third', self.f2, self.fine)
             ops.silog_loss_fwd(self.fine, self.t, self.loss_fine, self.ws_f)
@@ -426,8 +447,8 @@ class MSDNReplica:
         global_step += 1 always (src/models.py:329,343,356)."""
         if keep_mask.dtype != torch.uint8:
             keep_mask = keep_mask.to(torch.uint8)
-        self.forward(images, depths, keep_mask, join=False)
         phase = phase_of(self.global_step, self.B)
+        self.forward(images, depths, keep_mask, join=False, phase=phase)
         red = self.reducer
         scale = 1.0 / red.world_size if red is not None else 1.0
         if phase == 1:

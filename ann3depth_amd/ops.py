@@ -83,6 +83,24 @@ def conv2d_fwd(d, x, w, bias, y, act=None):
     return y
 
 
+def conv2d_pool_fwd(d, x, w, bias, y_pooled, act='relu'):
+    """maxpool2x2(act(conv2d(x) + bias)) in one kernel; y_pooled [n, ho//2, wo//2, >= k] (last dim = pixel stride)."""
+    lib = _lib.load()
+    ws, n = _ws().get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
+    check(lib.a3d_conv2d_pool_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y_pooled), y_pooled.shape[-1],
+                                  ACT[act], ws, n, _stream()), 'a3d_conv2d_pool_fwd')
+    return y_pooled
+
+
+def copy_channel(src, c_src, dst, c_dst):
+    """dst[..., c_dst] = src[..., c_src] (same pixel count; last dims are the pixel strides)."""
+    npix = src.numel() // src.shape[-1]
+    assert dst.numel() // dst.shape[-1] == npix
+    check(_lib.load().a3d_copy_channel(npix, _ptr(src), src.shape[-1], c_src, _ptr(dst), dst.shape[-1], c_dst,
+                                       _stream()), 'a3d_copy_channel')
+    return dst
+
+
 def conv2d_bwd_data(d, dz, w, dx, relu_mask=None):
     lib = _lib.load()
     ws, n = _ws().get(lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)), dz.device)

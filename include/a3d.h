@@ -59,6 +59,13 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                    int act, void* ws, size_t ws_bytes, void* stream);
 
+/* tf.layers.max_pooling2d(tf.layers.conv2d(x, ..., activation), 2, 2) in one kernel (src/models.py:211-216,241-243):
+ * y_pooled[n, ho/2, wo/2, k] (pixel stride ld_pooled >= k) = 2x2 / stride-2 VALID max pool of act(conv + bias); the conv
+ * output itself is never written.  For the layers whose pre-pool activation no later kernel of the step reads (the
+ * network that is not being trained in the current phase).  fp32 only; same workspace as a3d_conv2d_fwd. */
+int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
+                        int ld_pooled, int act, void* ws, size_t ws_bytes, void* stream);
+
 /* Conv2DBackpropInput.  dz = gradient wrt the pre-activation output [n,ho,wo,k] (pixel stride ldy).
  * If relu_mask != NULL (same shape/stride as dx) the result is multiplied by (relu_mask > 0): this fuses the
  * ReluGrad of the PREVIOUS layer, whose output is this layer's input. */
@@ -93,6 +100,11 @@ int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, f
  * tf.concat([pooled, coarse], -1) of src/models.py:246; requires ldy >= c+1). */
 int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int ldy, const float* extra,
                        void* stream);
+/* dst[pix, c_dst] = src[pix, c_src] for npix pixels (pixel strides ld_src / ld_dst): the coarse map into channel 63 of
+ * the fine network's concat buffer (tf.concat, src/models.py:246) when the pooling kernel that normally does it is
+ * fused away. */
+int a3d_copy_channel(size_t npix, const float* src, int ld_src, int c_src, float* dst, int ld_dst, int c_dst,
+                     void* stream);
 /* MaxPoolGrad (first maximum in scan order) fused with the ReluGrad of the conv that produced x:
  * dx = (argmax ? dy : 0) * (x > 0 if relu_mask else 1).  dy has pixel stride lddy. */
 int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* dy, int lddy, float* dx,

@@ -62,8 +62,11 @@ def test_msdn_step_matches_oracle(models, phase, global_step):
     np.testing.assert_array_equal(net.t.cpu().numpy(), a['depths'])
     assert rel(net.coarse.cpu().numpy(), a['coarse']) < DEPTH_TOL
     assert rel(net.fine.cpu().numpy(), a['fine']) < DEPTH_TOL
-    for name, ref in [('c0', 'c0'), ('c1', 'c1'), ('c4', 'c4'), ('drop', 'drop'), ('f1', 'f1'), ('cat', 'cat'), ('f2', 'f2')]:
-        assert rel(getattr(net, name).cpu().numpy(), a[ref]) < 1e-4, name
+    # the network that is not trained in this phase runs conv + pool fused: its pre-pool activations are not written
+    skipped = {1: ('f1',), 2: ('c0', 'c1'), 3: ('c0', 'c1', 'f1')}[phase]
+    for name in ('c0', 'p0', 'c1', 'p1', 'c4', 'drop', 'f1', 'cat', 'f2'):
+        if name not in skipped:
+            assert rel(getattr(net, name).cpu().numpy(), a[name]) < 1e-4, name
     # log(o + 1e-8) of outputs that land within ~1e-7 of zero moves by O(1) under last-bit changes of o
     assert abs(out['coarse_loss'].item() - a['loss_coarse']) < LOSS_TOL * abs(a['loss_coarse'])
     assert abs(out['fine_loss'].item() - a['loss_fine']) < LOSS_TOL * abs(a['loss_fine'])
@@ -157,8 +160,9 @@ def test_msdn_full_batch_matches_oracle(models, phase, global_step):
     np.testing.assert_array_equal(net.x.cpu().numpy(), a['images'])
     assert rel(net.coarse.cpu().numpy(), a['coarse']) < DEPTH_TOL
     assert rel(net.fine.cpu().numpy(), a['fine']) < DEPTH_TOL
-    for name in ('c0', 'c1', 'c2', 'c3', 'c4', 'drop', 'f1', 'cat', 'f2'):
-        assert rel(getattr(net, name).cpu().numpy(), a[name]) < 1e-4, name
+    for name in ('c0', 'p0', 'c1', 'p1', 'c2', 'c3', 'c4', 'drop', 'f1', 'cat', 'f2'):
+        if name not in {1: ('f1',), 2: ('c0', 'c1')}[phase]:              # not written in this phase (fused pool)
+            assert rel(getattr(net, name).cpu().numpy(), a[name]) < 1e-4, name
     assert abs(out['coarse_loss'].item() - a['loss_coarse']) < LOSS_TOL * abs(a['loss_coarse'])
     assert abs(out['fine_loss'].item() - a['loss_fine']) < LOSS_TOL * abs(a['loss_fine'])
     a_gpu = gpu_activations(net)

@@ -376,3 +376,41 @@ def test_tensorflow_published_vectors_through_the_c_abi(ops):
         y = torch.empty((want.shape[1] * want.shape[2], 2, 2, 1), device='cuda')
         ops.extract_patches(dev(np.array([1, 2, 3, 4], np.float32).reshape(1, 2, 2, 1)), 2, 1, y)
         np.testing.assert_array_equal(y.cpu().numpy().reshape(want.shape), want)
+
+
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', [
+    (3, 228, 304, 3, 63, 9, 2, 'VALID'),      # fine/first: 110x148 -> 55x74, window-run form, Cout = 63
+    (2, 228, 304, 3, 96, 11, 4, 'VALID'),     # conv2d_0: 55x74 -> 27x37, the odd last row is never computed
+    (4, 27, 37, 96, 256, 5, 1, 'SAME'),       # conv2d_1: 27x37 -> 13x18, odd row and column dropped
+    (1, 9, 8, 5, 7, 3, 1, 'SAME'),            # scalar operands, tiny
+    (2, 2, 2, 4, 4, 1, 1, 'VALID'),           # exactly one window per image
+])
+def test_conv2d_pool_fwd_equals_conv_then_pool(ops, n, h, w, c, k, ks, st, pad):
+    """The fused conv + ReLU + 2x2 max pool writes what conv2d_fwd followed by maxpool2x2_fwd writes (to fp32 summation
+    order: the unfused conv may run split-K or the LDS-DMA kernel) and stays within tolerance of the float64 oracle."""
+    rng = np.random.default_rng(7 * h + w + c + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    b = rng.standard_normal(k).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda')
+    ops.conv2d_fwd(d, xd, wd, bd, y, 'relu')
+    ref = torch.empty((n, d.ho // 2, d.wo // 2, k), device='cuda')
+    ops.maxpool2x2_fwd(y, ref)
+    for ld in (k, k + 1):                      # dense output, and a concat buffer with one extra channel
+        out = torch.full((n, d.ho // 2, d.wo // 2, ld), -7.0, device='cuda')
+        ops.conv2d_pool_fwd(d, xd, wd, bd, out, 'relu')
+        assert rel_l2(out[..., :k].cpu().numpy(), ref.cpu().numpy()) < 2e-6
+        fused = out[..., :k].clone()
+        if ld > k:
+            assert bool((out[..., k] == -7.0).all())                       # the extra channel is left alone
+            src = torch.rand((n, d.ho // 2, d.wo // 2, 1), device='cuda')
+            ops.copy_channel(src, 0, out, k)
+            assert torch.equal(out[..., k], src[..., 0]) and torch.equal(out[..., :k], fused)
+    y64 = T.maxpool2x2_fwd(T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), st, pad, True))
+    assert rel_l2(ref.cpu().numpy(), y64) < RTOL_F32
+    no_act = torch.empty_like(ref)
+    ops.conv2d_pool_fwd(d, xd, wd, None, no_act, None)
+    y_lin = T.maxpool2x2_fwd(T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), np.zeros(k), st, pad, False))
+    assert rel_l2(no_act.cpu().numpy(), y_lin) < RTOL_F32
