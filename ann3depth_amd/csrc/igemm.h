@@ -109,6 +109,7 @@ struct IgemmParams {
   // (row = 4 * window + position), so the four conv outputs of a window sit in ONE lane's accumulator registers and
   // only their maximum is written, to pooled pixel `row / 4`.  div_phw / div_pw then describe the POOLED grid.
   int pool;
+  uint8_t* argmax;      // pool: position (0..3, row-major in the window, first maximum) of each written maximum, or null
   // BWD_D with stride > 1 runs one launch per output-parity class (h % stride, w % stride): only the filter taps
   // r = tap_r0 + stride*r', s = tap_s0 + stride*s' reach such a pixel, so each class is a stride-1 problem over a
   // sub-sampled pixel grid and a sub-sampled filter.  sub_step == 1: plain launch.
@@ -474,7 +475,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     ldc = p.N;
   }
   if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
-  if (MODE == MODE_FWD && p.pool) {      // never split-K (host); the activations here are monotonic: act(max) == max(act)
+  if (MODE == MODE_FWD && p.pool) {      // never split-K (host)
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -486,11 +487,21 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         for (int g = 0; g < 4; ++g) {
           const int row = m0 + wm * Cfg::WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
           if (row >= p.M) continue;
-          float val = fmaxf(fmaxf(acc[a][b][4 * g], acc[a][b][4 * g + 1]), fmaxf(acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]));
-          val += bias;
-          if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
-          else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
+          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[a][b][4 * g + i] + bias;
+            if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
+            else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
+          }
+          float val = v[0];
+          int arg = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i)
+            if (v[i] > val) { val = v[i]; arg = i; }
           Cout[(size_t)(row >> 2) * ldc + col] = val;
+          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
         }
       }
     }

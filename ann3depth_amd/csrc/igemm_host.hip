@@ -427,7 +427,7 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
 // conv2d forward; pool != 0: y is the 2x2 / stride-2 max pool of the activated conv output, [n, ho/2, wo/2, k] with
 // pixel stride ld_out, and the conv output itself is never written
 static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         int pool, int ld_out, void* ws, size_t ws_bytes, void* stream) {
+                         int pool, int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
@@ -479,6 +479,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   p.ldb = d->k; p.ldc = d->ldy;
   if (pool) {
     p.pool = 1;
+    p.argmax = argmax;
     p.div_phw = make_fastdiv(ph * pw * 4); p.div_pw = make_fastdiv(pw);
     p.ldc = ld_out;
   }
@@ -487,12 +488,12 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
 
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                    void* ws, size_t ws_bytes, void* stream) {
-  return conv_fwd_impl(d, x, w, bias, y, act, 0, 0, ws, ws_bytes, stream);
+  return conv_fwd_impl(d, x, w, bias, y, act, 0, 0, nullptr, ws, ws_bytes, stream);
 }
 
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
-                        int ld_pooled, int act, void* ws, size_t ws_bytes, void* stream) {
-  return conv_fwd_impl(d, x, w, bias, y_pooled, act, 1, ld_pooled, ws, ws_bytes, stream);
+                        int ld_pooled, uint8_t* argmax, int act, void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y_pooled, act, 1, ld_pooled, argmax, ws, ws_bytes, stream);
 }
 
 // One parity class (ph, pw) of a strided bwd-data as a stride-1 problem; false if the class has no pixels.

@@ -79,6 +79,41 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// the same from the recorded argmax position and the pooled value (a3d_conv2d_pool_fwd): one thread per 2x2 cell of
+// the input grid, like maxpool_bwd_kernel (cells cut by VALID flooring write zeros)
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ argmax,
+                                                              const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                              int wo, int ldy, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const size_t total = (size_t)n * hc * wc * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int q = (int)(t % wc);
+    t /= wc;
+    const int p = (int)(t % hc);
+    const int b = (int)(t / hc);
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+    if (p < ho && q < wo) {
+      const size_t win = ((size_t)b * ho + p) * wo + q;
+      const int arg = argmax[win * c + ch];
+      float g = dy[win * lddy + ch];
+      if (relu_mask && !(y[win * ldy + ch] > 0.f)) g = 0.f;
+      dx[base] = arg == 0 ? g : 0.f;
+      dx[base + c] = arg == 1 ? g : 0.f;
+      dx[base + (size_t)w * c] = arg == 2 ? g : 0.f;
+      dx[base + (size_t)w * c + c] = arg == 3 ? g : 0.f;
+    } else {
+      const bool has_r = 2 * p + 1 < h, has_c = 2 * q + 1 < w;
+      dx[base] = 0.f;
+      if (has_c) dx[base + c] = 0.f;
+      if (has_r) dx[base + (size_t)w * c] = 0.f;
+      if (has_r && has_c) dx[base + (size_t)w * c + c] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ ResizeBilinear (legacy, align_corners=False)
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
                                                      int w, int c, int oh, int ow, float sy, float sx) {
@@ -421,6 +456,17 @@ int a3d_copy_channel(size_t npix, const float* src, int ld_src, int c_src, float
   hipLaunchKernelGGL(copy_channel_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 2048)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, dst, npix, ld_src, c_src, ld_dst, c_dst);
   return check_launch("copy_channel");
+}
+
+int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, const float* y, int ldy, const float* dy,
+                           int lddy, float* dx, int relu_mask, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && argmax && y && dy && dx && ldy >= c && lddy >= c,
+                "maxpool_bwd_idx: bad arguments");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  clear_stale_error();
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     argmax, y, dy, dx, n, h, w, c, h / 2, w / 2, ldy, lddy, relu_mask);
+  return check_launch("maxpool_bwd_idx");
 }
 
 }  // extern "C"

@@ -126,8 +126,8 @@ class MSDNReplica:
         # bench.py's line.  (Running every backward-filter GEMM beside the backward-data chain instead: +3 % / -6.5 %.)
         self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
-        # conv + ReLU + max pool in one kernel for the network that is NOT trained in the current phase: its pre-pool
-        # activations (f1 in the coarse phase; c0, c1 in the fine phase) are read by no later kernel of the step
+        # conv + ReLU + max pool in one kernel inside step(): the pre-pool activations c0, c1, f1 are never written
+        # (the network being trained keeps one byte per pool window instead, see forward())
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
         self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
         shapes = collections.OrderedDict()
@@ -168,6 +168,11 @@ class MSDNReplica:
         self.f2 = buf(B, OUT_H, OUT_W, 64)
         self.fine = buf(B, OUT_H, OUT_W, 1)
         self.loss_coarse = buf(1); self.loss_fine = buf(1)
+        # window positions of the pool maxima (all MaxPoolGrad needs besides the pooled values, see forward())
+        self.a0 = torch.empty((B, 27, 37, 96), dtype=torch.uint8, device=dev)
+        self.a1 = torch.empty((B, 13, 18, 256), dtype=torch.uint8, device=dev)
+        self.af1 = torch.empty((B, OUT_H, OUT_W, 63), dtype=torch.uint8, device=dev)
+        self.pooled_fwd = None            # which network ran conv + pool fused in the last forward
         self.ws_c = buf(2 * B); self.ws_f = buf(2 * B)
         # gradients wrt pre-activations
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
@@ -340,22 +345,44 @@ class MSDNReplica:
             torch.cuda.current_stream().wait_stream(self.side)
 
     # ---- forward: src/models.py:277-290 ----
-    def _conv_pool(self, name, x, y_pooled):
+    def prepool_equivalent(self, which):
+        """'c0' | 'c1' | 'f1' as far as a backward pass can tell: the tensor itself when the last forward wrote it,
+        otherwise zeros with each pool window's maximum at its recorded position (same MaxPoolGrad routing, same
+        ReluGrad mask).  For tests and debugging."""
+        src = {'c0': (self.c0, self.p0, self.a0, 1), 'c1': (self.c1, self.p1, self.a1, 1),
+               'f1': (self.f1, self.cat, self.af1, 2)}[which]
+        full, pooled, arg, phase = src
+        if self.pooled_fwd != phase:
+            return full
+        c = arg.shape[-1]
+        out = torch.zeros_like(full)
+        ph, pw = arg.shape[1], arg.shape[2]
+        win = out[:, :2 * ph, :2 * pw, :].reshape(full.shape[0], ph, 2, pw, 2, c)
+        a = arg.long()
+        for pos in range(4):
+            win[:, :, pos >> 1, :, pos & 1, :] = torch.where(a == pos, pooled[..., :c], torch.zeros_like(pooled[..., :c]))
+        return out
+
+    def _conv_pool(self, name, x, y_pooled, argmax=None):
         w, b = self._kb(name)
-        ops.conv2d_pool_fwd(self.d[name], x, w, b, y_pooled, 'relu')
+        ops.conv2d_pool_fwd(self.d[name], x, w, b, y_pooled, 'relu', argmax)
 
     def forward(self, images, depths, keep_mask, join=True, phase=None):
         """join=False leaves the fine network's forward in flight on the side stream (step() joins later).
-        phase (1 coarse / 2 fine / 3 none trained; None = keep every activation): lets the network whose backward
-        will not run skip its pre-pool activations (c0, c1 resp. f1 are then NOT written)."""
+        phase (1 coarse / 2 fine / 3 none trained) runs every conv that feeds a max pool fused with it: the pre-pool
+        activations c0, c1, f1 are then NOT written.  The network being trained also records the position of each
+        maximum (a0, a1 / af1): MaxPoolGrad routes dy to that position and the fused ReluGrad only asks whether the
+        maximum is positive, so the backward needs nothing else of c0 / c1 / f1.  phase None keeps every activation."""
         ops.resize_bilinear_tf1(images, self.x)
         ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
-        lean_coarse = self.fuse_pool and phase in (2, 3)
-        lean_fine = self.fuse_pool and phase in (1, 3)
-        if lean_coarse:
-            self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0)
-            self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1)
+        fused = self.fuse_pool and phase in (1, 2, 3)
+        self.pooled_fwd = phase if fused else None
+        lean_fine = fused
+        if fused:
+            train = phase == 1
+            self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0 if train else None)
+            self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1 if train else None)
         else:
             self._conv('coarse/conv/conv2d_0', self.x, self.c0)
             ops.maxpool2x2_fwd(self.c0, self.p0)
@@ -366,7 +393,7 @@ class MSDNReplica:
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
         with self._beside():        # beside the two weight-streaming dense layers
             if lean_fine:
-                self._conv_pool('fine/first/conv2d', self.x, self.cat)                        # channels 0..62 of cat
+                self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
             else:
                 self._conv('fine/first/conv2d', self.x, self.f1)
         self.settle()               # the previous step's dense-layer update is due now, not earlier
@@ -418,11 +445,17 @@ class MSDNReplica:
         if after_conv2 is not None:
             after_conv2()          # gradients of conv2d_2..4 (the tail of the CoarseConv buffer) are complete
         ops.conv2d_bwd_data(self.d[n], self.dc2, self._v(n + '/kernel'), self.dp1)
-        ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
+        if self.pooled_fwd == 1:
+            ops.maxpool2x2_bwd_idx(self.a1, self.p1, self.dp1, self.dc1, relu_mask=True)
+        else:
+            ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
         n = 'coarse/conv/conv2d_1'
         self._bwd_filter(n, self.p0, self.dc1)
         ops.conv2d_bwd_data(self.d[n], self.dc1, self._v(n + '/kernel'), self.dp0)
-        ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
+        if self.pooled_fwd == 1:
+            ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
+        else:
+            ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
         n = 'coarse/conv/conv2d_0'
         self._bwd_filter(n, self.x, self.dc0)
 
@@ -436,7 +469,10 @@ class MSDNReplica:
         n = 'fine/second/conv2d'
         self._bwd_filter(n, self.cat, self.df2)
         ops.conv2d_bwd_data(self.d[n], self.df2, self._v(n + '/kernel'), self.dcat)
-        ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)      # reads channels 0..62 of dcat
+        if self.pooled_fwd == 2:                                               # both read channels 0..62 of dcat
+            ops.maxpool2x2_bwd_idx(self.af1, self.cat, self.dcat, self.df1, relu_mask=True)
+        else:
+            ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)
         n = 'fine/first/conv2d'
         self._bwd_filter(n, self.x, self.df1)
 

@@ -83,13 +83,24 @@ def conv2d_fwd(d, x, w, bias, y, act=None):
     return y
 
 
-def conv2d_pool_fwd(d, x, w, bias, y_pooled, act='relu'):
-    """maxpool2x2(act(conv2d(x) + bias)) in one kernel; y_pooled [n, ho//2, wo//2, >= k] (last dim = pixel stride)."""
+def conv2d_pool_fwd(d, x, w, bias, y_pooled, act='relu', argmax=None):
+    """maxpool2x2(act(conv2d(x) + bias)) in one kernel; y_pooled [n, ho//2, wo//2, >= k] (last dim = pixel stride).
+    argmax: optional uint8 [n, ho//2, wo//2, k], receives the window position of each maximum (for maxpool2x2_bwd_idx)."""
     lib = _lib.load()
     ws, n = _ws().get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
     check(lib.a3d_conv2d_pool_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y_pooled), y_pooled.shape[-1],
-                                  ACT[act], ws, n, _stream()), 'a3d_conv2d_pool_fwd')
+                                  _ptr(argmax), ACT[act], ws, n, _stream()), 'a3d_conv2d_pool_fwd')
     return y_pooled
+
+
+def maxpool2x2_bwd_idx(argmax, y_pooled, dy, dx, relu_mask=True):
+    """MaxPoolGrad (+ ReluGrad) from the argmax positions and pooled values of conv2d_pool_fwd; dx [n,h,w,c] dense,
+    y_pooled / dy: last dim = pixel stride (>= c)."""
+    n, h, w, c = dx.shape
+    check(_lib.load().a3d_maxpool2x2_bwd_idx(n, h, w, c, _ptr(argmax), _ptr(y_pooled), y_pooled.shape[-1], _ptr(dy),
+                                             dy.shape[-1], _ptr(dx), int(relu_mask), _stream()),
+          'a3d_maxpool2x2_bwd_idx')
+    return dx
 
 
 def copy_channel(src, c_src, dst, c_dst):

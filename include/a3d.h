@@ -61,10 +61,11 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
 
 /* tf.layers.max_pooling2d(tf.layers.conv2d(x, ..., activation), 2, 2) in one kernel (src/models.py:211-216,241-243):
  * y_pooled[n, ho/2, wo/2, k] (pixel stride ld_pooled >= k) = 2x2 / stride-2 VALID max pool of act(conv + bias); the conv
- * output itself is never written.  For the layers whose pre-pool activation no later kernel of the step reads (the
- * network that is not being trained in the current phase).  fp32 only; same workspace as a3d_conv2d_fwd. */
+ * output itself is never written.  argmax (may be NULL): [n, ho/2, wo/2, k] bytes, the position 0..3 (row-major in the
+ * window) of the first maximum — all that MaxPoolGrad + ReluGrad need besides the pooled value, so training does not
+ * need the conv output either (a3d_maxpool2x2_bwd_idx).  fp32 only; same workspace as a3d_conv2d_fwd. */
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
-                        int ld_pooled, int act, void* ws, size_t ws_bytes, void* stream);
+                        int ld_pooled, uint8_t* argmax, int act, void* ws, size_t ws_bytes, void* stream);
 
 /* Conv2DBackpropInput.  dz = gradient wrt the pre-activation output [n,ho,wo,k] (pixel stride ldy).
  * If relu_mask != NULL (same shape/stride as dx) the result is multiplied by (relu_mask > 0): this fuses the
@@ -100,6 +101,11 @@ int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, f
  * tf.concat([pooled, coarse], -1) of src/models.py:246; requires ldy >= c+1). */
 int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int ldy, const float* extra,
                        void* stream);
+/* The same MaxPoolGrad (+ ReluGrad) from what a3d_conv2d_pool_fwd leaves: dx[n,h,w,c] = dy at the recorded position of
+ * each window if (!relu_mask || pooled > 0), zero elsewhere (incl. the odd last row / column the pool dropped).
+ * y: pooled values [n,h/2,w/2] with pixel stride ldy; argmax dense [n,h/2,w/2,c]; dy pixel stride lddy. */
+int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, const float* y, int ldy, const float* dy,
+                           int lddy, float* dx, int relu_mask, void* stream);
 /* dst[pix, c_dst] = src[pix, c_src] for npix pixels (pixel strides ld_src / ld_dst): the coarse map into channel 63 of
  * the fine network's concat buffer (tf.concat, src/models.py:246) when the pooling kernel that normally does it is
  * fused away. */

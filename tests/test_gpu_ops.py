@@ -414,3 +414,35 @@ def test_conv2d_pool_fwd_equals_conv_then_pool(ops, n, h, w, c, k, ks, st, pad):
     ops.conv2d_pool_fwd(d, xd, wd, None, no_act, None)
     y_lin = T.maxpool2x2_fwd(T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), np.zeros(k), st, pad, False))
     assert rel_l2(no_act.cpu().numpy(), y_lin) < RTOL_F32
+
+
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad,ld', [(3, 40, 52, 3, 63, 9, 2, 'VALID', 64), (2, 27, 37, 96, 256, 5, 1, 'SAME', 256),
+                                                   (1, 9, 8, 5, 7, 3, 1, 'SAME', 7), (2, 35, 48, 3, 96, 11, 4, 'VALID', 96)])
+def test_maxpool_bwd_from_recorded_argmax(ops, n, h, w, c, k, ks, st, pad, ld):
+    """conv2d_pool_fwd's argmax bytes + pooled values give maxpool2x2_bwd_idx everything MaxPoolGrad + ReluGrad need:
+    same dx as the unfused conv -> pool -> maxpool2x2_bwd path (odd last row / column zero), and as the oracle."""
+    rng = np.random.default_rng(h * w + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    b = rng.standard_normal(k).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    ph, pw = d.ho // 2, d.wo // 2
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    pooled = torch.zeros((n, ph, pw, ld), device='cuda')
+    arg = torch.full((n, ph, pw, k), 9, dtype=torch.uint8, device='cuda')
+    ops.conv2d_pool_fwd(d, xd, wd, bd, pooled, 'relu', arg)
+    assert int(arg.max()) <= 3
+    dy = rng.standard_normal((n, ph, pw, ld)).astype(np.float32)          # only the first k channels are read
+    dyd = dev(dy)
+    dx = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda')
+    ops.maxpool2x2_bwd_idx(arg, pooled, dyd, dx, relu_mask=True)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda')
+    ops.conv2d_fwd(d, xd, wd, bd, y, 'relu')
+    dx_ref = torch.full_like(dx, float('nan'))
+    ops.maxpool2x2_bwd(y, dyd, dx_ref, relu_mask=True)
+    assert rel_l2(dx.cpu().numpy(), dx_ref.cpu().numpy()) < 1e-5
+    y64 = T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), st, pad, True)
+    want = T.relu_grad(T.maxpool2x2_bwd(y64, dy[..., :k].astype(np.float64)), y64)
+    assert rel_l2(dx.cpu().numpy(), want) < 1e-5
+    ops.maxpool2x2_bwd_idx(arg, pooled, dyd, dx, relu_mask=False)
+    assert rel_l2(dx.cpu().numpy(), T.maxpool2x2_bwd(y64, dy[..., :k].astype(np.float64))) < 1e-5
