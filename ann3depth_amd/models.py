@@ -567,15 +567,23 @@ class DCNFUnary:
         self.act = collections.OrderedDict()
         self.dact = {}
         self.desc = {}
+        # conv + ReLU + max pool in one kernel (fp32): the pre-pool activations (1.6 + 1.3 GB at batch 16) are never
+        # written, one argmax byte per pool window serves the backward (see MSDNReplica.forward)
+        self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
+        self.argmax, self.conv_hw = {}, {}
         self.act['x'] = buf(P, DCNF_PATCH, DCNF_PATCH, 3)
         h = DCNF_PATCH
         for n, ci, co, k in DCNF_CONVS:
             self.desc[n] = ops.conv_desc(P, h, h, ci, co, k, k, 1, 'VALID', precision=precision)
             h = h - k + 1
-            self.act[n] = buf(P, h, h, co)
+            self.conv_hw[n] = h
+            if not (self.fuse_pool and n in DCNF_POOL_AFTER):
+                self.act[n] = buf(P, h, h, co)
             if n in DCNF_POOL_AFTER:
                 h //= 2
                 self.act[n + '/pool'] = buf(P, h, h, co)
+                if self.fuse_pool:
+                    self.argmax[n] = torch.empty((P, h, h, co), dtype=torch.uint8, device=dev)
         for n, i, o, _ in DCNF_DENSES:
             self.act[n] = buf(P, o)
         self.z = self.act['dense_2']
@@ -591,6 +599,10 @@ class DCNFUnary:
         ops.extract_patches(self.resized, DCNF_PATCH, DCNF_SP, self.act['x'])   # :50-59
         t = self.act['x']
         for n, _, _, _ in DCNF_CONVS:
+            if self.fuse_pool and n in DCNF_POOL_AFTER:
+                t = ops.conv2d_pool_fwd(self.desc[n], t, self.var(n + '/kernel'), self.var(n + '/bias'),
+                                        self.act[n + '/pool'], 'relu', self.argmax[n])
+                continue
             ops.conv2d_fwd(self.desc[n], t, self.var(n + '/kernel'), self.var(n + '/bias'), self.act[n], 'relu')
             t = self.act[n]
             if n in DCNF_POOL_AFTER:
@@ -601,6 +613,22 @@ class DCNFUnary:
             ops.dense_fwd(t, self.var(n + '/kernel'), self.var(n + '/bias'), self.act[n], act)
             t = self.act[n]
         return self.z.view(self.B, self.rows * self.cols, 1)
+
+    def activations(self):
+        """name -> numpy array of every activation; a pre-pool activation that the fused conv + pool never wrote comes
+        back as zeros with each window's maximum at its recorded position (all a backward pass can see of it)."""
+        out = {k: v.cpu().numpy() for k, v in self.act.items()}
+        for n, arg in self.argmax.items():
+            pooled = self.act[n + '/pool']
+            hw, c = self.conv_hw[n], pooled.shape[-1]
+            full = torch.zeros((self.P, hw, hw, c), device=self.device)
+            ph = pooled.shape[1]
+            win = full[:, :2 * ph, :2 * ph, :].reshape(self.P, ph, 2, ph, 2, c)
+            a = arg.long()
+            for pos in range(4):
+                win[:, :, pos >> 1, :, pos & 1, :] = torch.where(a == pos, pooled, torch.zeros_like(pooled))
+            out[n] = full.cpu().numpy()
+        return out
 
     def _dbuf(self, key, like):
         if key not in self.dact:
@@ -627,7 +655,13 @@ class DCNFUnary:
         inputs = {'conv2d': 'x', 'conv2d_1': 'conv2d/pool', 'conv2d_2': 'conv2d_1/pool', 'conv2d_3': 'conv2d_2',
                   'conv2d_4': 'conv2d_3'}
         for n, _, _, _ in reversed(DCNF_CONVS):
-            if n in DCNF_POOL_AFTER:
+            if n in DCNF_POOL_AFTER and self.fuse_pool:
+                hw, co = self.conv_hw[n], a[n + '/pool'].shape[-1]
+                if n not in self.dact:
+                    self.dact[n] = torch.empty((P, hw, hw, co), device=self.device)
+                dzc = self.dact[n]
+                ops.maxpool2x2_bwd_idx(self.argmax[n], a[n + '/pool'], d.view(a[n + '/pool'].shape), dzc, relu_mask=True)
+            elif n in DCNF_POOL_AFTER:
                 dzc = self._dbuf(n, a[n])
                 ops.maxpool2x2_bwd(a[n], d, dzc, relu_mask=True)
             else:

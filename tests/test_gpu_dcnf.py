@@ -125,7 +125,7 @@ def test_dcnf_train_step_matches_oracle():
     np.testing.assert_allclose(float(out['mean_loss']), m_ref, rtol=2e-5)
     assert rel(rep.dz.cpu().numpy(), dz_ref[..., 0]) < 2e-3
     # backward chain on the GPU activations, then var -= 0.1 * grad
-    a_gpu = {k: v.cpu().numpy() for k, v in rep.unary.act.items()}
+    a_gpu = rep.unary.activations()
     a_gpu['flat'] = a_gpu['conv2d_4/pool'].reshape(48, -1)
     g = OD.unary_backward(params, a_gpu, rep.dz.cpu().numpy().reshape(48, 1))
     for n, gref in g.items():
