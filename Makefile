@@ -32,6 +32,15 @@ CKPT_DIR ?= checkpoints
 TIMEOUT ?= 4200
 # data-parallel replicas on this node (replaces PS_NODES / WORKERS of `make distributed`)
 GPUS ?= 1
+WORKERS ?= 8
+
+# `make convert nyu make3d1`: dataset names as extra goals, like the reference (Makefile:74-78)
+ifeq (convert,$(firstword $(MAKECMDGOALS)))
+    ifneq (,$(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS)))
+        DATASET := $(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS))
+        $(eval $(DATASET):;@:)
+    endif
+endif
 
 SCRIPT_PARAMETERS := --ckptdir=${CKPT_DIR} --datadir=${DATA_DIR} --model=${MODEL} --id=${RUNID} \
 					 --steps=${STEPS} --batchsize=${BATCHSIZE} --ckptfreq=${CKPT_FREQ} \
@@ -52,6 +61,17 @@ train: ${DATA_DIR}
 .PHONY: convert
 convert: ${DATA_DIR}
 	DATA_DIR=${DATA_DIR} python3 tools/data_tf_converter.py $(DATASET) --del_raw
+
+# the reference's `make distributed` submitted parameter servers and workers to a Sun Grid Engine (Makefile:87-96); here
+# the same number of workers are synchronous RCCL replicas on this node
+.PHONY: distributed
+distributed:
+	$(MAKE) train GPUS=${WORKERS}
+
+# tensorboard on the checkpoint directory (event files are written by ann3depth_amd/summary.py), Makefile:129-131
+.PHONY: tb
+tb:
+	tensorboard --logdir=${CKPT_DIR}
 
 .PHONY: help
 help:
