@@ -564,6 +564,7 @@ struct ReduceParams {
   int M, N, ldc, splitk, act, mode, mask_act; size_t slab;
   int sub_step, sub_ph, sub_pw, outW, outHW; FastDiv div_phw, div_pw;     // BWD_D parity-class row remap
   int vec4;              // plain 16-byte sum (bwd-filter slabs)
+  const float* dbias_ws; float* dbias_out;     // bwd-filter: the [splitk][N] BiasAddGrad slabs ride along, or null
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
 

@@ -155,6 +155,10 @@ __device__ __forceinline__ float slab_sum(const float* ws, size_t slab, int spli
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   const size_t total = (size_t)p.M * p.N;
+  if (p.dbias_out) {       // N sums of `splitk` values: the grid's first threads do them on the side
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.N; i += (size_t)gridDim.x * 256)
+      p.dbias_out[i] = slab_sum(p.dbias_ws, (size_t)p.N, p.splitk, i);
+  }
   if (p.vec4) {   // plain sum of 16-byte columns: bwd-filter slabs (no epilogue, contiguous output)
     typedef float f4 __attribute__((ext_vector_type(4)));
     const size_t nv = total / 4;
@@ -238,7 +242,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   }
   if (rc != A3D_OK) return rc;
   if (plan.splitk > 1) {
-    ReduceParams r;
+    ReduceParams r{};
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
     r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act;
@@ -247,17 +251,11 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     size_t total = (size_t)p.M * p.N;
     unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
+    r.dbias_ws = final_dbias ? p.dbias : nullptr;
+    r.dbias_out = final_dbias;
     clear_stale_error();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
     rc = check_launch("splitk_reduce");
-    if (rc == A3D_OK && final_dbias) {
-      ReduceParams b{};
-      b.ws = p.dbias; b.C = final_dbias; b.M = 1; b.N = p.N; b.ldc = p.N; b.splitk = plan.splitk;
-      b.mode = MODE_BWD_F; b.slab = (size_t)p.N;
-      clear_stale_error();
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, b);
-      rc = check_launch("dbias_reduce");
-    }
   }
   return rc;
 }
