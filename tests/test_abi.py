@@ -38,13 +38,29 @@ def test_errors_are_reported_not_thrown():
     assert rc == -1
 
 
-def test_gemm_code_objects_are_gfx950_mfma():
-    """The shipped library holds gfx950 code with fp32 MFMA instructions (not a host fallback)."""
+def test_gemm_code_objects_are_gfx950_mfma(tmp_path):
+    """The shipped library holds gfx950 code objects whose disassembly carries the matrix-core instructions the
+    design names (fp32 32x32x2 and bf16 32x32x16 MFMA, the LDS-DMA load and the transposing LDS read): it is not a
+    host fallback.  The bundle is extracted from a COPY under tmp_path (llvm-objdump writes next to its input)."""
+    import glob
+    import shutil
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     if not os.path.exists(objdump):
-        return
-    out = subprocess.run([objdump, '--offloading', _lib.LIB_PATH], capture_output=True, text=True).stdout
+        import pytest
+        pytest.skip('llvm-objdump not in this image')
+    copy = shutil.copy(_lib.LIB_PATH, tmp_path / 'liba3d.so')
+    out = subprocess.run([objdump, '--offloading', str(copy)], capture_output=True, text=True, cwd=tmp_path).stdout
     assert 'gfx950' in out
+    objs = glob.glob(str(tmp_path / 'liba3d.so.*gfx950*'))
+    assert objs, 'no gfx950 code object in the offload bundle'
+    seen = set()
+    wanted = ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16', 'ds_read_b64_tr_b16', 'global_load_lds_dwordx4')
+    for o in objs:
+        if os.path.getsize(o) == 0:
+            continue
+        asm = subprocess.run([objdump, '-d', '--mcpu=gfx950', o], capture_output=True, text=True).stdout
+        seen |= {w for w in wanted if w in asm}
+    assert seen == set(wanted), set(wanted) - seen
 
 
 def test_planner_handles_every_layer_shape_on_the_host():
