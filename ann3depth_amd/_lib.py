@@ -3,7 +3,9 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_void_p, POINTER
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'liba3d.so')
+# A3D_LIB points the binding at another build of the same library (tools/bench_layers.py A/B runs); there is still no
+# fallback: a missing file or symbol raises.
+LIB_PATH = os.environ.get('A3D_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'liba3d.so')
 
 
 class A3dError(RuntimeError):

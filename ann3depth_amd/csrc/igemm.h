@@ -19,17 +19,34 @@
 
 namespace a3d {
 
+// In-kernel phase stamps for a separate diagnostic build (make STAMPS=1 -> tools/ab/): where a K-tile iteration spends
+// its cycles.  No stamp executes in the shipped library.
+#ifdef A3D_STAMPS
+#define A3D_STAMP(var)                                                                         \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    unsigned long long t_;                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    var = t_;                                                                                  \
+  } while (0)
+#else
+#define A3D_STAMP(var) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FastDiv {
   uint32_t mul, shr, d;
+  uint32_t id;       // all ones when d <= 1 (the quotient is n itself), else 0: keeps fdiv branch-free
 };
 
 inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
   f.d = d;
-  if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+  f.id = 0;
+  if (d <= 1) { f.mul = 0; f.shr = 0; f.id = 0xffffffffu; return f; }
   uint32_t l = 0;
   while ((1u << l) < d) ++l;                  // l = ceil(log2 d), 1..31
   uint64_t p = 31 + l;
@@ -39,12 +56,12 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 // exact for n < 2^31
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-  return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+  return (__umulhi(n, f.mul) >> f.shr) + (n & f.id);
 }
 
 // Out-of-range tile elements (padding halo, K / M / N tails) are LOADED from this zero line instead of being
 // branched around: the select is one v_cndmask on the address, the load itself is unconditional.
-__device__ __attribute__((aligned(16))) const float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+static __device__ __attribute__((aligned(16))) float g_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -71,6 +88,30 @@ __device__ __forceinline__ void store_vec(float* dst, const float (&in)[VEC]) {
     *reinterpret_cast<f32x2*>(dst) = v;
   } else {
     *dst = in[0];
+  }
+}
+
+// ---- raw buffer loads: out-of-range lanes get kOOB as their offset and the hardware returns zeros for them (no
+//      select on a 64-bit address, no zero line, vmcnt only) ----
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kOOB = 0x80000000u;           // >= every descriptor's num_records (those are clamped to 2^31 - 1)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned long long bytes) {
+  const uint32_t nr = bytes > 0x7fffffffull ? 0x7fffffffu : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)nr, 0x00020000);
+}
+template <int VEC>
+__device__ __forceinline__ void load_vec_buf(__amdgpu_buffer_rsrc_t r, uint32_t off, float (&out)[VEC]) {
+  if constexpr (VEC == 4) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    out[0] = __uint_as_float(v[0]); out[1] = __uint_as_float(v[1]);
+    out[2] = __uint_as_float(v[2]); out[3] = __uint_as_float(v[3]);
+  } else if constexpr (VEC == 2) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    out[0] = __uint_as_float(v[0]); out[1] = __uint_as_float(v[1]);
+  } else {
+    out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
   }
 }
 
@@ -114,6 +155,16 @@ struct IgemmParams {
   // r = tap_r0 + stride*r', s = tap_s0 + stride*s' reach such a pixel, so each class is a stride-1 problem over a
   // sub-sampled pixel grid and a sub-sampled filter.  sub_step == 1: plain launch.
   int sub_step, sub_ph, sub_pw, tap_r0, tap_s0, S_full, outW, outHW;
+  // staging by raw buffer loads (igemm_body): element counts of the two operand tensors (bounds of the descriptors),
+  // and the fast column decode of layers whose gathered channel count is a multiple of BK: a K-tile then lies inside ONE
+  // filter tap, so (r, s, first channel) are wave-uniform.  kperm walks the taps of a channel chunk before moving to the
+  // next chunk (the 25 taps of a 5x5 layer re-read the same few KB of each pixel row: L1/L2-resident) instead of all
+  // channels of a tap first.  nocheck: unpadded forward / bwd-filter gathers never leave the image.
+  unsigned long long a_elems, b_elems;
+  int uni, kperm, cpt, ntaps, nocheck;
+  FastDiv div_cpt, div_taps;
+  int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
+  unsigned long long* stamps;   // diagnostic builds (-DA3D_STAMPS) only: per-wave phase cycle sums; null otherwise
 };
 
 // linear pixel of the (sub-)problem -> pixel index in the full output tensor
@@ -331,6 +382,10 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   float* As = reinterpret_cast<float*>(smem_raw);
   float* Bs = As + 2 * Cfg::A_ELEMS;
   int4* pixtab = reinterpret_cast<int4*>(Bs + 2 * Cfg::B_ELEMS);
+#ifdef A3D_STAMPS
+  unsigned long long t_entry = 0;
+  A3D_STAMP(t_entry);
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -370,36 +425,200 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   const bool do_bias = (MODE == MODE_BWD_F) && p.dbias != nullptr && tile_m == 0 && tid < BN;
   float bsum = 0.f;
 
-  const int a_cq = tid % ATile::CPR;
-  const int b_cq = tid % BTile::CPR;   // BWD_D only
+  // ===== staging: global -> registers by raw buffer loads.  Whatever does not change from K-tile to K-tile is computed
+  // ONCE per lane (row offsets, pixel coordinates, column validity); per tile only the filter tap moves — one scalar
+  // decode when the tap is wave-uniform (p.uni), one per-lane decode otherwise — and the B tiles move by re-basing their
+  // descriptor (scalar).  The previous form recomputed every address per tile with ~75 VALU instructions and several
+  // dependent LDS reads per wave: a third of each wave's time with no MFMA issued (in-kernel stamps).
+  constexpr int A_CPR = ATile::CPR, A_RPP = ATile::RPP, A_NL = ATile::NL;
+  const int a_r0 = tid / A_CPR, a_cq = tid % A_CPR;
+  const bool a_on = !ATile::PARTIAL || a_r0 < Cfg::A_ROWS;
+  constexpr int SGN = TRANSPOSED ? -1 : 1;
+  const int pW = p.W, pld = p.ld;
 
-  // ---- prologue ----
-  if (MODE == MODE_BWD_F) {
+  // image of the tile's first pixel: descriptors are based there, so lane offsets stay far below 2^31
+  auto image_of = [&](int pixel) -> uint32_t {
+    const int px = pixel < p.npix ? pixel : p.npix - 1;
+    return fdiv((uint32_t)px, p.div_phw);
+  };
+  // row table entry: {byte offset of the row's reference pixel from the base image, y0, x0, valid}
+  auto row_entry = [&](int pixel, uint32_t nf) -> int4 {
+    int4 e = make_pix<TRANSPOSED>(p, pixel);
+    e.x = ((e.x - (int)(nf * (uint32_t)p.pHW)) + e.y * pW + e.z) * pld * 4;
+    return e;
+  };
+
+  // ---- A operand ----
+  int a_rowoff[A_NL], a_y0[A_NL], a_x0[A_NL];
+  int a_dy = 0, a_dx = 0, a_coloff = 0;    // BWD_F: this lane's fixed window element
+  bool a_cvalid = true;
+  const float* a_base = p.A;
+  unsigned long long a_bytes = 0;
+  if constexpr (MODE == MODE_BWD_F) {
     // pixel axis is K: tables for tiles kt_begin and kt_begin+1
     if (tid < 2 * Cfg::PIX) {
-      int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
-      pixtab[which * Cfg::PIX + e] = make_pix<false>(p, (kt_begin + which) * BK + e);
+      const int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
+      const int pix0 = (kt_begin + which) * BK;
+      pixtab[which * Cfg::PIX + e] = row_entry(pix0 + e, image_of(pix0));
     }
+    const ColDec d = decode_col(p, m0 + a_cq * AVEC);
+    a_dy = d.r; a_dx = d.s;
+    a_coloff = ((d.r * pW + d.s) * pld + d.c) * 4;
+    a_cvalid = d.valid;
   } else {
-    if (tid < Cfg::PIX) pixtab[tid] = make_pix<TRANSPOSED>(p, m0 + tid);
+    const uint32_t nf = image_of(m0);
+    if (tid < Cfg::PIX) pixtab[tid] = row_entry(m0 + tid, nf);
+    const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pld;
+    a_base = p.A + boff;
+    a_bytes = (p.a_elems - boff) * 4ull;
   }
   __syncthreads();
-
-  ColDec cdec;
-  if (MODE == MODE_BWD_F) cdec = decode_col(p, m0 + a_cq * AVEC);
-
-  auto load_tiles = [&](int kt, int pbuf) {
-    if constexpr (MODE == MODE_BWD_F) {
-      ATile::load(ra, p, pixtab + pbuf * Cfg::PIX, cdec, tid);
-      BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
-    } else {
-      ColDec cd = decode_col(p, kt * BK + a_cq * AVEC);
-      ATile::load(ra, p, pixtab, cd, tid);
-      if constexpr (MODE == MODE_FWD)
-        BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
-      else
-        BTile::load(rb, p, n0, kt * BK + b_cq * BVEC, tid);
+  if constexpr (MODE != MODE_BWD_F) {
+    if (a_on) {
+#pragma unroll
+      for (int j = 0; j < A_NL; ++j) {
+        const int4 pt = pixtab[a_r0 + j * A_RPP];
+        a_rowoff[j] = pt.x + (p.uni ? a_cq * AVEC * 4 : 0);
+        a_y0[j] = pt.w ? pt.y : -(1 << 30);
+        a_x0[j] = pt.z;
+      }
     }
+  }
+
+  // k-tile of iteration index kt: (filter tap, first channel) when the tap is wave-uniform
+  struct TapPos { uint32_t rs, chunk; };
+  auto tap_of = [&](int kt) -> TapPos {
+    // both orders are a handful of scalar operations: computed side by side and selected, no branch in the K loop
+    const uint32_t c1 = fdiv((uint32_t)kt, p.div_taps), r1 = (uint32_t)kt - c1 * (uint32_t)p.ntaps;
+    const uint32_t r2 = fdiv((uint32_t)kt, p.div_cpt), c2 = (uint32_t)kt - r2 * (uint32_t)p.cpt;
+    TapPos t;
+    t.rs = p.kperm ? r1 : r2;
+    t.chunk = p.kperm ? c1 : c2;
+    return t;
+  };
+
+  auto issue_a = [&](int kt, int pbuf, bool live) {
+    if constexpr (MODE == MODE_BWD_F) {
+      const int pix0 = kt * BK;
+      const uint32_t nf = image_of(pix0);
+      const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pld;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.A + boff, live ? (p.a_elems - boff) * 4ull : 0ull);
+      if (!a_on) return;
+      const int4* ptab = pixtab + pbuf * Cfg::PIX;
+#pragma unroll
+      for (int j = 0; j < A_NL; ++j) {
+        const int4 pt = ptab[a_r0 + j * A_RPP];
+        const int y = pt.y + a_dy, x = pt.z + a_dx;
+        const bool ok = a_cvalid & (pt.w != 0) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        load_vec_buf<AVEC>(rs, ok ? (uint32_t)(pt.x + a_coloff) : kOOB, ra[j]);
+      }
+    } else {
+      int dy, dx, coloff;
+      bool cv = true;
+      if (p.uni) {
+        const TapPos t = tap_of(kt);
+        const uint32_t r = fdiv(t.rs, p.div_s), sx = t.rs - r * p.div_s.d;
+        dy = SGN * (int)r; dx = SGN * (int)sx;
+        coloff = ((dy * pW + dx) * pld + (int)t.chunk * BK) * 4;
+      } else {
+        const ColDec d = decode_col(p, kt * BK + a_cq * AVEC);
+        dy = SGN * d.r; dx = SGN * d.s;
+        coloff = ((dy * pW + dx) * pld + d.c) * 4;
+        cv = d.valid;
+      }
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(a_base, live ? a_bytes : 0ull);
+      if (!a_on) return;
+#pragma unroll
+      for (int j = 0; j < A_NL; ++j) {
+        // rows that do not exist carry y0 = INT_MIN/2 and fail the range test like any halo pixel
+        const int y = a_y0[j] + dy, x = a_x0[j] + dx;
+        const bool ok = cv & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        load_vec_buf<AVEC>(rs, ok ? (uint32_t)(a_rowoff[j] + coloff) : kOOB, ra[j]);
+      }
+    }
+  };
+
+  // ---- B operand ----
+  constexpr int B_CPR = BTile::CPR;
+  uint32_t b_voff[BNL];                    // loop-invariant lane offsets (kOOB: outside the tensor's columns / rows)
+  const int b_cq = tid % B_CPR;            // BWD_D
+  if constexpr (MODE == MODE_BWD_D) {
+    const int r0 = tid / B_CPR;
+#pragma unroll
+    for (int j = 0; j < BNL; ++j) {
+      const int row = r0 + j * BTile::RPP;
+      const bool ok = (!BTile::PARTIAL || r0 < Cfg::B_ROWS) && n0 + row < p.N;
+      b_voff[j] = ok ? (uint32_t)((row * p.Cg + b_cq * BVEC) * 4) : kOOB;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < BNL; ++j) {
+      const int idx = tid + j * NT;
+      const int r = idx / B_CPR, cq = idx % B_CPR;
+      const bool ok = (BTile::TOTAL % NT == 0 || idx < BTile::TOTAL) && n0 + cq * BVEC < p.N;   // BVEC = 4: N % 4 == 0
+      b_voff[j] = ok ? (uint32_t)((r * p.ldb + cq * BVEC) * 4) : kOOB;
+    }
+  }
+  auto issue_b = [&](int kt, bool live) {
+    if constexpr (MODE == MODE_BWD_D) {
+      // filter W[rs][cin][cout] read as rows = cin, columns = k = (rs, cout)
+      if (p.uni) {
+        const TapPos t = tap_of(kt);
+        // tap of the (sub-sampled, see sub_step) filter -> tap of the stored filter; the identity for plain launches
+        const uint32_t rp = fdiv(t.rs, p.div_s), sp = t.rs - rp * p.div_s.d;
+        const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
+        const unsigned long long boff = (unsigned long long)rs * (unsigned long long)(p.Cn * p.Cg) +
+                                        (unsigned long long)n0 * p.Cg + t.chunk * BK;
+        const __amdgpu_buffer_rsrc_t rsb = make_rsrc(p.B + boff, live ? (p.b_elems - boff) * 4ull : 0ull);
+#pragma unroll
+        for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsb, b_voff[j], rb[j]);
+      } else {
+        const int kcol = kt * BK + b_cq * BVEC;
+        const bool kvalid = kcol < p.K;
+        const uint32_t k = kvalid ? (uint32_t)kcol : 0u;
+        const uint32_t rs0 = fdiv(k, p.div_c);       // div_c.d == Cout here
+        const int ko = (int)(k - rs0 * p.div_c.d);
+        const uint32_t rp = fdiv(rs0, p.div_s), sp = rs0 - rp * p.div_s.d;
+        const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
+        const uint32_t base = (rs * (uint32_t)(p.Cn * p.Cg) + (uint32_t)n0 * (uint32_t)p.Cg + (uint32_t)ko) * 4u;
+        const __amdgpu_buffer_rsrc_t rsb = make_rsrc(p.B, live ? p.b_elems * 4ull : 0ull);
+#pragma unroll
+        for (int j = 0; j < BNL; ++j)
+          load_vec_buf<BVEC>(rsb, (kvalid && b_voff[j] != kOOB) ? base + (b_voff[j] - (uint32_t)(b_cq * BVEC * 4)) : kOOB, rb[j]);
+      }
+    } else {
+      // plain [K][ldb] tile at rows row0.., columns n0..: the descriptor is re-based (scalar) and ends with the tensor's
+      // row K-1, so rows of the K tail read as zeros
+      int row0 = kt * BK;
+      if (MODE == MODE_FWD && p.uni) {
+        const TapPos t = tap_of(kt);
+        row0 = (int)(t.rs * (uint32_t)p.Cg + t.chunk * BK);
+      }
+      const long long rows = (long long)p.K - row0;
+      const long long rec = rows > 0 ? (rows * p.ldb - n0) * 4ll : 0ll;
+      const __amdgpu_buffer_rsrc_t rsb =
+          make_rsrc(p.B + ((unsigned long long)row0 * (unsigned long long)p.ldb + (unsigned long long)n0),
+                    (live && rec > 0) ? (unsigned long long)rec : 0ull);
+#pragma unroll
+      for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsb, b_voff[j], rb[j]);
+    }
+  };
+
+#ifdef A3D_STAMPS
+  unsigned long long sA = 0, dA = 0;
+#endif
+  auto load_tiles = [&](int kt, int pbuf, bool live) {
+#ifdef A3D_STAMPS
+    unsigned long long t0_;
+    A3D_STAMP(t0_);
+    issue_a(kt, pbuf, live && !(p.dbg & 1));
+    A3D_STAMP(sA);
+    dA += sA - t0_;
+    issue_b(kt, live && !(p.dbg & 2));
+#else
+    issue_a(kt, pbuf, live);
+    issue_b(kt, live);
+#endif
   };
   auto store_tiles = [&](int buf) {
     ATile::store(ra, As + buf * Cfg::A_ELEMS, Cfg::A_LD, tid);
@@ -407,19 +626,30 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   };
 
   if (nkt > 0) {
-    load_tiles(kt_begin, 0);
+    load_tiles(kt_begin, 0, true);
     store_tiles(0);
   }
   __syncthreads();
 
   int cur = 0;
+#ifdef A3D_STAMPS
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0;
+  A3D_STAMP(tbeg);
+#endif
   for (int it = 0; it < nkt; ++it) {
     const int kt = kt_begin + it;
     const bool more = it + 1 < nkt;
-    if (more) load_tiles(kt + 1, (it + 1) & 1);
+    A3D_STAMP(s0);
+    // The staging instructions are few, but issued at priority 0 they queue behind the MFMAs of the three other waves of
+    // this SIMD (stamps: 20-30 cycles per instruction); raised, they slip into the matrix pipe's 64-cycle shadows.
+    if (p.dbg & 4) __builtin_amdgcn_s_setprio(3);
+    load_tiles(kt + 1, (it + 1) & 1, more);      // branch-free: the descriptors of a tile that does not exist hold 0 records
+    __builtin_amdgcn_sched_barrier(0);           // the loads stay here: a whole tile of MFMAs ahead of their first use
+    if (p.dbg & 4) __builtin_amdgcn_s_setprio(0);
+    A3D_STAMP(s1);
     if (MODE == MODE_BWD_F) {
       // table for tile kt+2 goes into the buffer tile kt used (all its loads were issued before the last barrier)
-      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
+      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = row_entry((kt + 2) * BK + tid, image_of((kt + 2) * BK));
     }
     const float* Ac = As + cur * Cfg::A_ELEMS;
     const float* Bc = Bs + cur * Cfg::B_ELEMS;
@@ -462,7 +692,11 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       for (int u = 0; u < BK / 8; ++u) {
         constexpr int LAST = BK / 8 - 1;
         if (u < LAST) read_frags(u + 1, (u + 1) & 1);
-        if (u == LAST && more) store_tiles(cur ^ 1);
+        if (u == LAST) {
+          A3D_STAMP(s2);
+          if (more) store_tiles(cur ^ 1);
+          A3D_STAMP(s3);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -508,7 +742,11 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       }
       // the next tile's global loads were issued before chunk 0; park them in the other LDS buffer ahead of the
       // last chunk's MFMAs so that only the barrier is left at the end of the tile
-      if (u == BK / 8 - 1 && more) store_tiles(cur ^ 1);
+      if (u == BK / 8 - 1) {
+        A3D_STAMP(s2);
+        if (more) store_tiles(cur ^ 1);
+        A3D_STAMP(s3);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -518,9 +756,30 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
     }
     }
+    A3D_STAMP(s4);
     __syncthreads();
+    A3D_STAMP(s5);
+#ifdef A3D_STAMPS
+    d01 += s1 - s0; d12 += s2 - s1; d23 += s3 - s2; d34 += s4 - s3; d45 += s5 - s4;
+#endif
     cur ^= 1;
   }
+#ifdef A3D_STAMPS
+  A3D_STAMP(tend);
+  if (p.stamps && lane == 0) {
+    unsigned long long* o = p.stamps + ((size_t)bid_in * NWAVES + wave) * 16;
+    o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = dA;
+    o[8] = tbeg - t_entry; o[9] = t_entry; o[10] = tend;
+  }
+#define A3D_STAMP_EXIT()                                                                                   \
+  do {                                                                                                     \
+    unsigned long long t_exit_;                                                                            \
+    A3D_STAMP(t_exit_);                                                                                    \
+    if (p.stamps && lane == 0) p.stamps[((size_t)bid_in * NWAVES + wave) * 16 + 11] = t_exit_;              \
+  } while (0)
+#else
+#define A3D_STAMP_EXIT() do { } while (0)
+#endif
 
   // ---- epilogue ----
   float* Cout = p.C;
@@ -561,6 +820,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         }
       }
     }
+    A3D_STAMP_EXIT();
     return;
   }
 #pragma unroll
@@ -594,6 +854,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       }
     }
   }
+  A3D_STAMP_EXIT();
 }
 
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>

@@ -32,6 +32,12 @@ static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
 
+#ifdef A3D_STAMPS
+static unsigned long long* g_stamps = nullptr;
+static unsigned g_stamp_grid = 0;
+static const size_t kStampBytes = (size_t)8 << 20;
+#endif
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
@@ -39,6 +45,9 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
+// A/B switches of the staging fast paths (tools/bench_layers.py); read once
+static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
+static bool env_flag_no_kperm() { static const bool v = env_int("A3D_NO_KPERM", 0) != 0; return v; }
 
 // ---- opt-in launch timing (a3d_timing_*) ----
 struct TimingSlot {
@@ -195,6 +204,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
 }
 
 int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st) {
+  if (mode == MODE_BWD_D && p.stride != 1)      // strided bwd-data always arrives as stride-1 parity classes
+    return set_error(A3D_EINVAL, "igemm: bwd-data launches are stride-1 problems");
   p.splitk = plan.splitk;
   p.ktiles_per_split = plan.ktiles_per_split;
   p.tiles_m = plan.tiles_m;
@@ -209,6 +220,13 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   }
   const unsigned grid = (unsigned)((long)plan.tiles_m * plan.tiles_n * plan.splitk);
   int rc;
+#ifdef A3D_STAMPS
+  if (!g_stamps) (void)hipMalloc(&g_stamps, kStampBytes);
+  (void)hipMemsetAsync(g_stamps, 0, kStampBytes, st);
+  p.stamps = grid * 8ull * 16 * 8 <= kStampBytes ? g_stamps : nullptr;
+  g_stamp_grid = grid;
+#endif
+  p.dbg = env_int("A3D_DBG", 0);
   TimingSlot slot{};
   bool timed = false;
   {
@@ -378,11 +396,37 @@ static void fill_common(IgemmParams& p, const GemmProblem& g) {
   p.sub_step = 1;
 }
 
+// Staging parameters of igemm_body (call after S, Cg, H, W, stride and the paddings are set): operand extents for the
+// buffer descriptors, the wave-uniform tap decode for layers whose gathered channel count is a multiple of BK = 32, and
+// whether the gather can leave the image at all.
+static void fill_staging(IgemmParams& p, int mode, unsigned long long a_elems, unsigned long long b_elems, int taps_r,
+                         int taps_s, int filt_r, int filt_s) {
+  p.a_elems = a_elems;
+  p.b_elems = b_elems;
+  p.ntaps = std::max(1, taps_r * taps_s);
+  p.cpt = std::max(1, p.Cg / 32);
+  p.uni = (mode != MODE_BWD_F) && p.Cg % 32 == 0 && p.K == p.ntaps * p.Cg && !env_flag_no_uni();
+  p.kperm = p.uni && p.ntaps > 1 && p.cpt > 1 && !env_flag_no_kperm();
+  p.div_cpt = make_fastdiv(p.cpt);
+  p.div_taps = make_fastdiv(p.ntaps);
+  // forward-style gathers (FWD, BWD_F) of an unpadded conv whose last window ends inside the image never go out of range
+  p.nocheck = mode != MODE_BWD_D && p.pad_t == 0 && p.pad_l == 0 && filt_r > 0 && filt_s > 0;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
 
 extern "C" {
+
+#ifdef A3D_STAMPS
+// diagnostic build only: copies the last launch's [grid][8 waves][8] phase sums to the host; returns the grid size
+int a3d_debug_stamps(unsigned long long* out, size_t cap_bytes) {
+  (void)hipDeviceSynchronize();
+  if (g_stamps && out) (void)hipMemcpy(out, g_stamps, std::min(cap_bytes, kStampBytes), hipMemcpyDeviceToHost);
+  return (int)g_stamp_grid;
+}
+#endif
 
 int a3d_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_timing_mu);
@@ -481,6 +525,12 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     p.div_phw = make_fastdiv(ph * pw * 4); p.div_pw = make_fastdiv(pw);
     p.ldc = ld_out;
   }
+  {
+    // nocheck needs the LAST window inside the image: rows (ho-1)*stride + r - 1 < h; columns: the last gathered float
+    const bool inside = (d->ho - 1) * d->stride + d->r <= d->h && (d->wo - 1) * d->stride + d->s <= d->w;
+    fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * d->ldx, (unsigned long long)g.K * d->k,
+                 run ? d->r : d->r, run ? 1 : d->s, inside ? d->r : 0, inside ? d->s : 0);
+  }
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
 }
 
@@ -570,6 +620,8 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       p.ldb = 0; p.ldc = d->ldx;
       p.sub_step = d->stride; p.sub_ph = ph; p.sub_pw = pw; p.tap_r0 = c.r0; p.tap_s0 = c.s0; p.S_full = d->s;
       p.outW = d->w; p.outHW = d->h * d->w;
+      fill_staging(p, MODE_BWD_D, (unsigned long long)d->n * d->ho * d->wo * d->ldy,
+                   (unsigned long long)d->r * d->s * d->c * d->k, c.rp, c.sp, 0, 0);
       if (try_multi) {
         p.splitk = 1; p.ktiles_per_split = plan.ktiles_per_split; p.tiles_m = plan.tiles_m; p.tiles_n = plan.tiles_n;
         p.slab = (size_t)p.M * p.N;
@@ -675,6 +727,12 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
   p.ldb = d->ldy; p.ldc = d->k;
+  {
+    const bool inside = (d->ho - 1) * d->stride + d->r <= d->h && (d->wo - 1) * d->stride + d->s <= d->w;
+    fill_staging(p, MODE_BWD_F, (unsigned long long)d->n * d->h * d->w * d->ldx,
+                 (unsigned long long)d->n * d->ho * d->wo * d->ldy, d->r, run ? 1 : d->s, inside ? d->r : 0,
+                 inside ? d->s : 0);
+  }
   rc = launch_igemm(MODE_BWD_F, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
   if (rc != A3D_OK || !run) return rc;
   clear_stale_error();
@@ -714,6 +772,7 @@ int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const flo
   p.npix = m; p.nrsc = k; p.H = 1; p.W = 1; p.ld = k; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1; p.Cg = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(k); p.div_s = make_fastdiv(1);
   p.ldb = n; p.ldc = n;
+  fill_staging(p, MODE_FWD, (unsigned long long)m * k, (unsigned long long)k * n, 1, 1, 1, 1);
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
 }
 
@@ -742,6 +801,8 @@ int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, flo
   p.Cg = n; p.Cn = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(n); p.div_s = make_fastdiv(1);
   p.ldc = k;
+  p.S_full = 1;
+  fill_staging(p, MODE_BWD_D, (unsigned long long)m * n, (unsigned long long)k * n, 1, 1, 0, 0);
   return launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
 }
 
