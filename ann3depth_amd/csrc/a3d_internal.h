@@ -33,7 +33,8 @@ struct GemmPlan {
   int splitk;
   int ktiles_per_split;
   int tiles_m, tiles_n;
-  size_t ws_bytes;   // split-K slabs (0 if splitk == 1)
+  int streamk;       // > 0: stream-K launch of this many blocks (splitk == 1)
+  size_t ws_bytes;   // split-K / stream-K slabs (0 if neither)
 };
 
 struct GemmProblem {

@@ -163,6 +163,15 @@ struct IgemmParams {
   unsigned long long a_elems, b_elems;
   int uni, kperm, cpt, ntaps, nocheck;
   FastDiv div_cpt, div_taps;
+  // stream-K (p.streamk): the (tile, k-tile) iterations, tile-major, are dealt to the blocks in equal contiguous shares
+  // (no tile quantisation: 177 tiles x 4 splits = 708 blocks on 512 slots was a 1.4-round launch).  A block that owns a
+  // whole tile writes it with the fused epilogue; shares that end inside a tile leave their accumulators, in register
+  // order, in slab 2*block (the block's first share) / 2*block + 1 (its last), and igemm_fixup_kernel adds a tile's slabs
+  // in block order = ascending k (deterministic) and applies the epilogue.
+  int streamk;
+  float* sk_ws;                 // [2 * grid][BM * BN] accumulator slabs
+  float* sk_bias;               // [2 * grid][BN] BiasAddGrad partial sums (bwd-filter)
+  FastDiv div_nk;               // k-tiles per tile
   int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
   unsigned long long* stamps;   // diagnostic builds (-DA3D_STAMPS) only: per-wave phase cycle sums; null otherwise
 };
@@ -365,6 +374,81 @@ struct FilterTTile {
   }
 };
 
+// stream-K share of block b of `nblk`: iterations [first, last) of the tile-major (tile, k-tile) order
+__device__ __forceinline__ uint32_t sk_first(uint32_t b, uint32_t nblk, uint32_t total) {
+  return (uint32_t)(((unsigned long long)b * total) / nblk);
+}
+
+// accumulators of one wave <-> slab, register order: 16 bytes per lane, 1 KiB per wave-instruction
+template <int TM, int TN>
+__device__ __forceinline__ void slab_store(float* slab, const f32x16 (&acc)[TM][TN], int wave, int lane) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(slab + ((((size_t)(wave * TM + a) * TN + b) * 4 + q) * 64 + lane) * 4) = v;
+      }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void slab_add(const float* slab, f32x16 (&acc)[TM][TN], int wave, int lane) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + ((((size_t)(wave * TM + a) * TN + b) * 4 + q) * 64 + lane) * 4);
+        acc[a][b][4 * q] += v[0]; acc[a][b][4 * q + 1] += v[1]; acc[a][b][4 * q + 2] += v[2]; acc[a][b][4 * q + 3] += v[3];
+      }
+}
+
+// The plain (non-pooling) epilogue of four accumulator registers (rows row0 .. row0+3 of column col): bias / activation /
+// dropout (FWD), activation gradient and parity-class row remap (BWD_D), or the raw sums of a classic split-K slab.
+template <int MODE>
+__device__ __forceinline__ void store_quad(const IgemmParams& p, const f32x4 q, int row0, int col, float* Cout, int ldc,
+                                           bool partial) {
+  if (col >= p.N) return;
+  float bias = 0.f;
+  if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + i;
+    if (row >= p.M) continue;
+    float val = q[i];
+    const size_t o = (partial || MODE != MODE_BWD_D
+                          ? (size_t)row
+                          : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
+                         ldc + col;
+    if (!partial) {
+      if (MODE == MODE_FWD) {
+        val += bias;
+        if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
+        else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
+        if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
+      } else if (MODE == MODE_BWD_D) {
+        if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
+      }
+    }
+    Cout[o] = val;
+  }
+}
+template <int MODE, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void store_tile(const IgemmParams& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                           int wn, int li, int lh, float* Cout, int ldc, bool partial) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        store_quad<MODE>(p, v, m0 + wm * WM + a * 32 + 8 * q + 4 * lh, n0 + wn * WN + b * 32 + li, Cout, ldc, partial);
+      }
+}
+
 // The whole GEMM of one block: `nwg` blocks work on problem `p`, this one is number `bid_in`.
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
 __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t nwg, const uint32_t bid_in) {
@@ -400,16 +484,31 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tiles_mn = p.tiles_m * p.tiles_n;
-  const int split = bid / tiles_mn;
-  const int tmn = bid - split * tiles_mn;
+  const int nk_total = (p.K + BK - 1) / BK;      // p.ktiles_per_split is in units of this kernel's BK
+  // stream-K share of this block (iterations of the tile-major (tile, k-tile) order)
+  const uint32_t sk_total = (uint32_t)tiles_mn * (uint32_t)nk_total;
+  uint32_t sk_cur = p.streamk ? sk_first(bid, nwg, sk_total) : 0u;
+  const uint32_t sk_end = p.streamk ? sk_first(bid + 1, nwg, sk_total) : 1u;
+  for (int seg = 0; sk_cur < sk_end; ++seg) {      // classic launches: exactly one pass
+  int split = 0, tmn, kt_begin, kt_end;
+  if (p.streamk) {
+    tmn = (int)fdiv(sk_cur, p.div_nk);
+    kt_begin = (int)(sk_cur - (uint32_t)tmn * (uint32_t)nk_total);
+    kt_end = kt_begin + (int)(sk_end - sk_cur);
+    if (kt_end > nk_total) kt_end = nk_total;
+    sk_cur += (uint32_t)(kt_end - kt_begin);
+  } else {
+    split = bid / tiles_mn;
+    tmn = bid - split * tiles_mn;
+    kt_begin = split * p.ktiles_per_split;
+    kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > nk_total) kt_end = nk_total;
+    sk_cur = sk_end;
+  }
   const int tile_m = tmn / p.tiles_n, tile_n = tmn - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int nk_total = (p.K + BK - 1) / BK;      // p.ktiles_per_split is in units of this kernel's BK
-  const int kt_begin = split * p.ktiles_per_split;
-  int kt_end = kt_begin + p.ktiles_per_split;
-  if (kt_end > nk_total) kt_end = nk_total;
   const int nkt = kt_end - kt_begin;
+  if (seg > 0) __syncthreads();                    // the previous share's tiles and row table are dead from here on
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -784,13 +883,17 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   // ---- epilogue ----
   float* Cout = p.C;
   int ldc = p.ldc;
-  const bool partial = p.splitk > 1;
+  const bool partial = !p.streamk && p.splitk > 1;
   if (partial) {
     Cout = p.C + (size_t)split * p.slab;
     ldc = p.N;
   }
-  if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
-  if (MODE == MODE_FWD && p.pool) {      // never split-K (host)
+  if (p.streamk && (kt_begin != 0 || kt_end != nk_total)) {
+    // a share that ends inside the tile: accumulators (and the bias-gradient sums) go to this block's slab as they are
+    const size_t slot = (size_t)2 * bid + (seg > 0 ? 1 : 0);
+    slab_store<TM, TN>(p.sk_ws + slot * (size_t)(BM * BN), acc, wave, lane);
+    if (MODE == MODE_BWD_F && do_bias) p.sk_bias[slot * BN + tid] = bsum;
+  } else if (MODE == MODE_FWD && p.pool) {      // never split (host)
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -820,41 +923,73 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         }
       }
     }
-    A3D_STAMP_EXIT();
-    return;
+  } else {
+    if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
+    store_tile<MODE, TM, TN, Cfg::WM, Cfg::WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial);
   }
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = n0 + wn * Cfg::WN + b * 32 + li;
-      if (col >= p.N) continue;
-      float bias = 0.f;
-      if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        if (row >= p.M) continue;
-        float val = acc[a][b][v];
-        const size_t o = (partial || MODE != MODE_BWD_D
-                              ? (size_t)row
-                              : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
-                             ldc + col;
-        if (!partial) {
-          if (MODE == MODE_FWD) {
-            val += bias;
-            if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
-            else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
-            if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
-          } else if (MODE == MODE_BWD_D) {
-            if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
-          }
-        }
-        Cout[o] = val;
+  }   // shares of this block
+  A3D_STAMP_EXIT();
+}
+
+// Adds the slabs of every tile that more than one block worked on, in block order (= ascending k: the same sum whatever
+// the timing), and applies the epilogue the owning kernel would have applied.  A slab is a sequence of 1-KiB units, one per
+// (wave, accumulator, register quad) of the GEMM kernel; a wave of this kernel owns one unit of one tile, so a tile is
+// finished by BM*BN/256 independent waves (grid.y = groups of four units), each reading 16 bytes per lane per slab with
+// four slabs in flight.
+template <int MODE, int BM, int BN, int WAVES_M, int NWAVES>
+__global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, const uint32_t nblk) {
+  constexpr int WAVES_N = NWAVES / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  constexpr int UNITS = NWAVES * TM * TN * 4;
+  const int lane = threadIdx.x & 63;
+  const int unit = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+  const uint32_t tile = blockIdx.x;
+  const uint32_t nk = p.div_nk.d, total = (uint32_t)(p.tiles_m * p.tiles_n) * nk;
+  const uint32_t t0 = tile * nk, t1 = t0 + nk - 1;        // first and last iteration of the tile
+  uint32_t bf = (uint32_t)(((unsigned long long)t0 * nblk) / total), bl = (uint32_t)(((unsigned long long)t1 * nblk) / total);
+  while (bf + 1 < nblk && sk_first(bf + 1, nblk, total) <= t0) ++bf;
+  while (bl + 1 < nblk && sk_first(bl + 1, nblk, total) <= t1) ++bl;
+  if (bf == bl) return;                                    // one owner: written by the GEMM kernel itself
+  const int tile_m = (int)tile / p.tiles_n, tile_n = (int)tile - tile_m * p.tiles_n;
+  // slab of contributor b (first share of the block if that share starts in this tile, else its last share)
+  auto slot_of = [&](uint32_t b) -> size_t {
+    return (size_t)2 * b + (fdiv(sk_first(b, nblk, total), p.div_nk) == tile ? 0 : 1);
+  };
+  if (unit < UNITS) {
+    const size_t uoff = ((size_t)unit * 64 + lane) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    // contributors in block order; a launch with more blocks than iterations has blocks without work in between
+    auto skip_idle = [&](uint32_t b) -> uint32_t {
+      while (b <= bl && sk_first(b, nblk, total) == sk_first(b + 1, nblk, total)) ++b;
+      return b;
+    };
+    auto slab_of = [&](uint32_t b) -> f32x4 {
+      return *reinterpret_cast<const f32x4*>(p.sk_ws + slot_of(b) * (size_t)(BM * BN) + uoff);
+    };
+    uint32_t b0 = skip_idle(bf);
+    while (b0 <= bl) {
+      const uint32_t b1 = skip_idle(b0 + 1), b2 = b1 <= bl ? skip_idle(b1 + 1) : b1, b3 = b2 <= bl ? skip_idle(b2 + 1) : b2;
+      if (b3 <= bl) {                   // four slabs in flight
+        const f32x4 v0 = slab_of(b0), v1 = slab_of(b1), v2 = slab_of(b2), v3 = slab_of(b3);
+        s += v0; s += v1; s += v2; s += v3;
+        b0 = skip_idle(b3 + 1);
+      } else {
+        s += slab_of(b0);
+        b0 = b1;
       }
     }
+    // unit -> (wave, a, b, q) -> rows / column, as slab_store laid them out
+    const int q = unit & 3, ab = unit >> 2, bb = ab % TN, a = (ab / TN) % TM, wave = ab / (TN * TM);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
+    store_quad<MODE>(p, s, tile_m * BM + wm * WM + a * 32 + 8 * q + 4 * lh, tile_n * BN + wn * WN + bb * 32 + li, p.C,
+                     p.ldc, false);
   }
-  A3D_STAMP_EXIT();
+  if (MODE == MODE_BWD_F && p.dbias != nullptr && tile_m == 0 && blockIdx.y == 0 && (int)threadIdx.x < BN) {
+    static_assert(BN <= 256, "bias sums by the first 256 threads");
+    float bsum = 0.f;
+    for (uint32_t b = bf; b <= bl; ++b)
+      if (sk_first(b, nblk, total) != sk_first(b + 1, nblk, total)) bsum += p.sk_bias[slot_of(b) * BN + threadIdx.x];
+    if (tile_n * BN + (int)threadIdx.x < p.N) p.dbias[tile_n * BN + threadIdx.x] = bsum;
+  }
 }
 
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>

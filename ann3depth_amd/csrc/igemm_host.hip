@@ -15,6 +15,9 @@ int launch_igemm_mode0(int cfg, int avec, int bvec, IgemmParams& p, unsigned gri
 int launch_igemm_mode1(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_fixup_mode0(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
+int launch_fixup_mode1(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
+int launch_fixup_mode2(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
 
 struct TileCfg {
@@ -47,6 +50,7 @@ static int env_int(const char* name, int dflt) {
 }
 // A/B switches of the staging fast paths (tools/bench_layers.py); read once
 static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
+static bool env_flag_no_streamk() { static const bool v = env_int("A3D_NO_STREAMK", 0) != 0; return v; }
 static bool env_flag_no_kperm() { static const bool v = env_int("A3D_NO_KPERM", 0) != 0; return v; }
 
 // ---- opt-in launch timing (a3d_timing_*) ----
@@ -89,6 +93,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   double best_t = 1e300;
   const int nk = std::max(1, (g.K + 31) / 32);
   const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
+  const int force_streamk = env_int("A3D_FORCE_STREAMK", 0);      // tuning aid: stream-K with this many blocks
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
@@ -99,6 +104,10 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
     best.cfg = force_cfg; best.splitk = splitk; best.ktiles_per_split = kps;
     best.tiles_m = (g.M + bm - 1) / bm; best.tiles_n = (g.N + bn - 1) / bn;
     best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+    if (force_streamk > 0 && force_cfg < kFirstGldsCfg && !g.plain) {
+      best.splitk = 1; best.ktiles_per_split = nk; best.streamk = force_streamk;
+      best.ws_bytes = (size_t)2 * force_streamk * ((size_t)bm * bn + bn) * 4;
+    }
     return best;
   }
   // Cost model calibrated on MI355X with tools/sweep_igemm.py (profiles/r01_sweep_igemm.txt): a block progresses at
@@ -142,6 +151,37 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
         best.tiles_m = tm;
         best.tiles_n = tn;
         best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
+        best.streamk = 0;
+      }
+    }
+    // stream-K: equal shares of the (tile, k-tile) iterations for one or two blocks per CU — no tile quantisation, and
+    // at most two partial slabs per block (register-staged kernels only; the pooling forward never splits)
+    if (c < kFirstGldsCfg && !g.plain && !env_flag_no_streamk()) {
+      const long iters = tiles * nk;
+      for (int G = 256; G <= 512; G += 256) {
+        if (force_streamk > 0 && G != 256) continue;
+        const int grid = force_streamk > 0 ? force_streamk : G;
+        if (iters < 4L * grid) continue;
+        const long per = (iters + grid - 1) / grid;
+        // blocks meeting in one tile: their slabs are added one after the other by the fixup, so few tiles with very
+        // long K (bwd-filter of the 3-channel layers, dense layers) stay with classic split-K and its flat reduction
+        const long meet = (nk + per - 1) / per + 1;
+        if (force_streamk <= 0 && (meet > 12 || tiles < 24)) continue;
+        double t = (double)bm * bn * per * 32.0 / (96.5e3 * kCfgs[c].eff) * (grid <= 256 ? 0.62 : 1.0);
+        // ~1.5 slabs per block are written and read back, then the split tiles are written once more
+        const double slabs = std::min<double>(1.5 * grid, 2.0 * tiles) * bm * bn * 4.0;
+        t += 3.0 + 0.4 * meet + (2.0 * slabs + (double)std::min<long>(tiles, grid) * bm * bn * 4.0) / 3.0e6;
+        if (force_streamk > 0) t = 0;
+        if (t < best_t) {
+          best_t = t;
+          best.cfg = c;
+          best.splitk = 1;
+          best.ktiles_per_split = nk;
+          best.tiles_m = tm;
+          best.tiles_n = tn;
+          best.streamk = grid;
+          best.ws_bytes = (size_t)2 * grid * ((size_t)bm * bn + bn) * 4;
+        }
       }
     }
   }
@@ -218,7 +258,16 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     p.C = static_cast<float*>(ws);
     if (p.dbias) p.dbias = static_cast<float*>(ws) + (size_t)plan.splitk * p.slab;   // [splitk][N] after the C slabs
   }
-  const unsigned grid = (unsigned)((long)plan.tiles_m * plan.tiles_n * plan.splitk);
+  unsigned grid = (unsigned)((long)plan.tiles_m * plan.tiles_n * plan.splitk);
+  if (plan.streamk > 0) {
+    if (!ws) return set_error(A3D_EWORKSPACE, "igemm: stream-K needs a workspace");
+    const size_t tile_elems = (size_t)kCfgs[plan.cfg].bm * kCfgs[plan.cfg].bn;
+    p.streamk = 1;
+    p.sk_ws = static_cast<float*>(ws);
+    p.sk_bias = p.sk_ws + (size_t)2 * plan.streamk * tile_elems;
+    p.div_nk = make_fastdiv((uint32_t)std::max(1, (p.K + 31) / 32));
+    grid = (unsigned)plan.streamk;
+  }
   int rc;
 #ifdef A3D_STAMPS
   if (!g_stamps) (void)hipMalloc(&g_stamps, kStampBytes);
@@ -259,6 +308,12 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     g_timing.push_back(slot);
   }
   if (rc != A3D_OK) return rc;
+  if (plan.streamk > 0) {
+    const unsigned tiles = (unsigned)(plan.tiles_m * plan.tiles_n);
+    if (mode == MODE_FWD) return launch_fixup_mode0(plan.cfg, p, tiles, grid, st);
+    if (mode == MODE_BWD_D) return launch_fixup_mode1(plan.cfg, p, tiles, grid, st);
+    return launch_fixup_mode2(plan.cfg, p, tiles, grid, st);
+  }
   if (plan.splitk > 1) {
     ReduceParams r{};
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;

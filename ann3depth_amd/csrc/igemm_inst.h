@@ -57,6 +57,14 @@ static int launch_glds(IgemmParams& p, unsigned grid, hipStream_t st) {
   return check_launch("igemm_glds");
 }
 
+template <int BM, int BN, int WAVES_M, int NWAVES>
+static int launch_fixup_one(IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st) {
+  clear_stale_error();
+  hipLaunchKernelGGL((igemm_fixup_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES>), dim3(tiles, (BM * BN / 256 + 3) / 4), dim3(256),
+                     0, st, p, nblk);
+  return check_launch("igemm_fixup");
+}
+
 #if A3D_MODE == 1
 // multi-problem launch (parity classes of a strided bwd-data): 64x64 4-wave tiles only
 template <int AVEC, int BVEC>
@@ -84,6 +92,17 @@ int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x
 
 #define A3D_CAT_(a, b) a##b
 #define A3D_CAT(a, b) A3D_CAT_(a, b)
+
+// stream-K fixup of a launch made with register-staged config `cfg`
+int A3D_CAT(launch_fixup_mode, A3D_MODE)(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st) {
+  switch (cfg) {
+#define X(i, bm, bn, wm, nw, bk) \
+  case i: return launch_fixup_one<bm, bn, wm, nw>(p, tiles, nblk, st);
+    A3D_CFGS(X)
+#undef X
+  }
+  return set_error(A3D_EINVAL, "igemm fixup: unknown config %d", cfg);
+}
 
 int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
   switch (cfg) {

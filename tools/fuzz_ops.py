@@ -100,9 +100,26 @@ def run_dense():
     return (m, k, n), err
 
 
+def force_plan():
+    """Half of the cases pin a tile config and either a split-K factor or a stream-K grid (the planner's own picks cover
+    only a few of the combinations the kernels support)."""
+    for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK'):
+        os.environ.pop(v, None)
+    u = rng.random()
+    if u < 0.5:
+        return 'auto'
+    os.environ['A3D_FORCE_CFG'] = str(int(rng.integers(0, 11)))
+    if u < 0.75:
+        os.environ['A3D_FORCE_SPLITK'] = str(int(rng.choice([1, 2, 3, 5, 8, 13])))
+        return 'cfg%s sk%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_SPLITK'])
+    os.environ['A3D_FORCE_STREAMK'] = str(int(rng.choice([1, 2, 3, 7, 32, 100, 256, 512, 700])))
+    return 'cfg%s streamk%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_STREAMK'])
+
+
 t_end = time.time() + budget
 count, worst = 0, (0.0, None)
 while time.time() < t_end:
+    forced = force_plan()
     if rng.random() < 0.25:
         case, err = run_dense()
         case = ('dense',) + case
@@ -111,6 +128,7 @@ while time.time() < t_end:
         err = run_conv(*case)
         case = ('conv',) + case
     count += 1
+    case = case + (forced,)
     if not (err <= TOL):
         print('FAIL', case, err, flush=True)
     if err > worst[0]:
