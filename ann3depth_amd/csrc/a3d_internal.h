@@ -49,6 +49,10 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision = 0);
 struct IgemmParams;
 int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st);
 
+// ---- weight-streaming dense kernels for batches of at most 64 rows (dense.hip) ----
+bool dense_dw_applicable(int m, int k, int n);
+int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, hipStream_t st);
+
 // ---- single-output-channel 5x5 stencil (stencil1.hip) ----
 bool stencil1_applicable(const a3d_conv_desc* d);
 size_t stencil1_bwdf_ws_bytes(const a3d_conv_desc* d);

@@ -869,6 +869,10 @@ size_t a3d_dense_bwd_filter_ws_bytes(int m, int k, int n) {
 int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, void* ws,
                          size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_filter: bad dims");
+  if (dense_dw_applicable(m, k, n) && (long)k * n >= (1L << 16) && !env_int("A3D_NO_DENSE_KERNELS", 0)) {      // small batch: stream dw once (dense.hip)
+    A3D_CHECK_ARG(x && dz && dw, "dense_bwd_filter: null tensor");
+    return dense_dw_launch(m, k, n, x, dz, dw, db, static_cast<hipStream_t>(stream));
+  }
   a3d_conv_desc d = dense_desc(m, k, n);
   return a3d_conv2d_bwd_filter(&d, x, dz, dw, db, ws, ws_bytes, stream);
 }

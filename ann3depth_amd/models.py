@@ -98,6 +98,15 @@ class ParamGroup:
         self.beta1_power = self.beta1_power * np.float32(self.beta1)
         self.beta2_power = self.beta2_power * np.float32(self.beta2)
 
+    def frozen(self):
+        """True for the optimizer the reference builds, AdamOptimizer(rate, 0.9, beta2 = 1): alpha = 0, only m moves."""
+        return self.beta2 == 1.0 and float(self.beta2_power) == 1.0
+
+    def advance(self):
+        """The beta-power bookkeeping of one ApplyAdam whose tensor work was fused elsewhere (dense_bwd_filter_adam_tf1)."""
+        self.beta1_power = self.beta1_power * np.float32(self.beta1)
+        self.beta2_power = self.beta2_power * np.float32(self.beta2)
+
     def apply_sgd(self, grad_scale=1.0):
         """tf.train.GradientDescentOptimizer(lr): var -= lr * grad_scale * g."""
         ops.sgd_apply(self.var, self.grad, self.lr * grad_scale)
@@ -107,10 +116,15 @@ class MSDNReplica:
     """One data-parallel replica of the MSDN training graph (src/models.py:203-367) on one GPU."""
 
     def __init__(self, batchsize, device='cuda', params=None, seed=3000, global_step=0, beta2=1.0, reducer=None,
-                 precision='fp32'):
+                 precision='fp32', keep_dense_grads=True):
         """precision: arithmetic of the conv contractions — 'fp32' (exact, the parity default), 'bf16x3' (split
         operands on the bf16 matrix cores, ~1e-5) or 'bf16' (BASELINE config 5).  Tensors stay float32 in HBM; the
         Cin = 3 layers, the dense layers and everything element-wise always compute in fp32."""
+        # keep_dense_grads=False (the training driver and bench.py on one GPU): under the reference's frozen optimizer the
+        # gradient of the two dense kernels (268 MB) goes straight from the matrix cores into ApplyAdam's m slot
+        # (ops.dense_bwd_filter_adam_tf1) and is never written; grad('coarse/dense/...') is then stale.  A data-parallel
+        # replica needs the gradient for its all-reduce and always keeps it.
+        self.keep_dense_grads = keep_dense_grads or reducer is not None or batchsize > 64
         self.precision = precision
         self.B = B = batchsize
         self.device = torch.device(device)
@@ -413,9 +427,18 @@ class MSDNReplica:
         if join:
             self._join()
 
+    def _fused_dense_adam(self):
+        return not self.keep_dense_grads and self.groups['CoarseDense'].frozen()
+
     def _bwd_filter(self, name, x, dz):
         if name in self.d:
             ops.conv2d_bwd_filter(self.d[name], x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
+        elif self._fused_dense_adam():
+            g = self.groups[self.group_of[name + '/kernel']]
+            kw = [g.view(buf, name + '/kernel') for buf in (g.var, g.m, g.v)]
+            kb = [g.view(buf, name + '/bias') for buf in (g.var, g.m, g.v)]
+            ops.dense_bwd_filter_adam_tf1(x, dz, *kw, *kb, g.lr, g.beta1, g.beta2, float(g.beta1_power),
+                                          float(g.beta2_power), 1.0)
         else:
             ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 
@@ -490,9 +513,13 @@ class MSDNReplica:
         if phase == 1:
             gc, gd = self.groups['CoarseConv'], self.groups['CoarseDense']
             if red is None:
+                fused = self._fused_dense_adam()       # decided before the backward: it is what the dense layers ran
                 self.backward_coarse()
                 gc.apply(scale)
-                gd.apply(scale)
+                if fused:
+                    gd.advance()                       # ApplyAdam of coarse/dense/* already happened inside the backward
+                else:
+                    gd.apply(scale)
             else:
                 # dense bucket (268 MB): reduced while the conv backward runs AND, being due only before the next
                 # step's dense_0, while that step's conv forward runs (settle()); conv bucket (15 MB): waited for here
@@ -897,7 +924,8 @@ class _MultiScaleDeepNetwork:
         assert images.pipeline is depths.pipeline, 'inputs and targets must come from the same data.inputs() call'
         self.train = train
         replica = MSDNReplica(images.pipeline.B, device=torch.device('cuda', torch.cuda.current_device()),
-                              seed=self.seed, beta2=self.beta2, reducer=self.reducer, precision=self.precision)
+                              seed=self.seed, beta2=self.beta2, reducer=self.reducer, precision=self.precision,
+                              keep_dense_grads=False)        # one GPU + the reference's optimizer: dW feeds ApplyAdam directly
         if self.reducer is not None:                         # replicas start from rank 0's weights
             for g in replica.groups.values():
                 self.reducer.broadcast(g.var)

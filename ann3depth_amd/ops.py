@@ -211,6 +211,16 @@ def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power
                                          beta1_power, beta2_power, grad_scale, _stream()), 'a3d_adam_apply_tf1')
 
 
+def dense_bwd_filter_adam_tf1(x, dz, var_w, m_w, v_w, var_b, m_b, v_b, lr, beta1, beta2, beta1_power, beta2_power,
+                              grad_scale=1.0):
+    """dense_bwd_filter + ApplyAdam(beta2 = 1) of one dense layer in one pass; the gradient is not materialised."""
+    m, k = x.shape
+    n = dz.shape[1]
+    check(_lib.load().a3d_dense_bwd_filter_adam_tf1(m, k, n, _ptr(x), _ptr(dz), _ptr(var_w), _ptr(m_w), _ptr(v_w),
+                                                    _ptr(var_b), _ptr(m_b), _ptr(v_b), lr, beta1, beta2, beta1_power,
+                                                    beta2_power, grad_scale, _stream()), 'a3d_dense_bwd_filter_adam_tf1')
+
+
 def sgd_apply(var, g, lr):
     """tf.train.GradientDescentOptimizer (src/models.py:198)."""
     check(_lib.load().a3d_sgd_apply(var.numel(), _ptr(var), _ptr(g), lr, _stream()), 'a3d_sgd_apply')

@@ -179,7 +179,8 @@ def main():
     torch.cuda.set_device(device)
     B = args.batch
     reducer = dp.GradReducer() if world > 1 else None
-    net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=args.precision)
+    net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=args.precision,
+                             keep_dense_grads=False)      # as models.msdn builds it for `make train`
     img, dep = synth_batch(B, rank, device)
     masks = keep_masks(B, 8, rank, device)
 
@@ -193,7 +194,7 @@ def main():
                            world, timed_kernels=False)
         extra['fine_phase'] = {'value': round(world * B * args.steps / dtf, 1), 'ms_per_step': round(1e3 * dtf / args.steps, 3)}
     for prec in [p for p in args.also.split(',') if p and p != args.precision]:
-        alt = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=prec)
+        alt = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=prec, keep_dense_grads=False)
         dta, _ = run_phase(alt, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
         extra.setdefault('other_precisions', {})[prec] = {
             'value': round(world * B * args.steps / dta, 1), 'ms_per_step': round(1e3 * dta / args.steps, 3),
@@ -205,7 +206,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.precision, args.precision),
             'data': 'synthetic',
-            'config': {'workload': 'MSDN coarse+fine, batch 32 per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
+            'config': {'workload': f'MSDN coarse+fine, batch {B} per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
                                    'coarse-phase train step (global_step 0): both forwards + both losses, backward of '
                                    'coarse/*, 2x ApplyAdam(beta2=1)',
                        'per_gpu_batch': B, 'global_batch': B * world,

@@ -134,6 +134,18 @@ int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, cons
  * the mask in; the training driver draws it with this kernel. */
 int a3d_dropout_keep_mask(size_t count, uint64_t seed, uint64_t step, float rate, uint8_t* keep, void* stream);
 
+/* dense_bwd_filter and ApplyAdam of one dense layer in ONE pass, for the optimizer the reference actually builds:
+ * AdamOptimizer(rate, 0.9, beta2 = 1) (src/models.py:309) has alpha = 0 and 1 - beta2 = 0, so ApplyAdam moves only the
+ * m slot: m += (g - m)(1 - beta1) with g = grad_scale * x^T dz (kernel) / grad_scale * sum_rows dz (bias; pass the three
+ * bias pointers as NULL to leave the bias alone).  v / var are touched only where a non-finite g or m poisons them,
+ * exactly as a3d_adam_apply_tf1 does.  The gradient itself is never written: single-GPU training only (a data-parallel
+ * replica needs it for the all-reduce and calls a3d_dense_bwd_filter + a3d_adam_apply_tf1).  A3D_EINVAL unless
+ * alpha == 0 and beta2 == 1, and for m > 64.  Replaces compute_gradients + apply_gradients of the coarse/dense layers
+ * (src/models.py:319-330). */
+int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x, const float* dz, float* var_w, float* m_w,
+                                  float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1, float beta2,
+                                  float beta1_power, float beta2_power, float grad_scale, void* stream);
+
 /* tf.train.AdamOptimizer ApplyAdam (src/models.py:309): alpha = lr*sqrt(1-b2p)/(1-b1p);
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= m*alpha/(sqrt(v)+eps).  grad_scale multiplies g first
  * (1/world_size after an all-reduce sum). */

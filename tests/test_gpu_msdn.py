@@ -238,3 +238,27 @@ def test_two_stream_schedule_is_bit_identical(models, monkeypatch, global_step):
                                                                              'coarse': net.coarse.clone()})
     for k in state[0]:
         assert torch.equal(state[0][k], state[1][k]), k
+
+
+def test_msdn_fused_dense_adam_equals_kept_gradients(models):
+    """models.msdn's replica (keep_dense_grads=False: the dense kernels' gradient goes from the matrix cores straight into
+    ApplyAdam's m slot) against the replica that materialises every gradient: two coarse-phase steps, every variable and
+    both Adam slots of every group bit for bit, same losses, same beta powers (src/models.py:319-330)."""
+    B = 2
+    img, dep, keep = synth(B, 1234)
+    params = O.init_params(3000)
+    args = [torch.from_numpy(a).cuda() for a in (img, dep, keep)]
+    nets = [models.MSDNReplica(B, params=params, keep_dense_grads=k) for k in (True, False)]
+    assert nets[0].keep_dense_grads and not nets[1].keep_dense_grads
+    for _ in range(2):
+        outs = [n.step(*args) for n in nets]
+        torch.cuda.synchronize()
+        assert float(outs[0]['coarse_loss']) == float(outs[1]['coarse_loss'])
+    for gname in nets[0].groups:
+        ga, gb = nets[0].groups[gname], nets[1].groups[gname]
+        assert ga.beta1_power == gb.beta1_power and ga.beta2_power == gb.beta2_power
+        for buf in ('var', 'm', 'v'):
+            np.testing.assert_array_equal(getattr(ga, buf).cpu().numpy(), getattr(gb, buf).cpu().numpy(), err_msg=f'{gname}.{buf}')
+    assert float(nets[1].groups['CoarseDense'].m.abs().sum()) > 0          # the fused path did update m
+    # a non-reference beta2 keeps the two-pass path whatever the flag says
+    assert not models.MSDNReplica(B, params=params, beta2=0.999, keep_dense_grads=False)._fused_dense_adam()

@@ -303,6 +303,58 @@ def test_adam_frozen_path_poison_semantics(ops):
     assert np.isnan(ref['w']).sum() == 5 and np.isnan(opt.v['w']).sum() == 5
 
 
+@pytest.mark.parametrize('m,k,n', [(32, 384, 520), (5, 130, 4070), (64, 512, 256), (1, 512, 257)])
+def test_dense_bwd_filter_adam_fused_equals_two_passes(ops, m, k, n):
+    """a3d_dense_bwd_filter_adam_tf1 (gradient never written) against a3d_dense_bwd_filter + a3d_adam_apply_tf1 and the
+    oracle's ApplyAdam, over two steps, with non-finite gradients in both the kernel and the bias: m, v and var must agree
+    bit for bit (same MFMA sum order, same separate fp32 operations), the gradient with torch float64 to fp32 accuracy."""
+    rng = np.random.default_rng(m * 1000 + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    dz = rng.standard_normal((2, m, n)).astype(np.float32)
+    dz[1, 0, 3] = np.inf                       # poisons column 3 of the kernel gradient and bias 3
+    dz[1, m - 1, n - 1] = 2e19                 # finite, but its square is not: poisons through g*g
+    x[m - 1, 0] = 3e19
+    var_w = rng.standard_normal((k, n)).astype(np.float32)
+    var_b = rng.standard_normal(n).astype(np.float32)
+    v_w0 = (rng.random((k, n)) * 0.01).astype(np.float32)
+    scale = 0.5
+    fused = [dev(var_w), torch.zeros((k, n), device='cuda'), dev(v_w0), dev(var_b), torch.zeros(n, device='cuda'),
+             torch.zeros(n, device='cuda')]
+    plain = [t.clone() for t in fused]
+    opt = T.AdamTF1(0.1, 0.9, 1.0)
+    opt.m = {'w': np.zeros((k, n), np.float32), 'b': np.zeros(n, np.float32)}
+    opt.v = {'w': v_w0.copy(), 'b': np.zeros(n, np.float32)}
+    ref = {'w': var_w.copy(), 'b': var_b.copy()}
+    b1p = np.float32(0.9)
+    xd = dev(x)
+    for step in range(2):
+        dzd = dev(dz[step])
+        ops.dense_bwd_filter_adam_tf1(xd, dzd, *fused, 0.1, 0.9, 1.0, float(b1p), 1.0, scale)
+        dw, db = torch.empty((k, n), device='cuda'), torch.empty(n, device='cuda')
+        ops.dense_bwd_filter(xd, dzd, dw, db)
+        ops.adam_apply_tf1(plain[0], plain[1], plain[2], dw, 0.1, 0.9, 1.0, 1e-8, float(b1p), 1.0, scale)
+        ops.adam_apply_tf1(plain[3], plain[4], plain[5], db, 0.1, 0.9, 1.0, 1e-8, float(b1p), 1.0, scale)
+        with np.errstate(invalid='ignore', over='ignore'):
+            opt.apply(ref, {'w': dw.cpu().numpy() * np.float32(scale), 'b': db.cpu().numpy() * np.float32(scale)})
+        b1p = b1p * np.float32(0.9)
+        for a, b in zip(fused, plain):
+            np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+        np.testing.assert_array_equal(fused[1].cpu().numpy(), opt.m['w'])
+        np.testing.assert_array_equal(fused[2].cpu().numpy(), opt.v['w'])
+        np.testing.assert_array_equal(fused[0].cpu().numpy(), ref['w'])
+        np.testing.assert_array_equal(fused[4].cpu().numpy(), opt.m['b'])
+        np.testing.assert_array_equal(fused[3].cpu().numpy(), ref['b'])
+        if step == 0:
+            with np.errstate(invalid='ignore', over='ignore'):
+                want = x.astype(np.float64).T @ dz[0].astype(np.float64)
+                norm = np.abs(x).astype(np.float64).T @ np.abs(dz[0]).astype(np.float64)
+            err = np.abs(dw.cpu().numpy() - want) / norm
+            assert np.nanmax(err[np.isfinite(norm)]) < 1e-6
+    assert np.isnan(ref['w']).any() and np.isnan(ref['b']).any()
+    with pytest.raises(Exception):             # not the frozen optimizer: the fused entry refuses
+        ops.dense_bwd_filter_adam_tf1(xd, dzd, *fused, 0.1, 0.9, 0.999, float(b1p), 0.999, scale)
+
+
 def test_large_problem_plans_without_split(ops):
     """An output larger than the split-K slab budget (DCNF conv2d at batch 16: 1.6 GB) must still get a plan."""
     n = 96
