@@ -114,6 +114,42 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __r
   }
 }
 
+// four channels per thread, 16-byte accesses (c, ldy, lddy multiples of 4; 16-byte aligned tensors)
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_vec4_kernel(const uint8_t* __restrict__ argmax,
+                                                                   const float* __restrict__ y, const float* __restrict__ dy,
+                                                                   float* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                                   int wo, int ldy, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2, c4 = c / 4;
+  const uint32_t total = (uint32_t)n * hc * wc * c4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const uint32_t ch = (i % c4) * 4;
+    uint32_t t = i / c4;
+    const uint32_t q = t % wc;
+    t /= wc;
+    const uint32_t p = t % hc, b = t / hc;
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+    const bool has_r = 2 * p + 1 < (uint32_t)h, has_c = 2 * q + 1 < (uint32_t)w;
+    f32x4 o0 = zero, o1 = zero, o2 = zero, o3 = zero;
+    if (p < (uint32_t)ho && q < (uint32_t)wo) {
+      const size_t win = ((size_t)b * ho + p) * wo + q;
+      const uint32_t a4 = *reinterpret_cast<const uint32_t*>(argmax + win * c + ch);
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(dy + win * lddy + ch);
+      const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + win * ldy + ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t arg = (a4 >> (8 * j)) & 0xffu;
+        const float g = (relu_mask && !(y4[j] > 0.f)) ? 0.f : g4[j];
+        o0[j] = arg == 0 ? g : 0.f; o1[j] = arg == 1 ? g : 0.f; o2[j] = arg == 2 ? g : 0.f; o3[j] = arg == 3 ? g : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + base) = o0;
+    if (has_c) *reinterpret_cast<f32x4*>(dx + base + c) = o1;
+    if (has_r) *reinterpret_cast<f32x4*>(dx + base + (size_t)w * c) = o2;
+    if (has_r && has_c) *reinterpret_cast<f32x4*>(dx + base + (size_t)w * c + c) = o3;
+  }
+}
+
 // ------------------------------------------------------------------ ResizeBilinear (legacy, align_corners=False)
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
                                                      int w, int c, int oh, int ow, float sy, float sx) {
@@ -173,11 +209,15 @@ __device__ __forceinline__ float masked_log(float v) {
   return isnan(l) ? 0.f : l;     // tf.where(tf.is_nan(log), 0, log): -inf is kept
 }
 
-// one block per sample: ws[2b] = sum d^2, ws[2b+1] = sum d
-__global__ __launch_bounds__(256) void silog_sums_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
-                                                         float* __restrict__ ws, int npix) {
+// one block per sample: ws[2b] = sum d^2, ws[2b+1] = sum d; the block that finishes last (ticket in ws[2*nb], which
+// wraps back to 0: nothing to re-initialise between calls) adds the batch up — one launch instead of two.  The per-sample
+// sums cross CUs as write-through stores, drained before the ticket, and are read back past the L1 (MI355X_MICROARCH.md,
+// inter-workgroup visibility).
+__global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                        float* __restrict__ ws, float* __restrict__ loss, int npix, float c) {
   __shared__ float red[2][4];
-  const int b = blockIdx.x;
+  __shared__ unsigned last;
+  const int b = blockIdx.x, nb = gridDim.x;
   const float* o = out + (size_t)b * npix;
   const float* t = tgt + (size_t)b * npix;
   float s2 = 0.f, s1 = 0.f;
@@ -194,20 +234,21 @@ __global__ __launch_bounds__(256) void silog_sums_kernel(const float* __restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    ws[2 * b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    ws[2 * b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    __hip_atomic_store(&ws[2 * b], red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ws[2 * b + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = atomicInc(reinterpret_cast<unsigned*>(ws + 2 * nb), (unsigned)nb - 1u) == (unsigned)nb - 1u;
   }
-}
-
-__global__ __launch_bounds__(64) void silog_final_kernel(const float* __restrict__ ws, float* __restrict__ loss, int b,
-                                                         float c) {
+  __syncthreads();
+  if (!last || threadIdx.x >= 64) return;
   float s = 0.f;
-  for (int i = threadIdx.x; i < b; i += 64) {
-    const float s1 = ws[2 * i + 1];
-    s += ws[2 * i] - c * (s1 * s1);
+  for (int i = threadIdx.x; i < nb; i += 64) {
+    const float a2 = __hip_atomic_load(&ws[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float a1 = __hip_atomic_load(&ws[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += a2 - c * (a1 * a1);
   }
   s = wave_sum(s);
-  if (threadIdx.x == 0) loss[0] = s / (float)b;
+  if (threadIdx.x == 0) loss[0] = s / (float)nb;
 }
 
 __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
@@ -401,12 +442,8 @@ int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, floa
   A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && loss && ws, "silog_fwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   clear_stale_error();
-  hipLaunchKernelGGL(silog_sums_kernel, dim3(b), dim3(256), 0, st, out, tgt, ws, npix);
-  int rc = check_launch("silog_sums");
-  if (rc != A3D_OK) return rc;
-  clear_stale_error();
-  hipLaunchKernelGGL(silog_final_kernel, dim3(1), dim3(64), 0, st, ws, loss, b, kSilogC);
-  return check_launch("silog_final");
+  hipLaunchKernelGGL(silog_fwd_kernel, dim3(b), dim3(256), 0, st, out, tgt, ws, loss, npix, kSilogC);
+  return check_launch("silog_fwd");
 }
 
 int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,
@@ -463,6 +500,14 @@ int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, co
   A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && argmax && y && dy && dx && ldy >= c && lddy >= c,
                 "maxpool_bwd_idx: bad arguments");
   const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(argmax) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) |
+                       reinterpret_cast<uintptr_t>(dx);
+  if (c % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (al & 15) == 0 && total / 4 < (1u << 31)) {
+    clear_stale_error();
+    hipLaunchKernelGGL(maxpool_bwd_idx_vec4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       argmax, y, dy, dx, n, h, w, c, h / 2, w / 2, ldy, lddy, relu_mask);
+    return check_launch("maxpool_bwd_idx_vec4");
+  }
   clear_stale_error();
   hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      argmax, y, dy, dx, n, h, w, c, h / 2, w / 2, ldy, lddy, relu_mask);

@@ -187,7 +187,7 @@ class MSDNReplica:
         self.a1 = torch.empty((B, 13, 18, 256), dtype=torch.uint8, device=dev)
         self.af1 = torch.empty((B, OUT_H, OUT_W, 63), dtype=torch.uint8, device=dev)
         self.pooled_fwd = None            # which network ran conv + pool fused in the last forward
-        self.ws_c = buf(2 * B); self.ws_f = buf(2 * B)
+        self.ws_c = torch.zeros(2 * B + 1, device=dev); self.ws_f = torch.zeros(2 * B + 1, device=dev)   # + arrival ticket
         # gradients wrt pre-activations
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
         self.dc4 = buf(B, 6, 8, 256); self.dc3 = buf(B, 13, 18, 384); self.dc2 = buf(B, 13, 18, 384)

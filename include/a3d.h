@@ -123,7 +123,8 @@ int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, 
 /* tf.extract_image_patches(k x k, stride, SAME) + reshape (src/models.py:53-59): y [n*ph*pw, k, k, c]. */
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream);
 
-/* Scale-invariant log loss (src/models.py:255-275).  out/tgt [b, npix]; loss: 1 float. ws: b*2 floats. */
+/* Scale-invariant log loss (src/models.py:255-275).  out/tgt [b, npix]; loss: 1 float.  ws: b*2 + 1 floats; the last
+ * word must be zero before the FIRST call and is zero again after every call (arrival ticket of the single launch). */
 int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, float* loss, float* ws, void* stream);
 /* d loss / d out, using the per-sample sums left in ws by the forward call. */
 int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,

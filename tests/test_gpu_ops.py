@@ -236,7 +236,7 @@ def test_silog_loss(ops):
     o[0, 0] = -1e-8                                                          # log(0) = -inf stays: non-finite loss
     od, td = dev(o), dev(t)
     loss = torch.empty(1, device='cuda')
-    ws = torch.empty(2 * b, device='cuda')
+    ws = torch.zeros(2 * b + 1, device='cuda')      # per-sample sums + the arrival ticket (zero before the first call)
     dout = torch.empty_like(od)
     ops.silog_loss_fwd(od, td, loss, ws)
     assert not np.isfinite(loss.item())
@@ -252,6 +252,10 @@ def test_silog_loss(ops):
     g = dout.cpu().numpy()
     assert rel_l2(g, g_ref) < 1e-5
     assert (g[o < -1e-8] == 0).all()
+    for _ in range(3):                              # the ticket wraps back to zero: repeated calls give the same loss
+        ops.silog_loss_fwd(od, td, loss, ws)
+        assert abs(loss.item() - ref) < 2e-6 * abs(ref)
+    assert ws[2 * b].view(torch.int32).item() == 0
 
 
 @pytest.mark.parametrize('beta2', [1.0, 0.999])

@@ -1,0 +1,37 @@
+"""Compact re-fit sweep: hot MSDN layers x direction x {tile config} x a few split / stream-K choices."""
+import os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ann3depth_amd import ops
+from tools.sweep_igemm import LAYERS, CFGS, timeit
+B = 32
+only = sys.argv[1:] or ['conv2d_1', 'conv2d_2', 'conv2d_3', 'conv2d_4', 'fine2', 'conv2d_0', 'fine1']
+def clear():
+    for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK'):
+        os.environ.pop(v, None)
+for name, h, w, c, k, ks, st, pad in LAYERS:
+    if name not in only: continue
+    d = ops.conv_desc(B, h, w, c, k, ks, ks, st, pad)
+    x = torch.randn((B, h, w, c), device='cuda'); wt = torch.randn((ks, ks, c, k), device='cuda') * 0.01
+    bias = torch.zeros(k, device='cuda'); y = torch.empty((B, d.ho, d.wo, k), device='cuda'); dz = torch.randn_like(y)
+    dx = torch.empty_like(x); dw = torch.empty_like(wt); db = torch.empty(k, device='cuda')
+    flops = 2.0 * B * d.ho * d.wo * k * ks * ks * c
+    modes = {'fwd': lambda: ops.conv2d_fwd(d, x, wt, bias, y, 'relu'), 'bwd_f': lambda: ops.conv2d_bwd_filter(d, x, dz, dw, db)}
+    if c > 3: modes['bwd_d'] = lambda: ops.conv2d_bwd_data(d, dz, wt, dx, relu_mask=x)
+    for mode, fn in modes.items():
+        clear(); t_auto = timeit(fn)
+        res = []
+        for ci in (1, 4, 7, 8, 9, 10):
+            for kind, vals in (('sk', (1, 2, 3, 4, 6, 8, 13, 16, 32, 64, 128)), ('st', (256, 512))):
+                for v in vals:
+                    clear(); os.environ['A3D_FORCE_CFG'] = str(ci)
+                    if kind == 'sk': os.environ['A3D_FORCE_SPLITK'] = str(v)
+                    else:
+                        if ci >= 9: continue
+                        os.environ['A3D_FORCE_STREAMK'] = str(v)
+                    try: t = timeit(fn, 3)
+                    except Exception: continue
+                    res.append((t, CFGS[ci], kind + str(v)))
+        res.sort()
+        print(f'{name:9s} {mode:6s} auto {t_auto:7.1f}us {flops / t_auto / 1e6:5.0f}TF || ' + ' | '.join(f'{cn} {kv} {t:.0f}' for t, cn, kv in res[:7]), flush=True)
+clear()
