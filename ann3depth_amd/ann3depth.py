@@ -111,7 +111,8 @@ class Session:
     pipeline runs dry."""
 
     def __init__(self, train_op, checkpoint_dir, last_step, stop_at_signal, save_checkpoint_secs, save_summaries_steps,
-                 trace_every, logger, world=1, tf_checkpoints=False):
+                 trace_every, logger, world=1, tf_checkpoints=False, keep_checkpoints=5):
+        self.keep_checkpoints = keep_checkpoints          # tf.train.Saver(max_to_keep=5), the Saver default
         self.op, self.dir, self.last_step, self.sig = train_op, checkpoint_dir, last_step, stop_at_signal
         self.ckpt_secs, self.sum_steps, self.trace_every = save_checkpoint_secs, save_summaries_steps, trace_every
         self.log, self.world = logger, world
@@ -162,7 +163,17 @@ class Session:
         step = rep.global_step
         # tfhelper.TraceHook (src/tfhelper.py:192-249): trace the first step and every `trace_every`-th global step
         self.trace_next = bool(self.trace_every) and (step + 1) % self.trace_every == 0
-        if self.sig.signal_received:                                     # StopAtSignalHook.after_run
+        if self.world > 1:
+            # The replicas decide TOGETHER (dp.GradReducer.agree): a signal reaches the ranks at different steps, and
+            # the next step's all-reduces need everyone.  The agreed value is the signal number (exit code of every
+            # rank, src/ann3depth.py:129), or 1 when a rank's input has no batch left for the next step.
+            dry = getattr(train_op, 'end', None) is not None and train_op.end[0] <= train_op.k
+            agreed = rep.reducer.agree(self.sig.signal_received or (1 if dry else 0))
+            if agreed:
+                self.stop = True
+                if agreed > 1 and not self.sig.signal_received:
+                    self.sig.signal_received = agreed
+        elif self.sig.signal_received:                                   # StopAtSignalHook.after_run
             self.stop = True
         if self.sum_steps and step % self.sum_steps == 0:
             now = time.time()
@@ -199,16 +210,41 @@ class Session:
     def save(self):
         rep = self.op.replica
         torch.cuda.synchronize()
-        path = os.path.join(self.dir, f'model.ckpt-{rep.global_step}.pt')
+        prefix = f'model.ckpt-{rep.global_step}'
+        path = os.path.join(self.dir, prefix + '.pt')
         tmp = path + '.tmp'
         torch.save({k: v.detach().cpu() for k, v in rep.state_dict().items()}, tmp)
         os.replace(tmp, path)
         if self.tf_checkpoints:                               # the same state as a TensorFlow V2 checkpoint
-            tfckpt.write_bundle(os.path.join(self.dir, f'model.ckpt-{rep.global_step}'), rep.tf_variables())
-        with open(os.path.join(self.dir, 'checkpoint'), 'w') as f:
-            f.write(f'model_checkpoint_path: "{os.path.basename(path)}"\n')
+            tfckpt.write_bundle(os.path.join(self.dir, prefix), rep.tf_variables())
+        # CheckpointState as tf.train.Saver writes it: with --tf-checkpoints the entries are bundle prefixes, so
+        # tf.train.latest_checkpoint finds them (latest_checkpoint() below prefers '<prefix>.pt' when it exists)
+        kept = [n for n in self._kept_checkpoints() if n != prefix] + [prefix]
+        for old in kept[:-self.keep_checkpoints] if self.keep_checkpoints else []:
+            for f in os.listdir(self.dir):
+                if f == old + '.pt' or f == old + '.index' or f.startswith(old + '.data-'):
+                    os.remove(os.path.join(self.dir, f))
+        kept = kept[-self.keep_checkpoints:] if self.keep_checkpoints else kept
+        entry = (lambda n: n) if self.tf_checkpoints else (lambda n: n + '.pt')
+        tmp = os.path.join(self.dir, 'checkpoint.tmp')
+        with open(tmp, 'w') as f:
+            f.write(f'model_checkpoint_path: "{entry(prefix)}"\n')
+            for n in kept:
+                f.write(f'all_model_checkpoint_paths: "{entry(n)}"\n')
+        os.replace(tmp, os.path.join(self.dir, 'checkpoint'))
         self.t_last_ckpt = time.time()
         self.log.info(f'Saved checkpoint {path}')
+
+    def _kept_checkpoints(self):
+        """Checkpoint prefixes of this directory, oldest first (by global step)."""
+        steps = set()
+        for f in os.listdir(self.dir):
+            if f.startswith('model.ckpt-') and (f.endswith('.pt') or f.endswith('.index')):
+                try:
+                    steps.add(int(f[len('model.ckpt-'):].rsplit('.', 1)[0]))
+                except ValueError:
+                    pass
+        return [f'model.ckpt-{s_}' for s_ in sorted(steps)]
 
     def __exit__(self, exc_type, exc, tb):
         self.op.pipeline.close()
@@ -229,6 +265,8 @@ def latest_checkpoint(ckptdir):
         line = f.readline()
     name = line.split('"')[1] if '"' in line else ''
     path = name if os.path.isabs(name) else os.path.join(ckptdir, name)
+    if name and not name.endswith('.pt') and os.path.exists(path + '.pt'):
+        return path + '.pt'                                           # our own full state beside a bundle of the same step
     if name and (os.path.exists(path) or tfckpt.is_bundle(path)):    # ours (.pt file) or TensorFlow's (bundle prefix)
         return path
     return None

@@ -42,6 +42,20 @@ class GradReducer:
     def broadcast(self, tensor, src=0):
         dist.broadcast(tensor, src, group=self.group)
 
+    def agree(self, value):
+        """MAX of an integer over all ranks, on the host (a gloo control group beside the RCCL data group): the collective
+        stop decision of the training loop.  Every step queues synchronous gradient all-reduces, so a rank that left the
+        loop on its own (its signal handler fired, its input ran dry) would leave the others waiting in step k+1's
+        collective until the watchdog kills them; with this, all ranks leave after the same global step."""
+        if self.world_size == 1:
+            return int(value)
+        if not hasattr(self, '_control'):
+            backend = dist.get_backend(self.group)
+            self._control = self.group if backend == 'gloo' else dist.new_group(backend='gloo')
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._control)
+        return int(t.item())
+
 
 def init_from_env(backend=None):
     """Process-group setup from the launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables.

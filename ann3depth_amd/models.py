@@ -214,9 +214,10 @@ class MSDNReplica:
         """Finish what step() left in flight across the step boundary (the CoarseDense all-reduce and its ApplyAdam).
         Every accessor below and the next forward call it; call it yourself before touching `groups[...]` directly."""
         if self._deferred is not None:
-            work, group, scale = self._deferred
+            works, group, scale = self._deferred
             self._deferred = None
-            self.reducer.wait(work)
+            for work in works:
+                self.reducer.wait(work)
             group.apply(scale)
 
     def load_params(self, params):
@@ -443,11 +444,13 @@ class MSDNReplica:
             ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
-    def backward_coarse(self, after_dense=None, after_conv2=None):
+    def backward_coarse(self, after_dense=None, after_conv2=None, after_dense1=None):
         B = self.B
         ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1))
         n = 'coarse/dense/dense_1'
         self._bwd_filter(n, self.drop, self.dz1)
+        if after_dense1 is not None:
+            after_dense1()         # dense_1's gradient (67 MB) is complete: first piece of the dense bucket
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
         ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
         n = 'coarse/dense/dense_0'
@@ -528,13 +531,20 @@ class MSDNReplica:
                 # the 2.6 MB head is reduced on the critical path
                 handle, tail = [], []
                 cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
-                self.backward_coarse(after_dense=lambda: handle.append(red.start(gd.grad)),
+                # dense bucket in backward production order: dense_1 (67 MB) leaves as soon as its filter
+                # gradient exists, dense_0 (201 MB) in three pieces after its own — four collectives of 50-67 MB pipeline
+                # over the xGMI links where one 268 MB ring would serialise behind its own reduce-scatter
+                d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
+                third = -(-(d1 // 3) // ParamGroup.ALIGN) * ParamGroup.ALIGN
+                pieces0 = [(0, third), (third, 2 * third), (2 * third, d1)]
+                self.backward_coarse(after_dense1=lambda: handle.append(red.start(gd.grad[d1:])),
+                                     after_dense=lambda: handle.extend(red.start(gd.grad[a:b]) for a, b in pieces0),
                                      after_conv2=lambda: tail.append(red.start(gc.grad[cut:])))
                 head = red.start(gc.grad[:cut])
                 red.wait(tail[0])
                 red.wait(head)
                 gc.apply(scale)
-                self._deferred = (handle[0], gd, scale)
+                self._deferred = (handle, gd, scale)
         elif phase == 2:
             ga, gb = self.groups['FineA'], self.groups['FineB']
             self.backward_fine()

@@ -154,6 +154,40 @@ def cpu_baseline(seconds_budget=25.0):
                       f'{threads} OpenBLAS threads on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
 
 
+def comm_report(net, img, dep, masks, args, lib, world, dt):
+    """N > 1 only: how long each gradient bucket's RCCL all-reduce takes on its own (the 283 MB of src/ann3depth.py:77-92's
+    parameter-server traffic, in the pieces MSDNReplica.step sends them), and how much communication the step does NOT
+    hide: ms/step with the reducer minus ms/step of the same replica without one (same kernels, no collectives)."""
+    import torch.distributed as dist
+    from ann3depth_amd import models
+    gd, gc = net.groups['CoarseDense'], net.groups['CoarseConv']
+    d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
+    cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
+    buckets = {'dense_1': gd.grad[d1:], 'dense_0_piece': gd.grad[:d1 // 3], 'conv_tail': gc.grad[cut:],
+               'conv_head': gc.grad[:cut]}
+    times = {}
+    for name, buf in buckets.items():
+        scratch = buf.clone()
+        for _ in range(2):
+            dist.all_reduce(scratch)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(scratch)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / 5], device=img.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times[name] = {'ms': round(1e3 * float(t.item()), 3), 'mbytes': round(scratch.numel() * 4 / 1e6, 1)}
+        del scratch
+    solo = models.MSDNReplica(net.B, device=img.device, seed=3000, reducer=None, precision=args.precision)
+    n = max(3, args.steps // 2)
+    dts, _ = run_phase(solo, img, dep, masks, n, 2, 0, lib, world, timed_kernels=False)
+    return {'rccl_ranks': world, 'allreduce_ms': times,
+            'ms_per_step_without_comm': round(1e3 * dts / n, 3),
+            'exposed_comm_ms': round(1e3 * (dt / args.steps - dts / n), 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,6 +234,9 @@ def main():
             'value': round(world * B * args.steps / dta, 1), 'ms_per_step': round(1e3 * dta / args.steps, 3),
             'note': 'conv contractions on the bf16 matrix cores; NOT the headline: parity is stated for fp32'}
         del alt
+    comm = {}
+    if world > 1:
+        comm = comm_report(net, img, dep, masks, args, lib, world, dt)
     if rank == 0:
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
@@ -215,6 +252,7 @@ def main():
             'igemm_kernels': table,
         }
         line.update(extra)
+        line.update(comm)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

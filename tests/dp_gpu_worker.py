@@ -1,5 +1,7 @@
-"""Rank body of tests/test_gpu_dp.py: two ranks share cuda:0 and reduce over gloo (RCCL refuses two ranks on one
-device; the reducer code path — async bucket all-reduce, finish, 1/world folded into ApplyAdam — is the same)."""
+"""Rank body of tests/test_gpu_dp.py and tests/test_gpu_rccl_multi.py.  On the one-GPU test box two ranks share cuda:0 and
+reduce over gloo (RCCL refuses two ranks on one device; the reducer code path — async bucket all-reduces in production
+order, the dense bucket deferred across the step boundary, 1/world folded into ApplyAdam — is the same); on a box with at
+least two GPUs the same body runs one rank per device over RCCL (A3D_DIST_BACKEND=nccl)."""
 import os
 import sys
 
@@ -15,7 +17,7 @@ from ann3depth_amd import dp, models          # noqa: E402
 
 def main(out_path):
     rank, local_rank, world = dp.init_from_env()
-    assert world == 2 and dist.get_backend() == 'gloo'
+    assert world == 2 and dist.get_backend() == os.environ.get('A3D_DIST_BACKEND', 'gloo')
     B = 2
     rng = np.random.default_rng(99)
     img = (rng.integers(0, 256, (world * B, 96, 128, 3)) / 255).astype(np.float32)
@@ -39,6 +41,8 @@ def main(out_path):
             local = solo.groups[gn].grad.clone()
             dist.all_reduce(local)                                        # sum of both ranks' local gradients
             ok &= bool(torch.equal(net.groups[gn].grad, local))           # the bucket holds exactly that sum
+            if not ok:
+                print('bucket sum check failed', gn, gstep, flush=True)
             m_expect = local * (1.0 / world) * np.float32(1 - np.float32(0.9))
             err = (net.groups[gn].m - m_expect).abs().max() / m_expect.abs().max()
             ok &= bool(err < 1e-6)                                         # ApplyAdam saw the mean gradient
@@ -46,7 +50,23 @@ def main(out_path):
             other = net.groups[gn].m.clone()
             dist.broadcast(other, 0)
             ok &= bool(torch.equal(other, net.groups[gn].m))              # replicas stay bit-identical
-    flag = torch.tensor([int(ok)])
+    # N ranks == one rank on the concatenated batch: the activations of the big replica's forward, sliced
+    # per rank, are what each rank computed (same kernels, same per-sample arithmetic), and its gradient of the GLOBAL
+    # batch mean is the all-reduced sum / world.  The loss gradient ~ 1/(o + 1e-8) makes this an fp32-conditioning
+    # check, not a bit-level one (tests/test_gpu_msdn.py), hence the loose bound.
+    big = models.MSDNReplica(world * B, seed=3000, global_step=0)
+    big.step(cu(img), cu(dep), cu(keep, torch.uint8))
+    net = models.MSDNReplica(B, seed=3000, global_step=0, reducer=dp.GradReducer())
+    net.step(ti, td, tk)
+    net.settle()
+    torch.cuda.synchronize()
+    ok &= bool(((net.coarse - big.coarse[sl]).norm() / big.coarse[sl].norm()) < 1e-5)   # (tile plans differ with the batch)
+    for gn in ('CoarseDense', 'CoarseConv'):
+        a, b = net.groups[gn].grad * (1.0 / world), big.groups[gn].grad
+        ok &= bool(((a - b).norm() / b.norm()) < 3e-2)
+        if not ok:
+            print('concat-batch check failed', gn, float((a - b).norm() / b.norm()), flush=True)
+    flag = torch.tensor([int(ok)], device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         open(out_path, 'w').write(str(int(flag.item())))

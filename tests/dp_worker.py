@@ -51,6 +51,25 @@ def main(out_path):
         rel = lambda x, y: float(np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y))
         with open(out_path, 'w') as f:
             f.write(f'{rel(dense.numpy(), d2)} {rel(conv.numpy(), c2)}\n')
+    # collective stop decision (dp.GradReducer.agree): SIGUSR1 reaches rank 1 only, during its third "step"; both ranks
+    # must leave the loop after the same step with the signal number as the agreed value
+    import signal
+    got = {'sig': 0}
+    signal.signal(signal.SIGUSR1, lambda s, f: got.__setitem__('sig', s))
+    steps = 0
+    while True:
+        t = torch.ones(4)
+        torch.distributed.all_reduce(t)            # the step's gradient all-reduce: needs every rank
+        steps += 1
+        if rank == 1 and steps == 3:
+            os.kill(os.getpid(), signal.SIGUSR1)
+        agreed = red.agree(got['sig'])
+        if agreed:
+            break
+        assert steps < 50
+    assert agreed == signal.SIGUSR1 and steps == 3, (agreed, steps)
+    with open(out_path + f'.stop{rank}', 'w') as f:
+        f.write(f'{steps} {agreed}\n')
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -28,3 +28,6 @@ def test_two_rank_allreduce_equals_big_batch(tmp_path):
         assert p.wait(timeout=600) == 0
     e_dense, e_conv = (float(v) for v in open(out).read().split())
     assert e_dense < 1e-5 and e_conv < 1e-5
+    # the stop decision was collective: both ranks left after step 3 although only rank 1 was signalled
+    import signal
+    assert open(out + '.stop0').read() == open(out + '.stop1').read() == f'3 {int(signal.SIGUSR1)}\n'

@@ -70,3 +70,73 @@ def test_make_train_two_replicas(tmp_path, model, batch, steps):
     else:
         assert 'unary/unary_layers/conv2d/kernel' in sd and 'pairwise/pairwise_layers/dense/kernel' in sd
     assert not os.path.exists(str(tmp_path / 'unused'))                  # only the chief writes
+
+
+def test_signal_to_one_replica_stops_both(tmp_path):
+    """SIGUSR1 delivered to ONE rank of a two-replica `make train`.  The stop decision is collective
+    (dp.GradReducer.agree), so both ranks leave after the same global step, the chief writes the final checkpoint, and both
+    exit with the signal number (src/ann3depth.py:129) instead of hanging in the next step's all-reduce."""
+    import signal
+    import time
+
+    import numpy as np
+    import torch
+    from ann3depth_amd import tfrecord
+    root = str(tmp_path / 'data')
+    rng = np.random.default_rng(1)
+    os.makedirs(os.path.join(root, 'nyu'))
+    with tfrecord.TFRecordWriter(os.path.join(root, 'nyu', 'train.tfrecords')) as w:
+        for _ in range(32):
+            w.write_example(rng.random((48, 64, 3)).astype(np.float32) - np.float32(.5),
+                            rng.random((6, 8, 1)).astype(np.float32) - np.float32(.5))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ck = str(tmp_path / 'ckpt')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo', PYTHONPATH=os.path.dirname(HERE))
+        procs.append(subprocess.Popen(
+            [sys.executable, '-m', 'ann3depth_amd.ann3depth', '--model', 'msdn', '--batchsize', '2', '--steps', '100000000',
+             '--ckptdir', ck if rank == 0 else str(tmp_path / 'unused'), '--datadir', root, '--sumfreq', '1',
+             '--job-name', 'worker', '--timeout', '600', 'nyu'], env=env, cwd=os.path.dirname(HERE)))
+    d = os.path.join(ck, 'msdn')
+    deadline = time.time() + 240
+    while time.time() < deadline:                   # wait until training is under way (summaries appear every step)
+        if os.path.exists(os.path.join(d, 'summaries.jsonl')) and os.path.getsize(os.path.join(d, 'summaries.jsonl')) > 0:
+            break
+        assert all(p.poll() is None for p in procs), 'a replica died before training started'
+        time.sleep(0.5)
+    time.sleep(1.0)
+    procs[1].send_signal(signal.SIGUSR1)            # the NON-chief replica only
+    for p in procs:
+        assert p.wait(timeout=120) == signal.SIGUSR1
+    last = [l for l in open(os.path.join(d, 'checkpoint')) if l.startswith('model_checkpoint_path')][0].split('"')[1]
+    sd = torch.load(os.path.join(d, last))
+    assert int(sd['global_step']) >= 1
+
+
+def test_bench_two_ranks_reports_comm_fields():
+    """bench.py --gpus 2 the way the driver launches it, here with both ranks on the one GPU over gloo: the line carries the
+    rank count, the per-bucket all-reduce times and the exposed communication time (tests/test_gpu_rccl_multi.py runs the
+    same over RCCL when two devices exist)."""
+    import json
+    root = os.path.dirname(HERE)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, A3D_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+                        '--warmup', '1', '--batch', '4', '--no-fine', '--also', ''], capture_output=True, text=True, env=env,
+                       cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['config']['per_gpu_batch'] == 4
+    assert 'batch 4 per GPU' in line['config']['workload']
+    assert set(line['allreduce_ms']) == {'dense_1', 'dense_0_piece', 'conv_tail', 'conv_head'}
+    assert all(v['ms'] > 0 for v in line['allreduce_ms'].values())
+    assert line['exposed_comm_ms'] is not None and line['ms_per_step_without_comm'] > 0

@@ -36,7 +36,7 @@ def test_step_with_rccl_reducer_world1():
                 g.m.zero_()
                 g.beta1_power = g.beta1_power * 0 + 0.9
             net.step(img, dep, keep)
-            assert len(red.pending) == 1                     # CoarseDense rides across the step boundary
+            assert len(red.pending) == 4                     # CoarseDense (dense_1 + three pieces of dense_0) rides across the step boundary
         net.settle()
         torch.cuda.synchronize()
         assert red.pending == []
