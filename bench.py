@@ -154,6 +154,45 @@ def cpu_baseline(seconds_budget=25.0):
                       f'{threads} OpenBLAS threads on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
 
 
+def bench_dcnf(args, lib, device, rank, world):
+    """BASELINE config 4: DCNF-lite unary conv stack (src/models.py:50-89), batch 16 -> 768 patches of 100x100x3.
+    A step = unary forward (resize, patches, 5 conv / 3 pool / 3 dense) + unary backward from a synthetic dz: 2.672 GFLOP
+    per patch forward and twice that backward (no input gradient for the first conv: 2.672 * 2 -
+    0.377)."""
+    from ann3depth_amd import models
+    B = 16 if args.batch == 32 else args.batch
+    rng = np.random.default_rng(1000 + rank)
+    img = torch.from_numpy((rng.integers(0, 256, (B, 480, 640, 3)) / 255).astype(np.float32)).to(device)
+    net = models.DCNFUnary(B, device=device)
+    dz = torch.randn((net.P, 1), device=device)
+
+    def step():
+        net.forward(img)
+        net.backward(dz)
+    steps, warm = min(args.steps, 20), min(args.warmup, 3)
+    for _ in range(warm):
+        step()
+    lib.a3d_timing_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.a3d_timing_enable(0)
+    roof, table = roofline_from(collect_timing(lib))
+    gflop = net.P * (2.672 + 2 * 2.672 - 0.377)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec (DCNF-lite unary stack, forward + backward)', 'value': round(world * B * steps / dt, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1e3 * dt / steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DCNF-lite unary conv stack, batch {B} -> {net.P} patches 100x100x3, forward + backward '
+                                   f'(BASELINE config 4)', 'per_gpu_batch': B},
+            'step_tflops': round(gflop / (dt / steps) / 1e3, 1), 'roofline': roof, 'igemm_kernels': table}), flush=True)
+    return 0
+
+
 def comm_report(net, img, dep, masks, args, lib, world, dt):
     """N > 1 only: how long each gradient bucket's RCCL all-reduce takes on its own (the 283 MB of src/ann3depth.py:77-92's
     parameter-server traffic, in the pieces MSDNReplica.step sends them), and how much communication the step does NOT
@@ -199,6 +238,9 @@ def main():
                     help='conv arithmetic; the headline (and parity) mode is fp32')
     ap.add_argument('--also', default='bf16x3', help='comma list of extra precisions measured after the headline run')
     ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
+    ap.add_argument('--model', default='msdn', choices=['msdn', 'dcnf'],
+                    help="msdn = the headline (BASELINE config 2/3/5); dcnf = BASELINE config 4, the DCNF-lite unary stack "
+                         "at batch 16 (768 patches): a separate line, 'step' = unary forward + backward")
     args = ap.parse_args()
 
     from ann3depth_amd import _lib, dp, models
@@ -212,6 +254,8 @@ def main():
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     B = args.batch
+    if args.model == 'dcnf':
+        return bench_dcnf(args, lib, device, rank, world)
     reducer = dp.GradReducer() if world > 1 else None
     net = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=args.precision,
                              keep_dense_grads=False)      # as models.msdn builds it for `make train`

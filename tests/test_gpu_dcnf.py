@@ -163,3 +163,57 @@ def test_make_train_dcnf(tmp_path):
     assert [r['global_step'] for r in recs] == [1, 2, 3]
     assert all(abs(r['loss/mean_loss'] + np.log(1e-7)) < 1e-2 for r in recs)
     assert os.path.exists(os.path.join(d, 'model.ckpt-3.pt'))
+
+
+def test_dcnf_unary_at_baseline_size_matches_oracle():
+    """BASELINE config 4 itself: batch 16 -> 768 patches (the planner picks other tiles / split-K / stream-K shares at
+    M = 768 * 8100 than at the 48 patches of the B = 1 tests).  Patches are independent (shared weights, tf.map_fn over
+    the batch, src/models.py:85-89), so the numpy oracle runs on 2 of the 16 images — the first and the last — and
+    must reproduce their slice of every activation; the backward is checked through the slice of every activation
+    gradient and, for the filter gradients (sums over all 768 patches), through linearity: the gradient of the batch is
+    the sum of the gradients of the 16 images taken one at a time through the B = 1 path that
+    test_dcnf_unary_matches_oracle pins to the oracle."""
+    from ann3depth_amd import models
+    B = 16
+    rng = np.random.default_rng(16)
+    img = (rng.integers(0, 256, (B, 480, 640, 3)) / 255).astype(np.float32)
+    params = OD.init_params(3000)
+    net = models.DCNFUnary(B, params=params)
+    assert net.P == 768
+    timg = torch.from_numpy(img).cuda()
+    z = net.forward(timg)
+    dz = rng.standard_normal((768, 1)).astype(np.float32)
+    net.backward(torch.from_numpy(dz).cuda())
+    torch.cuda.synchronize()
+    zg = z.cpu().numpy().reshape(768, 1)
+    for i in (0, B - 1):
+        sl = slice(48 * i, 48 * (i + 1))
+        patches = OD.patches(img[i:i + 1])
+        np.testing.assert_array_equal(net.act['x'][sl].cpu().numpy(), patches)
+        a = OD.unary_forward(params, patches)
+        assert rel(zg[sl], a['z']) < 1e-3
+        for n in ('conv2d/pool', 'conv2d_1/pool', 'conv2d_2', 'conv2d_3', 'conv2d_4/pool', 'dense', 'dense_1'):
+            assert rel(net.act[n][sl].cpu().numpy(), a[n]) < 1e-4, (i, n)
+    # backward: one image at a time through the B = 1 replica, same weights, same dz slice — and the batch's own
+    # activations and pool positions (a max pool window whose two largest values agree to the last bit may resolve
+    # differently under another tile plan's summation order; that moves one gradient element, rel-L2 ~2e-3 downstream,
+    # and says nothing about the kernels under test)
+    one = models.DCNFUnary(1, params=params)
+    acc = {n: torch.zeros_like(net.group.view(net.group.grad, n), dtype=torch.float64) for n in net.shapes}
+    for i in range(B):
+        sl = slice(48 * i, 48 * (i + 1))
+        for k in one.act:
+            one.act[k].copy_(net.act[k][sl])
+        for k in one.argmax:
+            one.argmax[k].copy_(net.argmax[k][sl])
+        one.backward(torch.from_numpy(dz[sl]).cuda())
+        if i in (0, B - 1):                      # activation gradients are per patch: slices must agree
+            for key in ('dense_1', 'dense', 'flat', 'conv2d_4', 'in:conv2d_4', 'in:conv2d_2', 'conv2d_1', 'in:conv2d_1', 'conv2d'):
+                assert rel(net.dact[key][sl].cpu().numpy(), one.dact[key].cpu().numpy()) < 1e-4, (i, key)
+        for n in net.shapes:
+            acc[n] += one.group.view(one.group.grad, n).double()
+    for n in net.shapes:
+        g = net.group.view(net.group.grad, n).cpu().numpy()
+        ref = acc[n].cpu().numpy()
+        if np.linalg.norm(ref) > 0:
+            assert rel(g, ref) < 1e-4, n
