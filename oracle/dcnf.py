@@ -145,13 +145,11 @@ def color_histogram(sp):
     """src/models.py:95-100 for all superpixels: [B,48,1600,3] -> [B,48,256] float counts."""
     dt = sp.dtype
     values = (sp * np.array([16777216., 65536., 256.], dt)).sum(axis=-1)
-    scaled = (values - dt.type(0)) / dt.type(16777216.)
-    idx = np.clip(np.floor(dt.type(256) * scaled).astype(np.int64), 0, 255)
-    B, P, _ = idx.shape
+    B, P, _ = values.shape
     hist = np.zeros((B, P, 256), dt)
     for b in range(B):
         for p in range(P):
-            hist[b, p] = np.bincount(idx[b, p], minlength=256)
+            hist[b, p] = T.histogram_fixed_width(values[b, p], (0.0, 16777216.0), 256)
     return hist
 
 

@@ -143,6 +143,36 @@ def maxpool2x2_bwd(x, dy):
     return dx
 
 
+def maxpool_grad(x, dy, k, stride):
+    """MaxPoolGrad for any square window / stride, VALID: each window's gradient goes to its FIRST maximum in (row, col)
+    scan order.  Slow reference (loops); maxpool2x2_bwd above is the vectorised 2x2 / stride-2 case the path uses, and
+    tests pin the two to each other and this one to TensorFlow's _testMaxPoolGradDirect1."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
+    dx = np.zeros_like(x, dtype=dy.dtype)
+    for b in range(B):
+        for i in range(Ho):
+            for j in range(Wo):
+                for c in range(C):
+                    win = x[b, i * stride:i * stride + k, j * stride:j * stride + k, c]
+                    r, q = np.unravel_index(int(np.argmax(win)), win.shape)      # numpy argmax = first maximum
+                    dx[b, i * stride + r, j * stride + q, c] += dy[b, i, j, c]
+    return dx
+
+
+def histogram_fixed_width(values, value_range, nbins):
+    """tf.histogram_fixed_width (TF 1.3 histogram_ops.py): scaled = (v - lo) / (hi - lo), index = floor(nbins * scaled)
+    clipped to [0, nbins - 1], counted — all in the values' dtype.  Used by the reference's color_histogram
+    (src/models.py:95-100; oracle/dcnf.py restates that call with nbins = 256 over [0, 2^24))."""
+    v = np.asarray(values)
+    dt = v.dtype.type if v.dtype.kind == 'f' else np.float32
+    v = v.astype(dt)
+    lo, hi = dt(value_range[0]), dt(value_range[1])
+    scaled = (v - lo) / (hi - lo)
+    idx = np.clip(np.floor(dt(nbins) * scaled).astype(np.int64), 0, nbins - 1)
+    return np.bincount(idx.ravel(), minlength=nbins).astype(np.int32)
+
+
 # --------------------------------------------------------------------------------------------
 # dense / dropout — src/models.py:80-82,228-231
 # --------------------------------------------------------------------------------------------

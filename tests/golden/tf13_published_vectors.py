@@ -5,7 +5,12 @@ tensorflow==1.3.0, requirements-cpu.txt:1).  Transcribed offline from
   tensorflow/python/ops/image_ops_test.py             (ResizeImagesTest.testResizeUp / testResizeDown, BILINEAR)
   tensorflow/python/kernel_tests/extract_image_patches_op_test.py (testKsize2x2Stride1x1Rate1x1Valid / ...Same)
 In those tests every operand is filled with 1, 2, 3, ... in row-major order (`x = [f * 1.0 for f in range(1, n + 1)]`)
-unless data is given.  These are DATA (inputs by rule + expected outputs), not source; they pin the oracle's conv2d
+unless data is given.  Round 2 adds
+  tensorflow/python/training/adam_test.py                  (AdamOptimizerTest.testBasic: inputs + its numpy recurrence)
+  tensorflow/python/kernel_tests/pooling_ops_test.py       (_testMaxPoolGradDirect1: ties go to the first maximum)
+  tensorflow/python/kernel_tests/histogram_ops_test.py / histogram_fixed_width's docstring example
+  tensorflow/python/ops/nn_test.py                         (DropoutTest: kept elements are x / keep_prob)
+These are DATA (inputs by rule + expected outputs), not source; they pin the oracle's conv2d
 (VALID / SAME incl. the odd SAME split, stride > kernel), both conv gradients, max-pool and the legacy bilinear resize
 to what TensorFlow 1.3 computes.
 """
@@ -61,3 +66,29 @@ EXTRACT_PATCHES_2X2 = [
     ('VALID', [[[[1, 2, 3, 4]]]]),
     ('SAME', [[[[1, 2, 3, 4], [2, 0, 4, 0]], [[3, 4, 0, 0], [4, 0, 0, 0]]]]),
 ]
+
+
+# AdamOptimizerTest.testBasic: two variables, constant gradients, default hyper-parameters, three steps.  The test's
+# expected values are its own numpy recurrence (adam_update_numpy), reproduced by the consuming tests from these inputs:
+#   alpha_t = lr * sqrt(1 - beta2**t) / (1 - beta1**t);  m_t = beta1*m + (1-beta1)*g;  v_t = beta2*v + (1-beta2)*g*g
+#   param_t = param - alpha_t * m_t / (sqrt(v_t) + epsilon);   assertAllCloseAccordingToType (float32: 1e-6)
+ADAM_TEST_BASIC = {
+    'var0': [1.0, 2.0], 'grads0': [0.1, 0.1], 'var1': [3.0, 4.0], 'grads1': [0.01, 0.01],
+    'lr': 0.001, 'beta1': 0.9, 'beta2': 0.999, 'epsilon': 1e-8, 'steps': 3,
+}
+
+# _testMaxPoolGradDirect1 ("constant gradient behavior"): input 1x4x4x1 of ones, 2x2 window, stride 1, VALID; every window
+# is a four-way tie and MaxPoolGrad sends the window's gradient to its FIRST element in scan order.
+MAXPOOL_GRAD_DIRECT1 = {
+    'input_sizes': (1, 4, 4, 1), 'input_data': [1.0] * 16, 'window': 2, 'stride': 1,
+    'output_backprop': [11.0, 12.0, 13.0, 15.0, 16.0, 17.0, 19.0, 20.0, 21.0],
+    'expected_input_backprop': [11.0, 12.0, 13.0, 0.0, 15.0, 16.0, 17.0, 0.0, 19.0, 20.0, 21.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+}
+
+# tf.histogram_fixed_width: values below the range fall into the first bin, values >= the upper edge into the last.
+HISTOGRAM_FIXED_WIDTH = {
+    'value_range': [0.0, 5.0], 'nbins': 5, 'new_values': [-1.0, 0.0, 1.5, 2.0, 5.0, 15.0], 'expected': [2, 1, 1, 0, 2],
+}
+
+# nn.dropout: binary = floor(keep_prob + U); y = x / keep_prob * binary -> an all-ones input comes out as {0, 1/keep_prob}
+DROPOUT_KEEP_PROBS = [0.1, 0.5, 0.8]

@@ -432,6 +432,54 @@ def test_tensorflow_published_vectors_through_the_c_abi(ops):
         y = torch.empty((want.shape[1] * want.shape[2], 2, 2, 1), device='cuda')
         ops.extract_patches(dev(np.array([1, 2, 3, 4], np.float32).reshape(1, 2, 2, 1)), 2, 1, y)
         np.testing.assert_array_equal(y.cpu().numpy().reshape(want.shape), want)
+    # AdamOptimizerTest.testBasic: three ApplyAdam steps of two 2-element variables, against the test's float64 recurrence
+    c = V.ADAM_TEST_BASIC
+    for tag in ('0', '1'):
+        var, m, v = dev(np.array(c['var' + tag], np.float32)), torch.zeros(2, device='cuda'), torch.zeros(2, device='cuda')
+        g = dev(np.array(c['grads' + tag], np.float32))
+        p64, m64, v64 = np.array(c['var' + tag], np.float64), 0.0, 0.0
+        b1p, b2p = np.float32(c['beta1']), np.float32(c['beta2'])
+        for t in range(1, c['steps'] + 1):
+            ops.adam_apply_tf1(var, m, v, g, c['lr'], c['beta1'], c['beta2'], c['epsilon'], float(b1p), float(b2p))
+            b1p, b2p = b1p * np.float32(c['beta1']), b2p * np.float32(c['beta2'])
+            alpha_t = c['lr'] * np.sqrt(1 - c['beta2'] ** t) / (1 - c['beta1'] ** t)
+            g64 = np.array(c['grads' + tag], np.float64)
+            m64 = c['beta1'] * m64 + (1 - c['beta1']) * g64
+            v64 = c['beta2'] * v64 + (1 - c['beta2']) * g64 * g64
+            p64 = p64 - alpha_t * m64 / (np.sqrt(v64) + c['epsilon'])
+            np.testing.assert_allclose(var.cpu().numpy(), p64, rtol=1e-6, atol=1e-6)
+    # _testMaxPoolGradDirect1's rule (all ties -> first element of the window) at the path's 2x2 / stride 2, both kernels
+    ones = dev(np.ones((1, 4, 4, 4), np.float32))
+    dyp = dev(np.arange(1, 17, dtype=np.float32).reshape(1, 2, 2, 4))
+    dx = torch.full((1, 4, 4, 4), float('nan'), device='cuda')
+    ops.maxpool2x2_bwd(ones, dyp, dx, relu_mask=False)
+    want = np.zeros((1, 4, 4, 4), np.float32)
+    want[:, ::2, ::2, :] = dyp.cpu().numpy()
+    np.testing.assert_array_equal(dx.cpu().numpy(), want)
+    d = ops.conv_desc(1, 4, 4, 4, 4, 1, 1, 1, 'VALID')         # 1x1 identity conv + pool of an all-ones image: argmax = 0
+    yp = torch.empty((1, 2, 2, 4), device='cuda')
+    am = torch.full((1, 2, 2, 4), 9, dtype=torch.uint8, device='cuda')
+    ops.conv2d_pool_fwd(d, ones, dev(np.eye(4, dtype=np.float32).reshape(1, 1, 4, 4)), torch.zeros(4, device='cuda'), yp, 'relu', am)
+    assert int(am.max()) == 0 and float(yp.min()) == 1.0
+    dx.fill_(float('nan'))
+    ops.maxpool2x2_bwd_idx(am, yp, dyp, dx, relu_mask=True)
+    np.testing.assert_array_equal(dx.cpu().numpy(), want)
+    # histogram_fixed_width's clipping (below the range -> first bin, >= upper edge -> last bin) in the colour histogram:
+    # the published values scaled onto color_histogram's [0, 2^24) / 256 bins land in bins 0, 0, 76, 102, 255, 255
+    c = V.HISTOGRAM_FIXED_WIDTH
+    img = np.zeros((1, 40, 40, 3), np.float32)
+    img[0, 0, :6, 0] = np.array(c['new_values'], np.float32) / np.float32(5.0)       # red channel carries 2^24 * value
+    hist = ops.superpixel_hist(dev(img), 40).cpu().numpy().reshape(256)
+    from oracle import dcnf as OD
+    np.testing.assert_array_equal(hist, OD.color_histogram(OD.superpixels(np.pad(img, ((0, 0), (0, 200), (0, 280), (0, 0))))[:, :1])[0, 0])
+    assert hist[76] == 1 and hist[102] == 1 and hist[255] == 2 and hist[0] == 1600 - 4
+    # nn.dropout: kept units come out as x / keep_prob = 2 x (src/models.py:230), dropped ones as 0
+    x1 = dev(np.ones((4, 8), np.float32))
+    keep = dev((np.arange(32).reshape(4, 8) % 3 == 0).astype(np.uint8), torch.uint8)
+    y = torch.empty((4, 16), device='cuda')
+    ops.dense_fwd(x1, dev(np.full((8, 16), 0.125, np.float32)), torch.zeros(16, device='cuda'), y, 'relu',
+                  drop_keep=dev(np.repeat((np.arange(4) % 2 == 0)[:, None], 16, 1).astype(np.uint8), torch.uint8))
+    np.testing.assert_array_equal(y.cpu().numpy(), np.repeat(np.array([2, 0, 2, 0], np.float32)[:, None], 16, 1))
 
 
 @pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', [

@@ -55,3 +55,60 @@ def test_extract_image_patches(case):
     x = np.array([1, 2, 3, 4], np.float32).reshape(1, 2, 2, 1)
     want = np.array(want, np.float32)
     np.testing.assert_array_equal(T.extract_patches(x, 2, 1, pad).reshape(want.shape), want)
+
+
+def adam_update_numpy(param, g_t, t, m, v, alpha, beta1, beta2, epsilon):
+    """adam_test.py's reference recurrence, in float64."""
+    alpha_t = alpha * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m_t = beta1 * m + (1 - beta1) * g_t
+    v_t = beta2 * v + (1 - beta2) * g_t * g_t
+    return param - alpha_t * m_t / (np.sqrt(v_t) + epsilon), m_t, v_t
+
+
+def test_adam_basic():
+    """AdamOptimizerTest.testBasic: the oracle's ApplyAdam (fp32, TF's operation order) follows the test's float64
+    recurrence to the test's own float32 tolerance, beta powers included."""
+    c = V.ADAM_TEST_BASIC
+    opt = T.AdamTF1(c['lr'], c['beta1'], c['beta2'], c['epsilon'])
+    var = {'v0': np.array(c['var0'], np.float32), 'v1': np.array(c['var1'], np.float32)}
+    g = {'v0': np.array(c['grads0'], np.float32), 'v1': np.array(c['grads1'], np.float32)}
+    ref = {k: (np.array(c['var' + k[1]], np.float64), 0.0, 0.0) for k in var}
+    for t in range(1, c['steps'] + 1):
+        assert abs(float(opt.beta1_power) - c['beta1'] ** t) < 1e-6 and abs(float(opt.beta2_power) - c['beta2'] ** t) < 1e-6
+        opt.apply(var, g)
+        for k in var:
+            ref[k] = adam_update_numpy(ref[k][0], np.array(c['grads' + k[1]], np.float64), t, ref[k][1], ref[k][2],
+                                       c['lr'], c['beta1'], c['beta2'], c['epsilon'])
+            np.testing.assert_allclose(var[k], ref[k][0], rtol=1e-6, atol=1e-6)
+
+
+def test_maxpool_grad_ties_go_to_the_first_maximum():
+    c = V.MAXPOOL_GRAD_DIRECT1
+    x = np.array(c['input_data'], np.float32).reshape(c['input_sizes'])
+    dy = np.array(c['output_backprop'], np.float32).reshape(1, 3, 3, 1)
+    np.testing.assert_array_equal(T.maxpool_grad(x, dy, c['window'], c['stride']).ravel(),
+                                  np.array(c['expected_input_backprop'], np.float32))
+    # the 2x2 / stride-2 routine the path uses is that rule: equal to the general one on inputs full of ties
+    rng = np.random.default_rng(3)
+    xt = rng.integers(0, 3, (2, 6, 8, 5)).astype(np.float32)
+    dyt = rng.standard_normal((2, 3, 4, 5)).astype(np.float32)
+    np.testing.assert_array_equal(T.maxpool2x2_bwd(xt, dyt), T.maxpool_grad(xt, dyt, 2, 2))
+    ones = np.ones((1, 4, 4, 1), np.float32)
+    got = T.maxpool2x2_bwd(ones, np.array([[[[5.]], [[6.]]], [[[7.]], [[8.]]]], np.float32).reshape(1, 2, 2, 1))
+    np.testing.assert_array_equal(got.reshape(4, 4), [[5, 0, 6, 0], [0, 0, 0, 0], [7, 0, 8, 0], [0, 0, 0, 0]])
+
+
+def test_histogram_fixed_width():
+    c = V.HISTOGRAM_FIXED_WIDTH
+    np.testing.assert_array_equal(T.histogram_fixed_width(np.array(c['new_values'], np.float32), c['value_range'], c['nbins']),
+                                  c['expected'])
+
+
+@pytest.mark.parametrize('keep_prob', V.DROPOUT_KEEP_PROBS)
+def test_dropout_values(keep_prob):
+    x = np.ones((40, 30), np.float32)
+    keep = np.random.default_rng(0).random(x.shape) < keep_prob
+    y = T.dropout_fwd(x, keep, rate=1.0 - keep_prob)
+    vals = np.unique(y)
+    assert len(vals) == 2 and vals[0] == 0
+    np.testing.assert_allclose(vals[1], 1 / keep_prob, rtol=1e-6)
