@@ -131,14 +131,13 @@ class MSDNReplica:
         self.global_step = global_step
         self.reducer = reducer
         dev = self.device
-        # Opt-in second HIP stream (A3D_OVERLAP=1): the fine network's forward — MFMA-bound, and in the coarse phase
-        # needed only for its loss — runs beside the stretch of the coarse chain that is HBM- or launch-bound (dense
-        # forward, loss, dense backward, conv2d_4 backward) and is joined before the large conv backward GEMMs start.
-        # Measured on one MI355X at B = 32: +1.6 % in the coarse phase (8.18 k -> 8.31 k images/s), -0.3 % in the fine
-        # phase; co-running kernels stretch each other by 1.3-2x (the weight-streaming dense GEMMs and the MFMA-bound
-        # convs contend for the same CUs), so per-kernel timings stop being meaningful.  Off by default, never on in
-        # bench.py's line.  (Running every backward-filter GEMM beside the backward-data chain instead: +3 % / -6.5 %.)
-        self.overlap = os.environ.get('A3D_OVERLAP', '0') == '1'
+        # Second HIP stream (A3D_OVERLAP=0 turns it off): the fine network's forward — MFMA-bound, and in the coarse phase
+        # needed only for its loss — runs beside the stretch of the coarse chain that is HBM-bound (dense forward, loss,
+        # dense backward + ApplyAdam, conv2d_4 backward) and is joined before the large conv backward GEMMs start.
+        # Measured on one MI355X at B = 32 (round 2): coarse-phase step 3.42 -> 3.32 ms.  The two kinds of kernel share
+        # CUs only as far as the register file allows (two 8-wave GEMM blocks fill a SIMD's 512 registers), so the gain
+        # is a quarter of the stretch, not all of it.  The dominant bwd-filter GEMMs run after the join, alone.
+        self.overlap = os.environ.get('A3D_OVERLAP', '1') == '1'
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         # conv + ReLU + max pool in one kernel inside step(): the pre-pool activations c0, c1, f1 are never written
         # (the network being trained keeps one byte per pool window instead, see forward())
