@@ -15,7 +15,7 @@ class A3dError(RuntimeError):
 class ConvDesc(ctypes.Structure):
     """struct a3d_conv_desc"""
     _fields_ = [(n, c_int32) for n in ('n', 'h', 'w', 'c', 'k', 'r', 's', 'stride', 'pad_t', 'pad_l', 'ho', 'wo',
-                                       'ldx', 'ldy', 'precision')]
+                                       'ldx', 'ldy', 'precision', 'storage')]
 
 
 class ExampleView(ctypes.Structure):
@@ -59,6 +59,13 @@ SIGNATURES = {
     'a3d_dropout_keep_mask': (c_int, [c_size_t, ctypes.c_uint64, ctypes.c_uint64, c_float, _P, _P]),
     'a3d_adam_apply_tf1': (c_int, [c_size_t, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                    c_float, _P]),
+    'a3d_dense_fwd_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
+    'a3d_dense_bwd_data_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P]),
+    'a3d_cast_bf16': (c_int, [c_size_t, _P, _P, c_int, _P]),
+    'a3d_maxpool2x2_fwd_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P]),
+    'a3d_maxpool2x2_bwd_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    'a3d_copy_channel_bf16': (c_int, [c_size_t, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    'a3d_maxpool2x2_bwd_idx_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P]),
     'a3d_dense_bwd_filter_adam_tf1': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                               c_float, c_float, c_float, _P]),
     'a3d_superpixel_mean': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),

@@ -292,7 +292,7 @@ def parse_args(argv=None):
     parser.add_argument('--task-index', default=0, type=int, help='(ignored) rank comes from the launcher.')
     parser.add_argument('--beta2', default=None, type=float,
                         help='NON-REFERENCE: Adam beta2 (the reference hard-codes 1, which freezes the weights).')
-    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+    parser.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16', 'bf16s'],
                         help='NON-REFERENCE unless fp32: arithmetic of the conv contractions.')
     parser.add_argument('--seed', default=0, type=int, help='Shuffle-queue seed.')
     parser.add_argument('--tf-checkpoints', action='store_true',

@@ -42,6 +42,7 @@ struct GemmProblem {
   int M, N, K;
   int avec, bvec;    // 1 or 4
   int plain = 0;     // 1: register-staged kernel without split-K only (fused-pool forward)
+  int no_glds = 0;   // 1: not the LDS-DMA kernels (bf16 output)
 };
 
 GemmPlan plan_gemm(const GemmProblem& g, int precision = 0);

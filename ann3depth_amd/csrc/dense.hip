@@ -222,17 +222,6 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
     }
   }
 
-  // this wave's share of the m tile — rows 8*wave .. 8*wave+7, two 1-KiB halves each — requested first
-  f32x4 mold[16];
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = k0 + wave * 8 + r, col = nb + h * 256 + lane * 4;
-      mold[2 * r + h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < K && col < N) mold[2 * r + h] = *reinterpret_cast<const f32x4*>(m_w + (size_t)row * N + col);
-    }
-
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -262,6 +251,18 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
   for (int v = 0; v < 16; ++v)
     *reinterpret_cast<f32x4*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * kRowsLd + wave * 128 + 4 * li]) =
         (f32x4){acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+  // this wave's share of the m tile — rows 8*wave .. 8*wave+7, two 1-KiB halves each — requested once the accumulators
+  // are in LDS: the kernel then never holds both (under 128 registers: four waves per SIMD hide the HBM latency, and the
+  // waves fit beside the GEMM blocks of the fine network that run on the second stream at the same time)
+  f32x4 mold[16];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = k0 + wave * 8 + r, col = nb + h * 256 + lane * 4;
+      mold[2 * r + h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < K && col < N) mold[2 * r + h] = *reinterpret_cast<const f32x4*>(m_w + (size_t)row * N + col);
+    }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 8; ++r)

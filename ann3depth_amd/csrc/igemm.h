@@ -162,6 +162,9 @@ struct IgemmParams {
   // channels of a tap first.  nocheck: unpadded forward / bwd-filter gathers never leave the image.
   unsigned long long a_elems, b_elems;
   int uni, kperm, cpt, ntaps, nocheck;
+  // bf16 storage (igemm_bf16_kernel<.., A16, B16, C16>): which operands are bf16 in HBM, and div_c for the float view
+  int a16, b16, c16;
+  FastDiv div_c_half;
   FastDiv div_cpt, div_taps;
   // stream-K (p.streamk): the (tile, k-tile) iterations, tile-major, are dealt to the blocks in equal contiguous shares
   // (no tile quantisation: 177 tiles x 4 splits = 708 blocks on 512 slots was a 1.4-round launch).  A block that owns a
@@ -268,6 +271,7 @@ struct Im2colTile {
   static_assert(NT % CPR == 0, "cpr");
   static constexpr int RPP = NT / CPR;
   static constexpr int NL = (ROWS + RPP - 1) / RPP;
+  static constexpr int NROWS = ROWS;
   static constexpr bool PARTIAL = RPP > ROWS;      // fewer chunks than threads: the upper threads idle
   static_assert(PARTIAL || ROWS % RPP == 0, "rows");
 
@@ -338,6 +342,7 @@ template <int NT, int ROWS, int COLS, int VEC>
 struct FilterTTile {
   static constexpr int CPR = COLS / VEC;
   static constexpr int RPP = NT / CPR;
+  static constexpr int NROWS = ROWS;
   static constexpr int NL = (ROWS + RPP - 1) / RPP;
   static constexpr bool PARTIAL = RPP > ROWS;
   static_assert(PARTIAL || ROWS % RPP == 0, "rows");
@@ -432,7 +437,8 @@ __device__ __forceinline__ void store_quad(const IgemmParams& p, const f32x4 q, 
         if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
       }
     }
-    Cout[o] = val;
+    if (p.c16 && !partial) reinterpret_cast<__bf16*>(Cout)[o] = (__bf16)val;      // bf16-stored output tensor
+    else Cout[o] = val;
   }
 }
 template <int MODE, int TM, int TN, int WM, int WN>
@@ -918,7 +924,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
 #pragma unroll
           for (int i = 1; i < 4; ++i)
             if (v[i] > val) { val = v[i]; arg = i; }
-          Cout[(size_t)(row >> 2) * ldc + col] = val;
+          if (p.c16) reinterpret_cast<__bf16*>(Cout)[(size_t)(row >> 2) * ldc + col] = (__bf16)val;
+          else Cout[(size_t)(row >> 2) * ldc + col] = val;
           if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
         }
       }
@@ -1016,6 +1023,7 @@ struct ReduceParams {
   int M, N, ldc, splitk, act, mode, mask_act; size_t slab;
   int sub_step, sub_ph, sub_pw, outW, outHW; FastDiv div_phw, div_pw;     // BWD_D parity-class row remap
   int vec4;              // plain 16-byte sum (bwd-filter slabs)
+  int c16;               // output (and BWD_D mask) tensors are bf16
   const float* dbias_ws; float* dbias_out;     // bwd-filter: the [splitk][N] BiasAddGrad slabs ride along, or null
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);

@@ -70,6 +70,30 @@ __device__ __forceinline__ void store_bf16(const float (&regs)[Tile::NL][4], __b
   }
 }
 
+// registers of a loader tile that was gathered from a bf16 tensor through its "float view" (a float = two adjacent
+// bf16 channels; 4 floats = 8 bf16 = one 16-byte chunk) -> bf16 plane, bit for bit
+template <class Tile, bool PLAIN>
+__device__ __forceinline__ void store_raw16(const float (&regs)[Tile::NL][4], __bf16* hi, int ld, int tid) {
+#pragma unroll
+  for (int j = 0; j < Tile::NL; ++j) {
+    int row, cq;
+    if constexpr (PLAIN) {
+      const int idx = tid + j * 512;
+      if (Tile::TOTAL % 512 != 0 && idx >= Tile::TOTAL) continue;
+      row = idx / Tile::CPR;
+      cq = idx % Tile::CPR;
+    } else {
+      row = tid / Tile::CPR + j * Tile::RPP;
+      cq = tid % Tile::CPR;
+      if (Tile::PARTIAL && row >= Tile::NROWS) continue;
+    }
+    const f32x4 v = {regs[j][0], regs[j][1], regs[j][2], regs[j][3]};
+    *reinterpret_cast<f32x4*>(hi + row * ld + cq * 8) = v;
+  }
+}
+__device__ __forceinline__ float bf16_lo(float packed) { return __uint_as_float(__float_as_uint(packed) << 16); }
+__device__ __forceinline__ float bf16_hi(float packed) { return __uint_as_float(__float_as_uint(packed) & 0xffff0000u); }
+
 __device__ __forceinline__ bf16x4 lds_read_tr(const __bf16* p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
@@ -94,16 +118,28 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane, int ld, int col0,
   return r;
 }
 
-template <int MODE, int BM, int BN, bool X3>
+// A16 / B16: the A / B operand tensor is stored as bf16 in HBM (BASELINE config 5: bf16 activations and weight copies);
+// it is gathered through its float view (half as many "channels", 16-byte chunks of 8 bf16) and lands in the LDS plane
+// unconverted.  C16: the output tensor (and, in BWD_D, the ReluGrad mask, which is the same activation) is bf16; split-K
+// slabs and filter gradients stay fp32.
+template <int MODE, int BM, int BN, bool X3, bool A16 = false, bool B16 = false, bool C16 = false>
 __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p) {
   using Cfg = Bf16Cfg<MODE, BM, BN, X3>;
   constexpr int BK = Cfg::BK, NT = Cfg::NT, TN = Cfg::TN;
   constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
-  using ATile = Im2colTile<NT, Cfg::A_ROWS, Cfg::A_COLS, 4, TRANSPOSED>;
-  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<NT, Cfg::B_ROWS, Cfg::B_COLS, 4>,
-                                          PlainTile<NT, Cfg::B_ROWS, Cfg::B_COLS, 4>>::type;
+  static_assert(!(X3 && (A16 || B16)), "the split-operand mode needs fp32 sources");
+  using ATile = Im2colTile<NT, Cfg::A_ROWS, A16 ? Cfg::A_COLS / 2 : Cfg::A_COLS, 4, TRANSPOSED>;
+  using BTile = typename std::conditional<MODE == MODE_BWD_D, FilterTTile<NT, Cfg::B_ROWS, B16 ? Cfg::B_COLS / 2 : Cfg::B_COLS, 4>,
+                                          PlainTile<NT, Cfg::B_ROWS, B16 ? Cfg::B_COLS / 2 : Cfg::B_COLS, 4>>::type;
   static_assert(!ATile::PARTIAL, "A tile must cover all threads");
   constexpr bool B_PLAIN = (MODE != MODE_BWD_D);
+  // parameter view of a bf16 tensor as floats: half the channels per pixel / per filter tap
+  IgemmParams ph = p;
+  ph.ld = p.ld / 2; ph.Cg = p.Cg / 2; ph.nrsc = p.nrsc / 2; ph.K = p.K / 2; ph.div_c = p.div_c_half;
+  const IgemmParams& pA = A16 ? ph : p;
+  const IgemmParams& pB = B16 ? ph : p;
+  constexpr int AKS = A16 ? BK / 2 : BK;       // k-tile extent of the A / B gather in its own units
+  constexpr int BKS = B16 ? BK / 2 : BK;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* tiles = reinterpret_cast<__bf16*>(smem_raw);
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   // BiasAddGrad (BWD_F): every thread sums, in fp32 and over the whole K range, the dz values it stages (its 4
   // columns, its rows of each tile); one LDS reduction in the epilogue
   const bool do_bias = (MODE == MODE_BWD_F) && p.dbias != nullptr && tile_m == 0;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // B16: the thread's chunk is 8 columns
 
   const int a_cq = tid % ATile::CPR;
   const int b_cq = tid % BTile::CPR;
@@ -163,30 +199,37 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   __syncthreads();
 
   ColDec cdec;
-  if (MODE == MODE_BWD_F) cdec = decode_col(p, m0 + a_cq * 4);
+  if (MODE == MODE_BWD_F) cdec = decode_col(pA, (A16 ? m0 / 2 : m0) + a_cq * 4);
+  // a bf16 B tile is read in 16-byte chunks up to its row stride: pad columns (fine/first's 64th channel) are zeros
+  const int ldb_v = B16 ? p.ldb / 2 : p.ldb, n0_v = B16 ? n0 / 2 : n0, nn_v = B16 ? p.ldb / 2 : p.N;
 
   auto load_tiles = [&](int kt, int pbuf) {
     if constexpr (MODE == MODE_BWD_F) {
-      ATile::load(ra, p, pixtab + pbuf * Cfg::PIX, cdec, tid);
-      BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+      ATile::load(ra, pA, pixtab + pbuf * Cfg::PIX, cdec, tid);
+      BTile::load(rb, p.B, ldb_v, kt * BK, n0_v, p.K, nn_v, tid);
       if (do_bias) {
 #pragma unroll
         for (int j = 0; j < BTile::NL; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[e] += rb[j][e];
+          for (int e = 0; e < 4; ++e) {
+            if (B16) { bsum[2 * e] += bf16_lo(rb[j][e]); bsum[2 * e + 1] += bf16_hi(rb[j][e]); }
+            else bsum[e] += rb[j][e];
+          }
       }
     } else {
-      ColDec cd = decode_col(p, kt * BK + a_cq * 4);
-      ATile::load(ra, p, pixtab, cd, tid);
+      ColDec cd = decode_col(pA, kt * AKS + a_cq * 4);
+      ATile::load(ra, pA, pixtab, cd, tid);
       if constexpr (MODE == MODE_FWD)
-        BTile::load(rb, p.B, p.ldb, kt * BK, n0, p.K, p.N, tid);
+        BTile::load(rb, p.B, ldb_v, kt * BK, n0_v, p.K, nn_v, tid);
       else
-        BTile::load(rb, p, n0, kt * BK + b_cq * 4, tid);
+        BTile::load(rb, pB, n0, kt * BKS + b_cq * 4, tid);
     }
   };
   auto store_tiles = [&](int buf) {
-    store_bf16<ATile, X3, false>(ra, A_hi(buf), A_lo(buf), Cfg::A_LD, tid);
-    store_bf16<BTile, X3, B_PLAIN>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
+    if constexpr (A16) store_raw16<ATile, false>(ra, A_hi(buf), Cfg::A_LD, tid);
+    else store_bf16<ATile, X3, false>(ra, A_hi(buf), A_lo(buf), Cfg::A_LD, tid);
+    if constexpr (B16) store_raw16<BTile, B_PLAIN>(rb, B_hi(buf), Cfg::B_LD, tid);
+    else store_bf16<BTile, X3, B_PLAIN>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
   };
 
   if (nkt > 0) {
@@ -253,10 +296,11 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   }
   if (MODE == MODE_BWD_F && p.dbias != nullptr && tile_m == 0) {        // block-uniform branch
     float* red = reinterpret_cast<float*>(smem_raw);                       // tile buffers are free now
-    constexpr int RG = NT / (BN / 4);                                      // row groups: threads sharing a column chunk
-    const int rg = tid / (BN / 4);
+    constexpr int CW = B16 ? 8 : 4;                                        // columns per thread chunk
+    constexpr int RG = NT / (BN / CW);                                     // row groups: threads sharing a column chunk
+    const int rg = tid / (BN / CW);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[rg * BN + b_cq * 4 + e] = bsum[e];
+    for (int e = 0; e < CW; ++e) red[rg * BN + b_cq * CW + e] = bsum[e];
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
       float s = 0.f;
@@ -286,10 +330,14 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
           else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + expf(-val));
           if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
         } else if (MODE == MODE_BWD_D) {
-          if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
+          if (p.mask) {
+            const float y = C16 ? (float)reinterpret_cast<const __bf16*>(p.mask)[o] : p.mask[o];
+            val = apply_act_grad(val, y, p.mask_act, p.mask_scale);
+          }
         }
       }
-      Cout[o] = val;
+      if (C16 && !partial) reinterpret_cast<__bf16*>(Cout)[o] = (__bf16)val;
+      else Cout[o] = val;
     }
   }
 }

@@ -14,7 +14,7 @@ namespace a3d {
 int launch_igemm_mode0(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode1(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
 int launch_igemm_mode2(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st);
-int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st);
+int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st);   // p.a16/b16/c16 pick the storage variant
 int launch_fixup_mode0(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_fixup_mode1(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_fixup_mode2(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
@@ -115,7 +115,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   // Model picks are within 1.15x (mostly 1.05x) of the best measured configuration for every MSDN layer/direction.
   for (int c = 0; c < kNumCfgs; ++c) {
     if (kCfgs[c].eff <= 0.f) continue;
-    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain)) continue;
+    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
@@ -237,9 +237,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
       else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
       if (p.keep) s = p.keep[i] ? s * p.mask_scale : 0.f;
     } else if (p.mode == MODE_BWD_D) {
-      if (p.mask) s = apply_act_grad(s, p.mask[o], p.mask_act, p.mask_scale);
+      if (p.mask) {
+        const float y = p.c16 ? (float)reinterpret_cast<const __bf16*>(p.mask)[o] : p.mask[o];
+        s = apply_act_grad(s, y, p.mask_act, p.mask_scale);
+      }
     }
-    p.C[o] = s;
+    if (p.c16) reinterpret_cast<__bf16*>(p.C)[o] = (__bf16)s;
+    else p.C[o] = s;
   }
 }
 
@@ -318,7 +322,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     ReduceParams r{};
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
-    r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act;
+    r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act; r.c16 = p.c16;
     r.vec4 = mode == MODE_BWD_F && p.ldc == p.N && (p.slab % 4) == 0 && aligned16(final_c) && aligned16(ws);
     r.sub_step = p.sub_step; r.sub_ph = p.sub_ph; r.sub_pw = p.sub_pw; r.outW = p.outW; r.outHW = p.outHW;
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
@@ -443,6 +447,25 @@ static GemmProblem bwd_f_problem(const a3d_conv_desc* d) {
   return g;
 }
 
+// a3d_conv_desc.storage -> which GEMM operands are bf16, with the checks a 16-byte bf16 gather needs
+static int apply_storage(IgemmParams& p, GemmProblem& g, int precision, bool a16, bool b16, bool c16, int a_c, int a_ld,
+                         int b_c, int b_ld, const void* a, const void* b, const void* c, int c_c, int c_ld) {
+  if (!a16 && !b16 && !c16) return A3D_OK;
+  // a bf16 OUTPUT alone is also served by the fp32 kernels (the 3-channel layers of config 5 keep fp32 arithmetic)
+  A3D_CHECK_ARG(precision == A3D_PREC_BF16 || (precision == A3D_PREC_F32 && !a16 && !b16),
+                "bf16 operands need precision A3D_PREC_BF16");
+  A3D_CHECK_ARG(!a16 || (a_c % 8 == 0 && a_ld % 8 == 0 && aligned16(a)), "bf16 operand: channels / stride must be multiples of 8, base 16-byte aligned");
+  // b_c < 0: a row-major [rows][b_ld] operand read in whole 16-byte chunks (its pad columns must be readable zeros)
+  A3D_CHECK_ARG(!b16 || ((b_c < 0 || b_c % 8 == 0) && b_ld % 8 == 0 && aligned16(b)), "bf16 operand: channels / stride must be multiples of 8, base 16-byte aligned");
+  A3D_CHECK_ARG(!c16 || aligned16(c), "bf16 output: base must be 16-byte aligned");
+  (void)c_c; (void)c_ld;
+  p.a16 = a16; p.b16 = b16; p.c16 = c16;
+  if (c16) g.no_glds = 1;
+  if (a16) g.avec = 4;
+  if (b16) g.bvec = 4;
+  return A3D_OK;
+}
+
 static void fill_common(IgemmParams& p, const GemmProblem& g) {
   p = IgemmParams{};
   p.M = g.M; p.N = g.N; p.K = g.K;
@@ -534,6 +557,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     A3D_CHECK_ARG(d->ho >= 2 && d->wo >= 2 && ld_out >= d->k, "conv2d_pool_fwd: output smaller than one pool window");
     A3D_CHECK_ARG(!stencil1_applicable(d), "conv2d_pool_fwd: single-output-channel convs are not supported");
   } else if (stencil1_applicable(d)) {
+    A3D_CHECK_ARG(!d->storage, "conv2d_fwd: single-output-channel convs take float32 tensors");
     return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -561,11 +585,23 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     filter = wp;
     g.bvec = (d->k % 4 == 0) ? 4 : 1;           // the padded copy is 256-byte aligned
   }
+  IgemmParams p;
+  fill_common(p, g);
+  {
+    const int sb = d->storage;
+    A3D_CHECK_ARG(!sb || ((!pool || sb == A3D_STORE_Y_BF16) && !(run && (sb & A3D_STORE_W_BF16))),
+                  "conv2d_fwd: the fused pool takes float32 inputs (its output may be bf16); 3-channel filters stay float32");
+    const IgemmParams keep = p;
+    rc = apply_storage(p, g, d->precision, sb & A3D_STORE_X_BF16, sb & A3D_STORE_W_BF16, sb & A3D_STORE_Y_BF16, d->c,
+                       d->ldx, d->k, d->k, x, w, y, d->k, d->ldy);
+    if (rc != A3D_OK) return rc;
+    (void)keep;
+  }
   GemmPlan plan = plan_gemm(g, d->precision);
   if (ws_used + plan.ws_bytes > ws_bytes)
     return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
-  IgemmParams p;
-  fill_common(p, g);
+  A3D_CHECK_ARG(!(p.a16 || p.b16) || plan.prec == A3D_PREC_BF16, "conv2d_fwd: bf16 operands need vectorisable tensors");
+  A3D_CHECK_ARG(!p.c16 || plan.prec == A3D_PREC_BF16 || plan.cfg < kFirstGldsCfg, "conv2d_fwd: no bf16 output from the LDS-DMA kernel");
   p.A = x; p.B = filter; p.C = y; p.bias = bias; p.act = act;
   p.npix = g.M; p.nrsc = g.K;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
@@ -573,6 +609,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   p.S = run ? 1 : d->s; p.Cg = run ? rf.rlp : d->c;
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
+  p.div_c_half = make_fastdiv(std::max(1, p.Cg / 2));
   p.ldb = d->k; p.ldc = d->ldy;
   if (pool) {
     p.pool = 1;
@@ -646,7 +683,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   unsigned multi_grid = 0;
   long multi_tiles = 0;
   double multi_flops = 0;
-  const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !env_int("A3D_NO_MULTI", 0) &&
+  const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !d->storage && !env_int("A3D_NO_MULTI", 0) &&
                          env_int("A3D_FORCE_CFG", -1) < 0;
   for (int ph = 0; ph < d->stride; ++ph) {
     for (int pw = 0; pw < d->stride; ++pw) {
@@ -655,7 +692,14 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       GemmProblem g = c.g;
       if (!vec_ok_a) g.avec = 1;
       if (!vec_ok_b) g.bvec = 1;
+      IgemmParams p;
+      fill_common(p, g);
+      rc = apply_storage(p, g, d->precision, d->storage & A3D_STORE_Y_BF16, d->storage & A3D_STORE_W_BF16,
+                         d->storage & A3D_STORE_X_BF16, d->k, d->ldy, d->k, d->k, dz, w, dx, d->c, d->ldx);
+      if (rc != A3D_OK) return rc;
+      A3D_CHECK_ARG(!p.c16 || !relu_mask || aligned16(relu_mask), "conv2d_bwd_data: bf16 mask must be 16-byte aligned");
       GemmPlan plan = plan_gemm(g, d->precision);
+      A3D_CHECK_ARG(!d->storage || plan.prec == A3D_PREC_BF16, "conv2d_bwd_data: bf16 storage needs vectorisable operands");
       if (try_multi) {                                   // 64x64 tiles, no split-K
         plan = GemmPlan{};
         plan.cfg = 4; plan.splitk = 1; plan.ktiles_per_split = std::max(1, (g.K + 31) / 32);
@@ -663,8 +707,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       }
       if (plan.ws_bytes > ws_bytes)
         return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
-      IgemmParams p;
-      fill_common(p, g);
+      p.M = g.M; p.N = g.N; p.K = g.K;
       p.A = dz; p.B = w; p.C = dx; p.mask = relu_mask;
       p.npix = g.M; p.nrsc = g.K;
       p.H = d->ho; p.W = d->wo; p.ld = d->ldy; p.pHW = d->ho * d->wo;
@@ -672,6 +715,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       p.S = std::max(c.sp, 1); p.Cg = d->k; p.Cn = d->c;
       p.div_phw = make_fastdiv(c.hc * c.wc); p.div_pw = make_fastdiv(c.wc);
       p.div_c = make_fastdiv(d->k); p.div_s = make_fastdiv(std::max(c.sp, 1));
+      p.div_c_half = make_fastdiv(std::max(1, d->k / 2));
       p.ldb = 0; p.ldc = d->ldx;
       p.sub_step = d->stride; p.sub_ph = ph; p.sub_pw = pw; p.tap_r0 = c.r0; p.tap_s0 = c.s0; p.S_full = d->s;
       p.outW = d->w; p.outHW = d->h * d->w;
@@ -753,6 +797,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && dz && dw, "conv2d_bwd_filter: null tensor");
   if (stencil1_applicable(d)) {
+    A3D_CHECK_ARG(!d->storage, "conv2d_bwd_filter: single-output-channel convs take float32 tensors");
     if (stencil1_bwdf_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return stencil1_bwd_filter(d, x, dz, dw, db, ws, static_cast<hipStream_t>(stream));
   }
@@ -768,12 +813,16 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
     ws_used = run_filter_bytes(d, rf);
     out = static_cast<float*>(ws);
   }
+  IgemmParams p;
+  fill_common(p, g);
+  rc = apply_storage(p, g, d->precision, d->storage & A3D_STORE_X_BF16, d->storage & A3D_STORE_Y_BF16, false, d->c, d->ldx,
+                     -1, d->ldy, x, dz, dw, d->k, d->k);
+  if (rc != A3D_OK) return rc;
   GemmPlan plan = plan_gemm(g, d->precision);
+  A3D_CHECK_ARG(!d->storage || plan.prec == A3D_PREC_BF16, "conv2d_bwd_filter: bf16 storage needs vectorisable operands");
   size_t need = ws_used + plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  IgemmParams p;
-  fill_common(p, g);
   p.A = x; p.B = dz; p.C = out; p.dbias = db;     // BiasAddGrad = column sums of dz, fused into the same kernel
   p.npix = g.K; p.nrsc = g.M;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
@@ -781,6 +830,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   p.S = run ? 1 : d->s; p.Cg = run ? rf.rlp : d->c;
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
+  p.div_c_half = make_fastdiv(std::max(1, p.Cg / 2));
   p.ldb = d->ldy; p.ldc = d->k;
   {
     const bool inside = (d->ho - 1) * d->stride + d->r <= d->h && (d->wo - 1) * d->stride + d->s <= d->w;
@@ -811,21 +861,32 @@ size_t a3d_dense_fwd_ws_bytes(int m, int k, int n) {
 
 int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                   const uint8_t* drop_keep, void* ws, size_t ws_bytes, void* stream) {
+  return a3d_dense_fwd_ex(m, k, n, x, w, bias, y, act, drop_keep, A3D_PREC_F32, 0, ws, ws_bytes, stream);
+}
+
+int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
+                     const uint8_t* drop_keep, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_fwd: bad dims");
+  A3D_CHECK_ARG((storage & ~A3D_STORE_W_BF16) == 0, "dense_fwd: only the weights may be bf16");
   a3d_conv_desc d = dense_desc(m, k, n);
+  d.precision = precision;
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
   GemmProblem g = fwd_problem(&d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(fwd_problem(&d));
-  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_fwd: need %zu workspace bytes", plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
+  rc = apply_storage(p, g, precision, false, storage & A3D_STORE_W_BF16, false, k, k, n, n, x, w, y, n, n);
+  if (rc != A3D_OK) return rc;
+  GemmPlan plan = plan_gemm(g, precision);
+  A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_fwd: bf16 weights need vectorisable operands");
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_fwd: need %zu workspace bytes", plan.ws_bytes);
   p.A = x; p.B = w; p.C = y; p.bias = bias; p.act = act; p.keep = drop_keep; p.mask_scale = 2.f;
   p.npix = m; p.nrsc = k; p.H = 1; p.W = 1; p.ld = k; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1; p.Cg = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(k); p.div_s = make_fastdiv(1);
+  p.div_c_half = make_fastdiv(std::max(1, k / 2));
   p.ldb = n; p.ldc = n;
   fill_staging(p, MODE_FWD, (unsigned long long)m * k, (unsigned long long)k * n, 1, 1, 1, 1);
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
@@ -838,7 +899,14 @@ size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n) {
 
 int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
                        int mask_act, float scale, void* ws, size_t ws_bytes, void* stream) {
+  return a3d_dense_bwd_data_ex(m, k, n, dz, w, dx, mask, mask_act, scale, A3D_PREC_F32, 0, ws, ws_bytes, stream);
+}
+
+int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
+                          float scale, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_data: bad dims");
+  A3D_CHECK_ARG((storage & ~A3D_STORE_W_BF16) == 0, "dense_bwd_data: only the weights may be bf16");
+  A3D_CHECK_ARG(precision >= A3D_PREC_F32 && precision <= A3D_PREC_BF16, "dense_bwd_data: unknown precision %d", precision);
   A3D_CHECK_ARG(!mask || mask_act == A3D_ACT_RELU || mask_act == A3D_ACT_SIGMOID, "dense_bwd_data: bad mask_act");
   a3d_conv_desc d = dense_desc(m, k, n);
   int rc = check_desc(&d);
@@ -847,14 +915,18 @@ int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, flo
   GemmProblem g = bwd_d_problem(&d);
   if (!aligned16(dz)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
-  GemmPlan plan = plan_gemm(bwd_d_problem(&d));
-  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: need %zu workspace bytes", plan.ws_bytes);
   IgemmParams p;
   fill_common(p, g);
+  rc = apply_storage(p, g, precision, false, storage & A3D_STORE_W_BF16, false, n, n, n, n, dz, w, dx, k, k);
+  if (rc != A3D_OK) return rc;
+  GemmPlan plan = plan_gemm(g, precision);
+  A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_bwd_data: bf16 weights need vectorisable operands");
+  if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: need %zu workspace bytes", plan.ws_bytes);
   p.A = dz; p.B = w; p.C = dx; p.mask = mask; p.mask_scale = scale; p.mask_act = mask_act;
   p.npix = m; p.nrsc = n; p.H = 1; p.W = 1; p.ld = n; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1;
   p.Cg = n; p.Cn = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(n); p.div_s = make_fastdiv(1);
+  p.div_c_half = make_fastdiv(std::max(1, n / 2));
   p.ldc = k;
   p.S_full = 1;
   fill_staging(p, MODE_BWD_D, (unsigned long long)m * n, (unsigned long long)k * n, 1, 1, 0, 0);

@@ -150,6 +150,97 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_vec4_kernel(const uint8_t
   }
 }
 
+// ------------------------------------------------------------------ bf16 storage (BASELINE config 5)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__ src, void* __restrict__ dst, size_t count,
+                                                        int to_bf16) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const size_t nvec = count / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    if (to_bf16) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+      const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      reinterpret_cast<bf16x4*>(dst)[i] = o;
+    } else {
+      const bf16x4 v = reinterpret_cast<const bf16x4*>(src)[i];
+      const f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+      reinterpret_cast<f32x4*>(dst)[i] = o;
+    }
+  }
+  if (blockIdx.x == 0) {
+    const size_t i = nvec * 4 + threadIdx.x;
+    if (i < count) {
+      if (to_bf16) reinterpret_cast<__bf16*>(dst)[i] = (__bf16) reinterpret_cast<const float*>(src)[i];
+      else reinterpret_cast<float*>(dst)[i] = (float)reinterpret_cast<const __bf16*>(src)[i];
+    }
+  }
+}
+
+// max pool 2x2/2 and its gradient on bf16 tensors: the fp32 kernels above with 2-byte elements (max of bf16 values is
+// exact in either type; first maximum in scan order)
+__global__ __launch_bounds__(256) void maxpool_fwd_bf16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
+                                                               const float* __restrict__ extra, int n, int h, int w, int c,
+                                                               int ho, int wo, int ldx, int ldy) {
+  const int cout = c + (extra ? 1 : 0);
+  const size_t total = (size_t)n * ho * wo * cout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % cout);
+    const size_t pix = i / cout;
+    __bf16 v;
+    if (ch < c) {
+      const int q = (int)(pix % wo);
+      const size_t t = pix / wo;
+      const int p = (int)(t % ho);
+      const int b = (int)(t / ho);
+      const __bf16* s = x + (((size_t)b * h + 2 * p) * w + 2 * q) * ldx + ch;
+      const float m = fmaxf(fmaxf((float)s[0], (float)s[ldx]), fmaxf((float)s[(size_t)w * ldx], (float)s[(size_t)w * ldx + ldx]));
+      v = (__bf16)m;
+    } else {
+      v = (__bf16)extra[pix];
+    }
+    y[pix * ldy + ch] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
+                                                               __bf16* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                               int wo, int ldx, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const size_t total = (size_t)n * hc * wc * c;
+  const __bf16 zero = (__bf16)0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int q = (int)(t % wc);
+    t /= wc;
+    const int p = (int)(t % hc);
+    const int b = (int)(t / hc);
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * ldx + ch;
+    const size_t c_ = (size_t)ldx;      // x and dx share the pixel stride
+    const bool full = p < ho && q < wo;
+    if (full) {
+      const float v0 = (float)x[base], v1 = (float)x[base + c_], v2 = (float)x[base + (size_t)w * c_],
+                  v3 = (float)x[base + (size_t)w * c_ + c_];
+      int arg = 0;
+      float best = v0;
+      if (v1 > best) { best = v1; arg = 1; }
+      if (v2 > best) { best = v2; arg = 2; }
+      if (v3 > best) { best = v3; arg = 3; }
+      __bf16 g = dy[(((size_t)b * ho + p) * wo + q) * lddy + ch];
+      if (relu_mask && !(best > 0.f)) g = zero;
+      dx[base] = arg == 0 ? g : zero;
+      dx[base + c_] = arg == 1 ? g : zero;
+      dx[base + (size_t)w * c_] = arg == 2 ? g : zero;
+      dx[base + (size_t)w * c_ + c_] = arg == 3 ? g : zero;
+    } else {
+      const bool has_r = 2 * p + 1 < h, has_c = 2 * q + 1 < w;
+      dx[base] = zero;
+      if (has_c) dx[base + c_] = zero;
+      if (has_r) dx[base + (size_t)w * c_] = zero;
+      if (has_r && has_c) dx[base + (size_t)w * c_ + c_] = zero;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ ResizeBilinear (legacy, align_corners=False)
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
                                                      int w, int c, int oh, int ow, float sy, float sx) {
@@ -387,6 +478,44 @@ __global__ __launch_bounds__(256) void copy_channel_kernel(const float* __restri
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
     dst[i * ld_dst + c_dst] = src[i * ld_src + c_src];
 }
+__global__ __launch_bounds__(256) void copy_channel_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                size_t npix, int ld_src, int c_src, int ld_dst, int c_dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
+    dst[i * ld_dst + c_dst] = (__bf16)src[i * ld_src + c_src];
+}
+// a3d_maxpool2x2_bwd_idx with bf16 pooled values and bf16 dy; dx float32 (the 3-channel layers' filter gradient takes it)
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_bf16_kernel(const uint8_t* __restrict__ argmax,
+                                                                   const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
+                                                                   float* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                                   int wo, int ldy, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2;
+  const size_t total = (size_t)n * hc * wc * c;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    size_t t = i / c;
+    const int q = (int)(t % wc);
+    t /= wc;
+    const int p = (int)(t % hc);
+    const int b = (int)(t / hc);
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+    if (p < ho && q < wo) {
+      const size_t win = ((size_t)b * ho + p) * wo + q;
+      const int arg = argmax[win * c + ch];
+      float g = (float)dy[win * lddy + ch];
+      if (relu_mask && !((float)y[win * ldy + ch] > 0.f)) g = 0.f;
+      dx[base] = arg == 0 ? g : 0.f;
+      dx[base + c] = arg == 1 ? g : 0.f;
+      dx[base + (size_t)w * c] = arg == 2 ? g : 0.f;
+      dx[base + (size_t)w * c + c] = arg == 3 ? g : 0.f;
+    } else {
+      const bool has_r = 2 * p + 1 < h, has_c = 2 * q + 1 < w;
+      dx[base] = 0.f;
+      if (has_c) dx[base + c] = 0.f;
+      if (has_r) dx[base + (size_t)w * c] = 0.f;
+      if (has_r && has_c) dx[base + (size_t)w * c + c] = 0.f;
+    }
+  }
+}
 }  // namespace a3d
 
 using namespace a3d;
@@ -413,6 +542,37 @@ int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* 
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy,
                      dx, n, h, w, c, h / 2, w / 2, lddy, relu_mask);
   return check_launch("maxpool_bwd");
+}
+
+int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream) {
+  A3D_CHECK_ARG(count > 0 && src && dst, "cast_bf16: bad arguments");
+  A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "cast_bf16: 16-byte aligned buffers");
+  clear_stale_error();
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, count, to_bf16);
+  return check_launch("cast_bf16");
+}
+
+int a3d_maxpool2x2_fwd_bf16(int n, int h, int w, int c, const void* x, int ldx, void* y, int ldy, const float* extra,
+                            void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && x && y && ldx >= c && ldy >= c + (extra ? 1 : 0),
+                "maxpool_fwd_bf16: bad arguments");
+  const size_t total = (size_t)n * (h / 2) * (w / 2) * (c + (extra ? 1 : 0));
+  clear_stale_error();
+  hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const __bf16*>(x), static_cast<__bf16*>(y), extra, n, h, w, c, h / 2, w / 2, ldx, ldy);
+  return check_launch("maxpool_fwd_bf16");
+}
+
+int a3d_maxpool2x2_bwd_bf16(int n, int h, int w, int c, const void* x, int ldx, const void* dy, int lddy, void* dx,
+                            int relu_mask, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && x && dy && dx && lddy >= c && ldx >= c, "maxpool_bwd_bf16: bad arguments");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  clear_stale_error();
+  hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const __bf16*>(x), static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), n, h, w, c,
+                     h / 2, w / 2, ldx, lddy, relu_mask);
+  return check_launch("maxpool_bwd_bf16");
 }
 
 int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, int ow, float* y, void* stream) {
@@ -493,6 +653,27 @@ int a3d_copy_channel(size_t npix, const float* src, int ld_src, int c_src, float
   hipLaunchKernelGGL(copy_channel_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 2048)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, dst, npix, ld_src, c_src, ld_dst, c_dst);
   return check_launch("copy_channel");
+}
+
+int a3d_copy_channel_bf16(size_t npix, const float* src, int ld_src, int c_src, void* dst, int ld_dst, int c_dst, void* stream) {
+  A3D_CHECK_ARG(npix > 0 && src && dst && c_src >= 0 && c_src < ld_src && c_dst >= 0 && c_dst < ld_dst,
+                "copy_channel_bf16: bad arguments");
+  clear_stale_error();
+  hipLaunchKernelGGL(copy_channel_bf16_kernel, dim3((unsigned)std::min<size_t>((npix + 255) / 256, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, static_cast<__bf16*>(dst), npix, ld_src, c_src, ld_dst, c_dst);
+  return check_launch("copy_channel_bf16");
+}
+
+int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,
+                                int lddy, float* dx, int relu_mask, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && argmax && y && dy && dx && ldy >= c && lddy >= c,
+                "maxpool_bwd_idx_bf16: bad arguments");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * c;
+  clear_stale_error();
+  hipLaunchKernelGGL(maxpool_bwd_idx_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     argmax, static_cast<const __bf16*>(y), static_cast<const __bf16*>(dy), dx, n, h, w, c, h / 2, w / 2, ldy,
+                     lddy, relu_mask);
+  return check_launch("maxpool_bwd_idx_bf16");
 }
 
 int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, const float* y, int ldy, const float* dy,

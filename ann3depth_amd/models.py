@@ -125,6 +125,14 @@ class MSDNReplica:
         # (ops.dense_bwd_filter_adam_tf1) and is never written; grad('coarse/dense/...') is then stale.  A data-parallel
         # replica needs the gradient for its all-reduce and always keeps it.
         self.keep_dense_grads = keep_dense_grads or reducer is not None or batchsize > 64
+        # 'bf16s' = BASELINE config 5 proper: bf16 arithmetic AND bf16 storage — the conv stacks' activations and their
+        # gradients, and a bf16 copy of every kernel with at least 8 input channels, live in HBM as bf16; fp32 stay the
+        # master weights, the Adam slots, all filter / bias gradients and split-K slabs, the resized input, the 3-channel
+        # layers' filters, fine/second's output (fine/third is a single-output-channel stencil on fp32), and the
+        # tensors of the dense layers' small side (x, y, dz, dx: a few MB; dense_0's 201 MB of weights are read as bf16).
+        self.bf16s = precision == 'bf16s'
+        if self.bf16s:
+            precision = 'bf16'
         self.precision = precision
         self.B = B = batchsize
         self.device = torch.device(device)
@@ -167,17 +175,20 @@ class MSDNReplica:
 
         def buf(*shape):
             return torch.empty(shape, device=dev)
+
+        def abuf(*shape):           # an activation (or activation gradient) of the conv stacks: bf16 under 'bf16s'
+            return torch.empty(shape, device=dev, dtype=torch.bfloat16 if self.bf16s else torch.float32)
         self.conv = {c.name: c for c in MSDN_CONVS}
         # activations
         self.x = buf(B, NET_H, NET_W, 3)
         self.t = buf(B, OUT_H, OUT_W, 1)
-        self.c0 = buf(B, 55, 74, 96); self.p0 = buf(B, 27, 37, 96)
-        self.c1 = buf(B, 27, 37, 256); self.p1 = buf(B, 13, 18, 256)
-        self.c2 = buf(B, 13, 18, 384); self.c3 = buf(B, 13, 18, 384); self.c4 = buf(B, 6, 8, 256)
+        self.c0 = buf(B, 55, 74, 96) if not self.bf16s else None; self.p0 = abuf(B, 27, 37, 96)
+        self.c1 = abuf(B, 27, 37, 256); self.p1 = abuf(B, 13, 18, 256)
+        self.c2 = abuf(B, 13, 18, 384); self.c3 = abuf(B, 13, 18, 384); self.c4 = abuf(B, 6, 8, 256)
         self.drop = buf(B, 4096)
         self.coarse = buf(B, OUT_H, OUT_W, 1)
-        self.f1 = buf(B, 110, 148, 63)
-        self.cat = buf(B, OUT_H, OUT_W, 64)
+        self.f1 = buf(B, 110, 148, 63) if not self.bf16s else None        # 'bf16s': never written (fused with its pool)
+        self.cat = abuf(B, OUT_H, OUT_W, 64)
         self.f2 = buf(B, OUT_H, OUT_W, 64)
         self.fine = buf(B, OUT_H, OUT_W, 1)
         self.loss_coarse = buf(1); self.loss_fine = buf(1)
@@ -189,11 +200,13 @@ class MSDNReplica:
         self.ws_c = torch.zeros(2 * B + 1, device=dev); self.ws_f = torch.zeros(2 * B + 1, device=dev)   # + arrival ticket
         # gradients wrt pre-activations
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
-        self.dc4 = buf(B, 6, 8, 256); self.dc3 = buf(B, 13, 18, 384); self.dc2 = buf(B, 13, 18, 384)
-        self.dp1 = buf(B, 13, 18, 256); self.dc1 = buf(B, 27, 37, 256)
-        self.dp0 = buf(B, 27, 37, 96); self.dc0 = buf(B, 55, 74, 96)
+        self.dc4 = abuf(B, 6, 8, 256); self.dc3 = abuf(B, 13, 18, 384); self.dc2 = abuf(B, 13, 18, 384)
+        self.dp1 = abuf(B, 13, 18, 256); self.dc1 = abuf(B, 27, 37, 256)
+        self.dp0 = abuf(B, 27, 37, 96); self.dc0 = buf(B, 55, 74, 96)
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = buf(B, OUT_H, OUT_W, 64)
-        self.dcat = buf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
+        self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
+        if self.bf16s:
+            self.c4_32 = buf(B, 6, 8, 256); self.dc4_32 = buf(B, 6, 8, 256)      # the dense layers' fp32 side of c4 / dc4
         # descriptors
         def D(*a):
             return ops.conv_desc(*a, precision=precision)
@@ -207,6 +220,42 @@ class MSDNReplica:
             'fine/second/conv2d': D(B, OUT_H, OUT_W, 64, 64, 5, 5, 1, 'SAME'),
             'fine/third': D(B, OUT_H, OUT_W, 64, 1, 5, 5, 1, 'SAME'),
         }
+        # bf16 storage: per layer, which tensors of the forward / bwd-data / bwd-filter call are bf16 (ops.STORE_*), and
+        # the bf16 copies of the kernels (refreshed whenever the fp32 masters change)
+        self.store = {}
+        self.wcopy = {}
+        if self.bf16s:
+            X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+            for n in ('coarse/conv/conv2d_1', 'coarse/conv/conv2d_2', 'coarse/conv/conv2d_3', 'coarse/conv/conv2d_4'):
+                self.store[n] = {'fwd': X | W | Y, 'bwd_d': X | W | Y, 'bwd_f': X | Y}
+            # the two 3-channel layers (15 % of the FLOPs) take the fp32 image and keep fp32 arithmetic: conv + ReLU + max
+            # pool in one kernel, of which only the pooled map (bf16) and an argmax byte per window reach HBM — c0 / f1,
+            # the largest activations of the model, are never written; their gradient comes back fp32
+            for n in ('coarse/conv/conv2d_0', 'fine/first/conv2d'):
+                self.d[n] = ops.with_storage(self.d[n], 0)
+                self.d[n].precision = ops.PREC['fp32']
+                self.store[n] = {'fwd': Y, 'bwd_d': 0, 'bwd_f': 0}
+            self.store['fine/second/conv2d'] = {'fwd': X | W, 'bwd_d': W | X, 'bwd_f': X}     # f2 / df2 stay fp32
+            for n in list(self.store) + ['coarse/dense/dense_0']:
+                if n == 'coarse/dense/dense_0' or self.store[n]['fwd'] & W:
+                    self.wcopy[n] = torch.empty(self.shapes[n + '/kernel'], device=dev, dtype=torch.bfloat16)
+            self.refresh_weight_copies()
+
+    def _desc(self, name, which):
+        """The layer's conv descriptor for 'fwd' | 'bwd_d' | 'bwd_f', with that call's storage bits."""
+        d = self.d[name]
+        bits = self.store.get(name, {}).get(which, 0)
+        return ops.with_storage(d, bits) if bits else d
+
+    def _w(self, name, which='fwd'):
+        """The kernel a conv / dense call reads: the bf16 copy where this call takes one, else the fp32 master."""
+        if name in self.wcopy and (name not in self.store or self.store[name][which] & ops.STORE_W):
+            return self.wcopy[name]
+        return self._v(name + '/kernel')
+
+    def refresh_weight_copies(self):
+        for n, c in self.wcopy.items():
+            ops.cast_bf16(self._v(n + '/kernel'), c)
 
     # ---- variables ----
     def settle(self):
@@ -226,6 +275,8 @@ class MSDNReplica:
             a = np.asarray(params[n], np.float32)
             assert a.shape == tuple(shp), (n, a.shape, shp)
             g.view(g.var, n).copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        if getattr(self, 'wcopy', None):
+            self.refresh_weight_copies()
 
     def _v(self, name):
         g = self.groups[self.group_of[name]]
@@ -341,8 +392,20 @@ class MSDNReplica:
         return self._v(name + '/kernel'), self._v(name + '/bias')
 
     def _conv(self, name, x, y):
-        w, b = self._kb(name)
-        ops.conv2d_fwd(self.d[name], x, w, b, y, 'relu' if self.conv[name].relu else None)
+        ops.conv2d_fwd(self._desc(name, 'fwd'), x, self._w(name), self._v(name + '/bias'), y,
+                       'relu' if self.conv[name].relu else None)
+
+    def _pool(self, x, y, extra=None, c=None):
+        if self.bf16s:
+            ops.maxpool2x2_fwd_bf16(x, y, extra=extra, c=c)
+        else:
+            ops.maxpool2x2_fwd(x, y, extra=extra)
+
+    def _pool_bwd(self, x, dy, dx, c=None):
+        if self.bf16s:
+            ops.maxpool2x2_bwd_bf16(x, dy, dx, relu_mask=True, c=c)
+        else:
+            ops.maxpool2x2_bwd(x, dy, dx, relu_mask=True)
 
     @contextlib.contextmanager
     def _beside(self):
@@ -366,8 +429,11 @@ class MSDNReplica:
         src = {'c0': (self.c0, self.p0, self.a0, 1), 'c1': (self.c1, self.p1, self.a1, 1),
                'f1': (self.f1, self.cat, self.af1, 2)}[which]
         full, pooled, arg, phase = src
-        if self.pooled_fwd != phase:
+        if self.pooled_fwd != phase and not (self.bf16s and which in ('c0', 'f1')):
             return full
+        if full is None:          # 'bf16s': the tensor does not exist at all
+            full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'f1': (110, 148, 63)}[which], device=self.device)
+        pooled = pooled.float()
         c = arg.shape[-1]
         out = torch.zeros_like(full)
         ph, pw = arg.shape[1], arg.shape[2]
@@ -379,7 +445,7 @@ class MSDNReplica:
 
     def _conv_pool(self, name, x, y_pooled, argmax=None):
         w, b = self._kb(name)
-        ops.conv2d_pool_fwd(self.d[name], x, w, b, y_pooled, 'relu', argmax)
+        ops.conv2d_pool_fwd(self._desc(name, 'fwd'), x, w, b, y_pooled, 'relu', argmax)
 
     def forward(self, images, depths, keep_mask, join=True, phase=None):
         """join=False leaves the fine network's forward in flight on the side stream (step() joins later).
@@ -397,29 +463,40 @@ class MSDNReplica:
             train = phase == 1
             self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0 if train else None)
             self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1 if train else None)
+        elif self.bf16s:
+            self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0)
+            self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
+            self._pool(self.c1, self.p1)
         else:
             self._conv('coarse/conv/conv2d_0', self.x, self.c0)
-            ops.maxpool2x2_fwd(self.c0, self.p0)
+            self._pool(self.c0, self.p0)
             self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
-            ops.maxpool2x2_fwd(self.c1, self.p1)
+            self._pool(self.c1, self.p1)
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
         with self._beside():        # beside the two weight-streaming dense layers
             if lean_fine:
                 self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
+            elif self.bf16s:
+                self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
             else:
                 self._conv('fine/first/conv2d', self.x, self.f1)
         self.settle()               # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
-        ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
+        if self.bf16s:              # c4 crosses to the dense layers' fp32 side; dense_0 reads its 100 MB bf16 weight copy
+            ops.cast_bf16(self.c4, self.c4_32)
+            ops.dense_fwd_ex(self.c4_32.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
+                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W)
+        else:
+            ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
         ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
         with self._beside():
-            if lean_fine:
+            if lean_fine or self.bf16s:
                 ops.copy_channel(self.coarse, 0, self.cat, 63)                                # tf.concat([pool, coarse])
             else:
-                ops.maxpool2x2_fwd(self.f1, self.cat, extra=self.coarse)                      # pool + concat fused
+                self._pool(self.f1, self.cat, extra=self.coarse, c=63)                        # pool + concat fused
             self._conv('fine/second/conv2d', self.cat, self.f2)
             self._conv('fine/third', self.f2, self.fine)
             ops.silog_loss_fwd(self.fine, self.t, self.loss_fine, self.ws_f)
@@ -430,9 +507,12 @@ class MSDNReplica:
     def _fused_dense_adam(self):
         return not self.keep_dense_grads and self.groups['CoarseDense'].frozen()
 
+    def _bwd_data(self, name, dz, dx, relu_mask=None):
+        ops.conv2d_bwd_data(self._desc(name, 'bwd_d'), dz, self._w(name, 'bwd_d'), dx, relu_mask=relu_mask)
+
     def _bwd_filter(self, name, x, dz):
         if name in self.d:
-            ops.conv2d_bwd_filter(self.d[name], x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
+            ops.conv2d_bwd_filter(self._desc(name, 'bwd_f'), x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
         elif self._fused_dense_adam():
             g = self.groups[self.group_of[name + '/kernel']]
             kw = [g.view(buf, name + '/kernel') for buf in (g.var, g.m, g.v)]
@@ -453,34 +533,39 @@ class MSDNReplica:
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
         ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
         n = 'coarse/dense/dense_0'
-        flat = self.c4.view(B, -1)
+        flat = (self.c4_32 if self.bf16s else self.c4).view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
-        ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
+        if self.bf16s:
+            ops.dense_bwd_data_ex(self.dz0, self.wcopy[n], self.dc4_32.view(B, -1), mask=flat, scale=1.0, precision='bf16',
+                                  storage=ops.STORE_W)
+            ops.cast_bf16(self.dc4_32, self.dc4)
+        else:
+            ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:
             after_dense()          # dense gradients are complete: their all-reduce can overlap the conv backward
         n = 'coarse/conv/conv2d_4'
         self._bwd_filter(n, self.c3, self.dc4)
-        ops.conv2d_bwd_data(self.d[n], self.dc4, self._v(n + '/kernel'), self.dc3, relu_mask=self.c3)
+        self._bwd_data(n, self.dc4, self.dc3, relu_mask=self.c3)
         self._join()               # the fine forward has had the dense / conv2d_4 stretch; the big GEMMs below run alone
         n = 'coarse/conv/conv2d_3'
         self._bwd_filter(n, self.c2, self.dc3)
-        ops.conv2d_bwd_data(self.d[n], self.dc3, self._v(n + '/kernel'), self.dc2, relu_mask=self.c2)
+        self._bwd_data(n, self.dc3, self.dc2, relu_mask=self.c2)
         n = 'coarse/conv/conv2d_2'
         self._bwd_filter(n, self.p1, self.dc2)
         if after_conv2 is not None:
             after_conv2()          # gradients of conv2d_2..4 (the tail of the CoarseConv buffer) are complete
-        ops.conv2d_bwd_data(self.d[n], self.dc2, self._v(n + '/kernel'), self.dp1)
+        self._bwd_data(n, self.dc2, self.dp1)
         if self.pooled_fwd == 1:
             ops.maxpool2x2_bwd_idx(self.a1, self.p1, self.dp1, self.dc1, relu_mask=True)
         else:
-            ops.maxpool2x2_bwd(self.c1, self.dp1, self.dc1, relu_mask=True)
+            self._pool_bwd(self.c1, self.dp1, self.dc1)
         n = 'coarse/conv/conv2d_1'
         self._bwd_filter(n, self.p0, self.dc1)
-        ops.conv2d_bwd_data(self.d[n], self.dc1, self._v(n + '/kernel'), self.dp0)
-        if self.pooled_fwd == 1:
+        self._bwd_data(n, self.dc1, self.dp0)
+        if self.pooled_fwd == 1 or self.bf16s:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:
-            ops.maxpool2x2_bwd(self.c0, self.dp0, self.dc0, relu_mask=True)
+            self._pool_bwd(self.c0, self.dp0, self.dc0)
         n = 'coarse/conv/conv2d_0'
         self._bwd_filter(n, self.x, self.dc0)
 
@@ -490,14 +575,14 @@ class MSDNReplica:
         ops.silog_loss_bwd(self.fine, self.t, self.ws_f, self.dfine)
         n = 'fine/third'
         self._bwd_filter(n, self.f2, self.dfine)
-        ops.conv2d_bwd_data(self.d[n], self.dfine, self._v(n + '/kernel'), self.df2, relu_mask=self.f2)
+        self._bwd_data(n, self.dfine, self.df2, relu_mask=self.f2)
         n = 'fine/second/conv2d'
         self._bwd_filter(n, self.cat, self.df2)
-        ops.conv2d_bwd_data(self.d[n], self.df2, self._v(n + '/kernel'), self.dcat)
-        if self.pooled_fwd == 2:                                               # both read channels 0..62 of dcat
+        self._bwd_data(n, self.df2, self.dcat)
+        if self.pooled_fwd == 2 or self.bf16s:                                 # both read channels 0..62 of dcat
             ops.maxpool2x2_bwd_idx(self.af1, self.cat, self.dcat, self.df1, relu_mask=True)
         else:
-            ops.maxpool2x2_bwd(self.f1, self.dcat, self.df1, relu_mask=True)
+            self._pool_bwd(self.f1, self.dcat, self.df1, c=63)
         n = 'fine/first/conv2d'
         self._bwd_filter(n, self.x, self.df1)
 

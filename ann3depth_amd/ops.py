@@ -59,7 +59,10 @@ def same_pad(in_size, k, stride):
     return out, pad // 2
 
 
-def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32'):
+STORE_X, STORE_W, STORE_Y = 1, 2, 4      # a3d_conv_desc.storage bits: which tensors are bf16 in memory
+
+
+def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32', storage=0):
     """Descriptor of tf.layers.conv2d(x[n,h,w,c], k, (r,s), (stride,stride), padding).  precision selects the
     arithmetic of the contraction: 'fp32' (exact, default), 'bf16x3' (split operands) or 'bf16'."""
     padding = padding.upper()
@@ -72,7 +75,7 @@ def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precisio
     else:
         raise ValueError(padding)
     return ConvDesc(n=n, h=h, w=w, c=c, k=k, r=r, s=s, stride=stride, pad_t=pt, pad_l=pl, ho=ho, wo=wo,
-                    ldx=ldx or c, ldy=ldy or k, precision=PREC[precision])
+                    ldx=ldx or c, ldy=ldy or k, precision=PREC[precision], storage=storage)
 
 
 def conv2d_fwd(d, x, w, bias, y, act=None):
@@ -97,6 +100,12 @@ def maxpool2x2_bwd_idx(argmax, y_pooled, dy, dx, relu_mask=True):
     """MaxPoolGrad (+ ReluGrad) from the argmax positions and pooled values of conv2d_pool_fwd; dx [n,h,w,c] dense,
     y_pooled / dy: last dim = pixel stride (>= c)."""
     n, h, w, c = dx.shape
+    if y_pooled.dtype == torch.bfloat16:         # bf16 storage: pooled values and dy bf16, dx float32
+        assert dy.dtype == torch.bfloat16 and dx.dtype == torch.float32
+        check(_lib.load().a3d_maxpool2x2_bwd_idx_bf16(n, h, w, c, _ptr(argmax), _ptr(y_pooled), y_pooled.shape[-1], _ptr(dy),
+                                                      dy.shape[-1], _ptr(dx), int(relu_mask), _stream()),
+              'a3d_maxpool2x2_bwd_idx_bf16')
+        return dx
     check(_lib.load().a3d_maxpool2x2_bwd_idx(n, h, w, c, _ptr(argmax), _ptr(y_pooled), y_pooled.shape[-1], _ptr(dy),
                                              dy.shape[-1], _ptr(dx), int(relu_mask), _stream()),
           'a3d_maxpool2x2_bwd_idx')
@@ -107,8 +116,8 @@ def copy_channel(src, c_src, dst, c_dst):
     """dst[..., c_dst] = src[..., c_src] (same pixel count; last dims are the pixel strides)."""
     npix = src.numel() // src.shape[-1]
     assert dst.numel() // dst.shape[-1] == npix
-    check(_lib.load().a3d_copy_channel(npix, _ptr(src), src.shape[-1], c_src, _ptr(dst), dst.shape[-1], c_dst,
-                                       _stream()), 'a3d_copy_channel')
+    fn = _lib.load().a3d_copy_channel_bf16 if dst.dtype == torch.bfloat16 else _lib.load().a3d_copy_channel
+    check(fn(npix, _ptr(src), src.shape[-1], c_src, _ptr(dst), dst.shape[-1], c_dst, _stream()), 'a3d_copy_channel')
     return dst
 
 
@@ -219,6 +228,65 @@ def dense_bwd_filter_adam_tf1(x, dz, var_w, m_w, v_w, var_b, m_b, v_b, lr, beta1
     check(_lib.load().a3d_dense_bwd_filter_adam_tf1(m, k, n, _ptr(x), _ptr(dz), _ptr(var_w), _ptr(m_w), _ptr(v_w),
                                                     _ptr(var_b), _ptr(m_b), _ptr(v_b), lr, beta1, beta2, beta1_power,
                                                     beta2_power, grad_scale, _stream()), 'a3d_dense_bwd_filter_adam_tf1')
+
+
+def with_storage(d, storage):
+    """Copy of a conv descriptor with other storage bits (forward / bwd-data / bwd-filter mark different tensors)."""
+    e = ConvDesc()
+    ctypes.pointer(e)[0] = d
+    e.storage = storage
+    return e
+
+
+def _dense_ws(lib, m, k, n, precision, storage, device):
+    d = conv_desc(m, 1, 1, k, n, 1, 1, 1, 'VALID', precision=precision)
+    need = max(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)))
+    return _ws().get(need, device)
+
+
+def dense_fwd_ex(x, w, bias, y, act=None, drop_keep=None, precision='fp32', storage=0):
+    """dense_fwd with the arithmetic / weight storage of BASELINE config 5 (w may be the layer's bf16 copy)."""
+    m, k = x.shape
+    n = y.shape[1]
+    lib = _lib.load()
+    ws, nb = _dense_ws(lib, m, k, n, precision, storage, x.device)
+    check(lib.a3d_dense_fwd_ex(m, k, n, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], _ptr(drop_keep), PREC[precision],
+                               storage, ws, nb, _stream()), 'a3d_dense_fwd_ex')
+    return y
+
+
+def dense_bwd_data_ex(dz, w, dx, mask=None, mask_act='relu', scale=1.0, precision='fp32', storage=0):
+    m, n = dz.shape
+    k = dx.shape[1]
+    lib = _lib.load()
+    ws, nb = _dense_ws(lib, m, k, n, precision, storage, dz.device)
+    check(lib.a3d_dense_bwd_data_ex(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), ACT[mask_act], scale, PREC[precision],
+                                    storage, ws, nb, _stream()), 'a3d_dense_bwd_data_ex')
+    return dx
+
+
+def cast_bf16(src, dst):
+    """float32 -> bfloat16 or back, by dst's dtype (round to nearest even)."""
+    assert src.numel() == dst.numel() and {src.dtype, dst.dtype} == {torch.float32, torch.bfloat16}
+    check(_lib.load().a3d_cast_bf16(src.numel(), _ptr(src), _ptr(dst), int(dst.dtype == torch.bfloat16), _stream()),
+          'a3d_cast_bf16')
+    return dst
+
+
+def maxpool2x2_fwd_bf16(x, y, extra=None, c=None):
+    """bf16 tensors; x's and y's last dims are their pixel strides, c (default: x's) the channels pooled."""
+    n, h, w, ldx = x.shape
+    check(_lib.load().a3d_maxpool2x2_fwd_bf16(n, h, w, c or ldx, _ptr(x), ldx, _ptr(y), y.shape[-1], _ptr(extra), _stream()),
+          'a3d_maxpool2x2_fwd_bf16')
+    return y
+
+
+def maxpool2x2_bwd_bf16(x, dy, dx, relu_mask=True, c=None):
+    n, h, w, ldx = x.shape
+    assert dx.shape == x.shape
+    check(_lib.load().a3d_maxpool2x2_bwd_bf16(n, h, w, c or ldx, _ptr(x), ldx, _ptr(dy), dy.shape[-1], _ptr(dx),
+                                              int(relu_mask), _stream()), 'a3d_maxpool2x2_bwd_bf16')
+    return dx
 
 
 def sgd_apply(var, g, lr):

@@ -154,6 +154,41 @@ def cpu_baseline(seconds_budget=25.0):
                       f'{threads} OpenBLAS threads on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
 
 
+def hbm_bytes_bf16_storage(B):
+    """Algorithmic HBM bytes of one coarse-phase step under precision 'bf16s' (BASELINE config 5: 2-byte activations and
+    weight copies), by SURVEY 8d's accounting rule: every tensor is counted once per pass that must read or write it —
+    an activation once when produced and once per consumer pass, weights once per pass that uses them, the frozen
+    ApplyAdam as read g + read m + write m (conv group) or read m + write m (dense kernels, gradient never stored)."""
+    f4, b2 = 4, 2
+    px = lambda h, w, c, e: h * w * c * e
+    per_image = (
+        px(480, 640, 3, f4) + px(480, 640, 1, f4)                  # stored record, read by the resize
+        + 3 * px(228, 304, 3, f4) + 3 * px(55, 74, 1, f4)          # x: written, read by conv2d_0 fwd, fine/first fwd (+ conv2d_0 bwd-filter: below); t: written, read by both losses
+        + px(228, 304, 3, f4)                                      # x again: conv2d_0 bwd-filter
+        # forward activations, written once and read once by the next layer (bf16): p0, c1, p1, c2, c3, c4, cat; f2 fp32
+        + 2 * (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
+               + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4)
+        + px(27, 37, 96, 1)                                        # argmax bytes of conv2d_0's pool (a0), written
+        # backward of coarse/*: each stored activation read again (bwd-filter A operand / ReLU mask), each activation
+        # gradient written once and read by bwd-filter and bwd-data of the layer below (2 reads)
+        + (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
+        + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
+        + px(27, 37, 96, 1) + 2 * px(55, 74, 96, f4)               # a0 read; dc0 (fp32) written + read
+        + 6 * 4096 * f4 + 6 * 4070 * f4                            # dense side tensors (drop, coarse, dz0, dz1, ...)
+    )
+    conv_w = 34944 + 614656 + 885120 + 1327488 + 884992            # coarse/conv parameters
+    fine_w = 15372 + 102464 + 1601
+    d0, d1 = 12288 * 4096 + 4096, 4096 * 4070 + 4070
+    per_step = (
+        2 * (conv_w - 34944) * b2 + 2 * 34944 * f4                 # conv kernels: bf16 copies in fwd and bwd-data (conv2d_0: fp32)
+        + fine_w * f4                                              # fine network forward
+        + 2 * d0 * b2 + 2 * d1 * f4                                # dense_0 bf16 copy / dense_1 fp32, fwd and bwd-data
+        + conv_w * f4 * (1 + 3)                                    # conv dW written; ApplyAdam: g, m read, m written
+        + (d0 + d1) * f4 * 2                                       # dense dW -> m slot in place: m read, m written
+    )
+    return B * per_image + per_step
+
+
 def bench_dcnf(args, lib, device, rank, world):
     """BASELINE config 4: DCNF-lite unary conv stack (src/models.py:50-89), batch 16 -> 768 patches of 100x100x3.
     A step = unary forward (resize, patches, 5 conv / 3 pool / 3 dense) + unary backward from a synthetic dz: 2.672 GFLOP
@@ -234,7 +269,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE config 2/3: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16', 'bf16s'],
                     help='conv arithmetic; the headline (and parity) mode is fp32')
     ap.add_argument('--also', default='bf16x3', help='comma list of extra precisions measured after the headline run')
     ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
@@ -266,6 +301,13 @@ def main():
     dt, recs = run_phase(net, img, dep, masks, args.steps, args.warmup, 0, lib, world, timed_kernels=True)
     value = world * B * args.steps / dt
     roof, table = roofline_from(recs)
+    if args.precision == 'bf16s':
+        # the bf16 matrix cores leave this step HBM-bound: price the whole step against the HBM roofline
+        nbytes = hbm_bytes_bf16_storage(B)
+        roof = {'bound': 'hbm', 'scope': 'coarse-phase step, 2-byte activations and weight copies (hbm_bytes_bf16_storage)',
+                'achieved': round(nbytes / (dt / args.steps) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(nbytes / (dt / args.steps) / 8e12, 4), 'traffic': None,
+                'bytes_per_step': nbytes, 'bytes_per_image': round((nbytes) / B)}
     extra = {}
     if not args.no_fine:
         dtf, _ = run_phase(net, img, dep, masks, args.steps, min(args.warmup, 2), models.SAMPLES_COARSE // B, lib,
@@ -285,7 +327,7 @@ def main():
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.precision, args.precision),
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16s': 'bf16'}.get(args.precision, args.precision),
             'data': 'synthetic',
             'config': {'workload': f'MSDN coarse+fine, batch {B} per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
                                    'coarse-phase train step (global_step 0): both forwards + both losses, backward of '

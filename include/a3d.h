@@ -44,12 +44,23 @@ typedef struct a3d_conv_desc {
   int32_t ho, wo;            /* output [n,ho,wo,k] */
   int32_t ldx;               /* elements between consecutive input pixels  (>= c; c if dense-packed) */
   int32_t ldy;               /* elements between consecutive output pixels (>= k) */
-  int32_t precision;         /* A3D_PREC_*: arithmetic of the contraction (tensors are float32 in memory either way) */
+  int32_t precision;         /* A3D_PREC_*: arithmetic of the contraction */
+  int32_t storage;           /* A3D_STORE_* bits: which tensors are bf16 in memory (0: all float32); needs A3D_PREC_BF16 */
 } a3d_conv_desc;
+
+/* BASELINE config 5 ("bf16 activations + bf16 weight copies, fp32 master and accumulate"): tensors marked here are bf16 in
+ * HBM (pass their pointers through the float* parameters); channel counts and pixel strides of a bf16 tensor must be
+ * multiples of 8 and its base 16-byte aligned.  Filter / bias gradients, split-K slabs and biases are always float32.
+ *   forward      : X = x, W = w, Y = y
+ *   bwd_data     : Y = dz, W = w, X = dx and relu_mask (the same activation tensor)
+ *   bwd_filter   : X = x, Y = dz (dw, db float32)                                                     */
+#define A3D_STORE_X_BF16 1
+#define A3D_STORE_W_BF16 2
+#define A3D_STORE_Y_BF16 4
 
 #define A3D_PREC_F32 0     /* exact fp32 on the fp32 matrix cores (default; what parity is stated for) */
 #define A3D_PREC_BF16X3 1  /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product: ~1e-5 relative */
-#define A3D_PREC_BF16 2    /* operands rounded to bf16, fp32 accumulate (BASELINE config 5) */
+#define A3D_PREC_BF16 2    /* operands rounded to bf16, fp32 accumulate (BASELINE config 5's arithmetic; storage: a3d_conv_desc.storage) */
 
 const char* a3d_version(void);
 int a3d_last_error(char* buf, size_t len);
@@ -63,7 +74,8 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
  * y_pooled[n, ho/2, wo/2, k] (pixel stride ld_pooled >= k) = 2x2 / stride-2 VALID max pool of act(conv + bias); the conv
  * output itself is never written.  argmax (may be NULL): [n, ho/2, wo/2, k] bytes, the position 0..3 (row-major in the
  * window) of the first maximum — all that MaxPoolGrad + ReluGrad need besides the pooled value, so training does not
- * need the conv output either (a3d_maxpool2x2_bwd_idx).  fp32 only; same workspace as a3d_conv2d_fwd. */
+ * need the conv output either (a3d_maxpool2x2_bwd_idx).  fp32 arithmetic and inputs only (storage A3D_STORE_Y_BF16: the
+ * pooled output is bf16); same workspace as a3d_conv2d_fwd. */
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
                         int ld_pooled, uint8_t* argmax, int act, void* ws, size_t ws_bytes, void* stream);
 
@@ -134,6 +146,32 @@ int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, cons
  * u from Philox4x32-10 keyed by (seed, step).  TF's own random stream is not reproducible, so parity tests pass
  * the mask in; the training driver draws it with this kernel. */
 int a3d_dropout_keep_mask(size_t count, uint64_t seed, uint64_t step, float rate, uint8_t* keep, void* stream);
+
+/* a3d_dense_fwd / a3d_dense_bwd_data with the arithmetic and storage of a3d_conv_desc: precision A3D_PREC_*, storage
+ * A3D_STORE_W_BF16 when w is the layer's bf16 weight copy (k and n multiples of 8).  x / dz / y / dx stay float32: at
+ * batch <= 64 they are a few MB against the layer's 100-200 MB of weights. */
+int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
+                     const uint8_t* drop_keep, int precision, int storage, void* ws, size_t ws_bytes, void* stream);
+int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
+                          float scale, int precision, int storage, void* ws, size_t ws_bytes, void* stream);
+
+/* float32 <-> bf16 (round to nearest even) of `count` elements: weight copies after ApplyAdam, and the two small tensors
+ * that cross between the bf16 conv stack and the float32 dense layers (to_bf16 != 0: src float32 -> dst bf16). */
+int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream);
+
+/* a3d_maxpool2x2_fwd / a3d_maxpool2x2_bwd on bf16 tensors (x, y, dy, dx bf16, pixel strides ldx / ldy / lddy >= c; `extra`, the concatenated channel, stays
+ * float32: it is the coarse network's output).  Same semantics, first maximum in scan order. */
+int a3d_maxpool2x2_fwd_bf16(int n, int h, int w, int c, const void* x, int ldx, void* y, int ldy, const float* extra,
+                            void* stream);
+int a3d_maxpool2x2_bwd_bf16(int n, int h, int w, int c, const void* x, int ldx, const void* dy, int lddy, void* dx,
+                            int relu_mask, void* stream);     /* dx has x's pixel stride */
+
+/* a3d_copy_channel into a bf16 tensor, and a3d_maxpool2x2_bwd_idx from bf16 pooled values / bf16 dy to a float32 dx: the
+ * fused conv + pool of the two 3-channel layers keeps fp32 arithmetic under bf16 storage and writes only its pooled map
+ * (bf16) and argmax bytes. */
+int a3d_copy_channel_bf16(size_t npix, const float* src, int ld_src, int c_src, void* dst, int ld_dst, int c_dst, void* stream);
+int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,
+                                int lddy, float* dx, int relu_mask, void* stream);
 
 /* dense_bwd_filter and ApplyAdam of one dense layer in ONE pass, for the optimizer the reference actually builds:
  * AdamOptimizer(rate, 0.9, beta2 = 1) (src/models.py:309) has alpha = 0 and 1 - beta2 = 0, so ApplyAdam moves only the
