@@ -209,7 +209,7 @@ struct IgemmCfg {
   static constexpr int B_LD = B_COLS + 4;
   static constexpr int A_ELEMS = A_ROWS * A_LD, B_ELEMS = B_ROWS * B_LD;
   static constexpr int PIX = A_ROWS;   // pixel-table entries (rows of the im2col tile)
-  static constexpr size_t LDS_BYTES = (size_t)(2 * (A_ELEMS + B_ELEMS)) * 4 + (size_t)2 * PIX * 16;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * (A_ELEMS + B_ELEMS)) * 4 + (size_t)3 * PIX * 16;
 };
 
 // ---- pixel table: one int4 per row of the im2col tile: {image base in pixels, y0, x0, valid} ----
@@ -560,7 +560,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   const float* a_base = p.A;
   unsigned long long a_bytes = 0;
   if constexpr (MODE == MODE_BWD_F) {
-    // pixel axis is K: tables for tiles kt_begin and kt_begin+1
+    // pixel axis is K: row tables of tiles kt_begin and kt_begin+1; three buffers indexed by (tile - kt_begin) % 3
     if (tid < 2 * Cfg::PIX) {
       const int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
       const int pix0 = (kt_begin + which) * BK;
@@ -602,47 +602,6 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     return t;
   };
 
-  auto issue_a = [&](int kt, int pbuf, bool live) {
-    if constexpr (MODE == MODE_BWD_F) {
-      const int pix0 = kt * BK;
-      const uint32_t nf = image_of(pix0);
-      const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pld;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.A + boff, live ? (p.a_elems - boff) * 4ull : 0ull);
-      if (!a_on) return;
-      const int4* ptab = pixtab + pbuf * Cfg::PIX;
-#pragma unroll
-      for (int j = 0; j < A_NL; ++j) {
-        const int4 pt = ptab[a_r0 + j * A_RPP];
-        const int y = pt.y + a_dy, x = pt.z + a_dx;
-        const bool ok = a_cvalid & (pt.w != 0) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
-        load_vec_buf<AVEC>(rs, ok ? (uint32_t)(pt.x + a_coloff) : kOOB, ra[j]);
-      }
-    } else {
-      int dy, dx, coloff;
-      bool cv = true;
-      if (p.uni) {
-        const TapPos t = tap_of(kt);
-        const uint32_t r = fdiv(t.rs, p.div_s), sx = t.rs - r * p.div_s.d;
-        dy = SGN * (int)r; dx = SGN * (int)sx;
-        coloff = ((dy * pW + dx) * pld + (int)t.chunk * BK) * 4;
-      } else {
-        const ColDec d = decode_col(p, kt * BK + a_cq * AVEC);
-        dy = SGN * d.r; dx = SGN * d.s;
-        coloff = ((dy * pW + dx) * pld + d.c) * 4;
-        cv = d.valid;
-      }
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(a_base, live ? a_bytes : 0ull);
-      if (!a_on) return;
-#pragma unroll
-      for (int j = 0; j < A_NL; ++j) {
-        // rows that do not exist carry y0 = INT_MIN/2 and fail the range test like any halo pixel
-        const int y = a_y0[j] + dy, x = a_x0[j] + dx;
-        const bool ok = cv & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
-        load_vec_buf<AVEC>(rs, ok ? (uint32_t)(a_rowoff[j] + coloff) : kOOB, ra[j]);
-      }
-    }
-  };
-
   // ---- B operand ----
   constexpr int B_CPR = BTile::CPR;
   uint32_t b_voff[BNL];                    // loop-invariant lane offsets (kOOB: outside the tensor's columns / rows)
@@ -664,19 +623,72 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       b_voff[j] = ok ? (uint32_t)((r * p.ldb + cq * BVEC) * 4) : kOOB;
     }
   }
-  auto issue_b = [&](int kt, bool live) {
+
+  // ---- state of the NEXT tile to fetch: lane offsets and the two descriptors.  prepare() computes it (scalar tap
+  // decode / row-table reads / a few VALU per row) and is placed in the shadow of the current tile's MFMAs; issue() at the
+  // top of an iteration is then nothing but the buffer loads.
+  uint32_t a_off[A_NL];
+  uint32_t b_off[BNL];
+  __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, 0), rsB = make_rsrc(p.B, 0);
+  auto prepare = [&](auto uni_c, auto fetch_c, int kt, int slot, bool live) {       // slot: row-table buffer of tile kt (BWD_F)
+    constexpr bool FETCH = decltype(fetch_c)::value;  // issue each load as soon as its offset exists (no state kept)
+    constexpr bool UNI = decltype(uni_c)::value;      // wave-uniform tap: hoisted out of the K loop (two loop bodies)
+    // ---------- A ----------
+    if constexpr (MODE == MODE_BWD_F) {
+      const int pix0 = kt * BK;
+      const uint32_t nf = image_of(pix0);
+      const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pld;
+      rsA = make_rsrc(p.A + boff, live ? (p.a_elems - boff) * 4ull : 0ull);
+      if (a_on) {
+        const int4* ptab = pixtab + slot * Cfg::PIX;
+#pragma unroll
+        for (int j = 0; j < A_NL; ++j) {
+          const int4 pt = ptab[a_r0 + j * A_RPP];
+          const int y = pt.y + a_dy, x = pt.z + a_dx;
+          const bool ok = a_cvalid & (pt.w != 0) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+          a_off[j] = ok ? (uint32_t)(pt.x + a_coloff) : kOOB;
+          if (FETCH) load_vec_buf<AVEC>(rsA, a_off[j], ra[j]);
+        }
+      }
+    } else {
+      int dy, dx, coloff;
+      bool cv = true;
+      if constexpr (UNI) {
+        const TapPos t = tap_of(kt);
+        const uint32_t r = fdiv(t.rs, p.div_s), sx = t.rs - r * p.div_s.d;
+        dy = SGN * (int)r; dx = SGN * (int)sx;
+        coloff = ((dy * pW + dx) * pld + (int)t.chunk * BK) * 4;
+      } else {
+        const ColDec d = decode_col(p, kt * BK + a_cq * AVEC);
+        dy = SGN * d.r; dx = SGN * d.s;
+        coloff = ((dy * pW + dx) * pld + d.c) * 4;
+        cv = d.valid;
+      }
+      rsA = make_rsrc(a_base, live ? a_bytes : 0ull);
+      if (a_on) {
+#pragma unroll
+        for (int j = 0; j < A_NL; ++j) {
+          // rows that do not exist carry y0 = INT_MIN/2 and fail the range test like any halo pixel
+          const int y = a_y0[j] + dy, x = a_x0[j] + dx;
+          const bool ok = cv & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+          a_off[j] = ok ? (uint32_t)(a_rowoff[j] + coloff) : kOOB;
+          if (FETCH) load_vec_buf<AVEC>(rsA, a_off[j], ra[j]);
+        }
+      }
+    }
+    // ---------- B ----------
     if constexpr (MODE == MODE_BWD_D) {
       // filter W[rs][cin][cout] read as rows = cin, columns = k = (rs, cout)
-      if (p.uni) {
+      if constexpr (UNI) {
         const TapPos t = tap_of(kt);
         // tap of the (sub-sampled, see sub_step) filter -> tap of the stored filter; the identity for plain launches
         const uint32_t rp = fdiv(t.rs, p.div_s), sp = t.rs - rp * p.div_s.d;
         const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
         const unsigned long long boff = (unsigned long long)rs * (unsigned long long)(p.Cn * p.Cg) +
                                         (unsigned long long)n0 * p.Cg + t.chunk * BK;
-        const __amdgpu_buffer_rsrc_t rsb = make_rsrc(p.B + boff, live ? (p.b_elems - boff) * 4ull : 0ull);
+        rsB = make_rsrc(p.B + boff, live ? (p.b_elems - boff) * 4ull : 0ull);
 #pragma unroll
-        for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsb, b_voff[j], rb[j]);
+        for (int j = 0; j < BNL; ++j) b_off[j] = b_voff[j];
       } else {
         const int kcol = kt * BK + b_cq * BVEC;
         const bool kvalid = kcol < p.K;
@@ -686,59 +698,60 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         const uint32_t rp = fdiv(rs0, p.div_s), sp = rs0 - rp * p.div_s.d;
         const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
         const uint32_t base = (rs * (uint32_t)(p.Cn * p.Cg) + (uint32_t)n0 * (uint32_t)p.Cg + (uint32_t)ko) * 4u;
-        const __amdgpu_buffer_rsrc_t rsb = make_rsrc(p.B, live ? p.b_elems * 4ull : 0ull);
+        rsB = make_rsrc(p.B, live ? p.b_elems * 4ull : 0ull);
 #pragma unroll
         for (int j = 0; j < BNL; ++j)
-          load_vec_buf<BVEC>(rsb, (kvalid && b_voff[j] != kOOB) ? base + (b_voff[j] - (uint32_t)(b_cq * BVEC * 4)) : kOOB, rb[j]);
+          b_off[j] = (kvalid && b_voff[j] != kOOB) ? base + (b_voff[j] - (uint32_t)(b_cq * BVEC * 4)) : kOOB;
       }
     } else {
       // plain [K][ldb] tile at rows row0.., columns n0..: the descriptor is re-based (scalar) and ends with the tensor's
       // row K-1, so rows of the K tail read as zeros
       int row0 = kt * BK;
-      if (MODE == MODE_FWD && p.uni) {
+      if constexpr (MODE == MODE_FWD && UNI) {
         const TapPos t = tap_of(kt);
         row0 = (int)(t.rs * (uint32_t)p.Cg + t.chunk * BK);
       }
-      const long long rows = (long long)p.K - row0;
-      const long long rec = rows > 0 ? (rows * p.ldb - n0) * 4ll : 0ll;
-      const __amdgpu_buffer_rsrc_t rsb =
-          make_rsrc(p.B + ((unsigned long long)row0 * (unsigned long long)p.ldb + (unsigned long long)n0),
-                    (live && rec > 0) ? (unsigned long long)rec : 0ull);
+      // selects, not branches: the K loop stays one basic block
+      const int rows = p.K - row0;
+      const long long rec = ((long long)(rows > 0 ? rows : 0) * p.ldb - n0) * 4ll;
+      rsB = make_rsrc(p.B + ((unsigned long long)row0 * (unsigned long long)p.ldb + (unsigned long long)n0),
+                      (unsigned long long)((live && rec > 0) ? rec : 0ll));
+    }
+    if (FETCH) {
 #pragma unroll
-      for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsb, b_voff[j], rb[j]);
+      for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsB, MODE == MODE_BWD_D ? b_off[j] : b_voff[j], rb[j]);
     }
   };
-
-#ifdef A3D_STAMPS
-  unsigned long long sA = 0, dA = 0;
-#endif
-  auto load_tiles = [&](int kt, int pbuf, bool live) {
-#ifdef A3D_STAMPS
-    unsigned long long t0_;
-    A3D_STAMP(t0_);
-    issue_a(kt, pbuf, live && !(p.dbg & 1));
-    A3D_STAMP(sA);
-    dA += sA - t0_;
-    issue_b(kt, live && !(p.dbg & 2));
-#else
-    issue_a(kt, pbuf, live);
-    issue_b(kt, live);
-#endif
+  auto issue = [&]() {
+    if (a_on) {
+#pragma unroll
+      for (int j = 0; j < A_NL; ++j) load_vec_buf<AVEC>(rsA, a_off[j], ra[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsB, MODE == MODE_BWD_D ? b_off[j] : b_voff[j], rb[j]);
   };
   auto store_tiles = [&](int buf) {
     ATile::store(ra, As + buf * Cfg::A_ELEMS, Cfg::A_LD, tid);
     BTile::store(rb, Bs + buf * Cfg::B_ELEMS, Cfg::B_LD, tid);
   };
 
+#ifdef A3D_STAMPS
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0;
+#endif
+  auto k_loop = [&](auto uni_c) {
+  // AHEAD: the next tile's addresses are computed one tile early, in the shadow of the MFMAs (forward / bwd-data: a
+  // handful of scalar operations).  The bwd-filter gather reads its row table from LDS and keeps more lane state; there
+  // the addresses are computed where they are used (measured: +4-7 % the other way round).
+  constexpr bool AHEAD = MODE != MODE_BWD_F;
   if (nkt > 0) {
-    load_tiles(kt_begin, 0, true);
+    prepare(uni_c, std::true_type{}, kt_begin, 0, true);
+    if (AHEAD) prepare(uni_c, std::false_type{}, kt_begin + 1, 1, nkt > 1);
     store_tiles(0);
   }
   __syncthreads();
 
   int cur = 0;
 #ifdef A3D_STAMPS
-  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0;
   A3D_STAMP(tbeg);
 #endif
   for (int it = 0; it < nkt; ++it) {
@@ -747,14 +760,15 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     A3D_STAMP(s0);
     // The staging instructions are few, but issued at priority 0 they queue behind the MFMAs of the three other waves of
     // this SIMD (stamps: 20-30 cycles per instruction); raised, they slip into the matrix pipe's 64-cycle shadows.
-    if (p.dbg & 4) __builtin_amdgcn_s_setprio(3);
-    load_tiles(kt + 1, (it + 1) & 1, more);      // branch-free: the descriptors of a tile that does not exist hold 0 records
+    if (AHEAD) issue();                          // tile kt+1 (a tile that does not exist: descriptors of 0 records)
+    else prepare(uni_c, std::true_type{}, kt + 1, (it + 1) % 3, more);
     __builtin_amdgcn_sched_barrier(0);           // the loads stay here: a whole tile of MFMAs ahead of their first use
-    if (p.dbg & 4) __builtin_amdgcn_s_setprio(0);
     A3D_STAMP(s1);
+    // addresses of tile kt+2: no dependence on anything below, free to sink among the MFMAs
+    if (AHEAD) prepare(uni_c, std::false_type{}, kt + 2, (it + 2) % 3, it + 2 < nkt);
     if (MODE == MODE_BWD_F) {
-      // table for tile kt+2 goes into the buffer tile kt used (all its loads were issued before the last barrier)
-      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = row_entry((kt + 2) * BK + tid, image_of((kt + 2) * BK));
+      // row table of tile kt+2 into the buffer tile kt-1 used (three buffers: tiles kt and kt+1 are still live)
+      if (tid < Cfg::PIX) pixtab[((it + 2) % 3) * Cfg::PIX + tid] = row_entry((kt + 2) * BK + tid, image_of((kt + 2) * BK));
     }
     const float* Ac = As + cur * Cfg::A_ELEMS;
     const float* Bc = Bs + cur * Cfg::B_ELEMS;
@@ -869,11 +883,18 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
 #endif
     cur ^= 1;
   }
+  };
+  if constexpr (MODE == MODE_BWD_F) {        // the tap belongs to the lane there: one loop body
+    k_loop(std::false_type{});
+  } else {
+    if (p.uni) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+  }
 #ifdef A3D_STAMPS
   A3D_STAMP(tend);
   if (p.stamps && lane == 0) {
     unsigned long long* o = p.stamps + ((size_t)bid_in * NWAVES + wave) * 16;
-    o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = dA;
+    o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = 0;
     o[8] = tbeg - t_entry; o[9] = t_entry; o[10] = tend;
   }
 #define A3D_STAMP_EXIT()                                                                                   \
