@@ -17,10 +17,10 @@
 #include <cstdlib>
 
 #include "a3d_internal.h"
+#include "igemm.h"
 
 namespace a3d {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A wave owns 32 weight rows x 32*CW columns.  Lane li takes dz[m][n0 + CW li .. + CW-1] with ONE 4*CW-byte load and
 // feeds the CW values to CW MFMAs, so accumulator j holds the columns n0 + CW li + j: the CW accumulators of a lane are
@@ -184,22 +184,48 @@ __global__ __launch_bounds__(256) void dense_dw_kernel(const float* __restrict__
 }
 
 // The Adam form of the big layers: the same contraction, but the block's 32 x 512 gradient tile crosses LDS so that the
-// m slot is read and written as WHOLE 2-KiB row segments (1 KiB contiguous per wave-instruction) instead of 512-byte
-// pieces 16 KB apart: the read-modify-write stream of a 201 MB slot is what this kernel costs, and HBM serves long runs
-// far better (measured on dense_0: 426 us with 256-byte pieces, 100 us with 512-byte pieces).  Needs N % 4 == 0.
+// m slot is read and written as WHOLE 2-KiB row segments (256*CW contiguous bytes per wave-instruction) instead of
+// 512-byte pieces 16 KB apart: the read-modify-write stream of a 201 MB slot is what this kernel costs, and HBM serves
+// long runs far better (measured on dense_0: 426 us with 256-byte pieces, 100 us with 512-byte pieces).  The wave's share
+// of the m tile is requested FIRST, so its HBM latency passes under the contraction (operands from L2) instead of after
+// it: the LDS tile allows two blocks per CU, so the registers that hold m across the contraction cost no occupancy.
+// CW = 4 needs N % 4 == 0 and 16-byte slots; CW = 2 serves rows of 8-byte alignment (dense_1: [4096, 4070]).
 constexpr int kRowsLd = 512 + 4;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifdef A3D_STAMPS
+__device__ unsigned long long g_dense_stamps[4096 * 4 * 8];       // diagnostic build: [block][wave][8]
+#endif
+template <int CW>
 __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                  float* __restrict__ var_w, float* __restrict__ m_w,
                                                                  float* __restrict__ v_w, float* __restrict__ var_b,
                                                                  float* __restrict__ m_b, float* __restrict__ v_b, int M,
                                                                  int K, int N, float omb1, float gscale) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float vec __attribute__((ext_vector_type(CW)));
+  constexpr int G = 4 / CW;              // column groups of 32*CW per wave (128 columns)
+  constexpr int NI = 512 / (64 * CW);    // wave-instructions per 2-KiB row segment
   __shared__ __attribute__((aligned(16))) float tile[32 * kRowsLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int nb = blockIdx.x * 512, n0 = nb + wave * 128, k0 = blockIdx.y * 32;
   const bool use_scale = gscale != 1.f;
   const float qnan = __builtin_nanf("");
+
+#ifdef A3D_STAMPS
+  unsigned long long s_t0, s_t1, s_t2, s_t3, s_t4, s_t5;
+#endif
+  A3D_STAMP(s_t0);
+  // this wave's share of the m tile: rows 8*wave .. 8*wave+7, NI pieces each
+  vec mold[8 * NI];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int h = 0; h < NI; ++h) {
+      const int row = k0 + wave * 8 + r, col = nb + (h * 64 + lane) * CW;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) mold[NI * r + h][j] = 0.f;
+      if (row < K && col < N) mold[NI * r + h] = *reinterpret_cast<const vec*>(m_w + (size_t)row * N + col);
+    }
 
   if (blockIdx.y == 0 && m_b != nullptr) {        // BiasAddGrad + its Adam step, two columns per thread
     for (int col = nb + tid; col < nb + 512 && col < N; col += 256) {
@@ -222,68 +248,84 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
     }
   }
 
-  f32x16 acc[4];
+  A3D_STAMP(s_t1);
+  f32x16 acc[G][CW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
-  const int krow = k0 + li, col0 = n0 + 4 * li;
-  const bool kok = krow < K, cok = col0 < N;       // N % 4 == 0: a lane's four columns exist together
+    for (int j = 0; j < CW; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[g][j][v] = 0.f;
+  const int krow = k0 + li;
+  const bool kok = krow < K;                       // N % CW == 0: a lane's CW columns exist together
+#ifdef A3D_DENSE_NOGEMM
+  const int T = 0;
+#else
   const int T = (M + 1) / 2;
+#endif
   for (int t0 = 0; t0 < T; t0 += 8) {
     float a[8];
-    f32x4 bq[8];
+    vec bq[8][G];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int m = 2 * (t0 + u) + lh;
       const bool mok = m < M;
       a[u] = (mok && kok) ? x[(size_t)m * K + krow] : 0.f;
-      bq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (mok && cok) bq[u] = *reinterpret_cast<const f32x4*>(dz + (size_t)m * N + col0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int col = n0 + (32 * g + li) * CW;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) bq[u][g][j] = 0.f;
+        if (mok && col < N) bq[u][g] = *reinterpret_cast<const vec*>(dz + (size_t)m * N + col);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bq[u][j], acc[j], 0, 0, 0);
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bq[u][g][j], acc[g][j], 0, 0, 0);
   }
-  // gradient tile -> LDS: register v of the four accumulators = columns 128*wave + 4*li .. +3 of row (v&3)+8*(v>>2)+4*lh
+  A3D_STAMP(s_t2);
+  // gradient tile -> LDS: register v of group g's CW accumulators = columns 128*wave + (32 g + li)*CW .. of row
+  // (v&3) + 8*(v>>2) + 4*lh
 #pragma unroll
-  for (int v = 0; v < 16; ++v)
-    *reinterpret_cast<f32x4*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * kRowsLd + wave * 128 + 4 * li]) =
-        (f32x4){acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
-  // this wave's share of the m tile — rows 8*wave .. 8*wave+7, two 1-KiB halves each — requested once the accumulators
-  // are in LDS: the kernel then never holds both (under 128 registers: four waves per SIMD hide the HBM latency, and the
-  // waves fit beside the GEMM blocks of the fine network that run on the second stream at the same time)
-  f32x4 mold[16];
+  for (int g = 0; g < G; ++g)
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
+    for (int v = 0; v < 16; ++v) {
+      vec t;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = k0 + wave * 8 + r, col = nb + h * 256 + lane * 4;
-      mold[2 * r + h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < K && col < N) mold[2 * r + h] = *reinterpret_cast<const f32x4*>(m_w + (size_t)row * N + col);
+      for (int j = 0; j < CW; ++j) t[j] = acc[g][j][v];
+      *reinterpret_cast<vec*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * kRowsLd + wave * 128 + (32 * g + li) * CW]) = t;
     }
   __syncthreads();
+  A3D_STAMP(s_t3);
+#ifdef A3D_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  A3D_STAMP(s_t4);
+#endif
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int lr = wave * 8 + r, row = k0 + lr, c = h * 256 + lane * 4, col = nb + c;
+    for (int h = 0; h < NI; ++h) {
+      const int lr = wave * 8 + r, row = k0 + lr, c = (h * 64 + lane) * CW, col = nb + c;
       if (row >= K || col >= N) continue;
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(&tile[lr * kRowsLd + c]);
+      const vec g4 = *reinterpret_cast<const vec*>(&tile[lr * kRowsLd + c]);
+      const vec mo = mold[NI * r + h];
       const size_t o = (size_t)row * N + col;
-      f32x4 mn;
+      vec mn;
       float chk = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < CW; ++j) {
         const float g = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
-        mn[j] = __fadd_rn(mold[2 * r + h][j], __fmul_rn(__fsub_rn(g, mold[2 * r + h][j]), omb1));
+        mn[j] = __fadd_rn(mo[j], __fmul_rn(__fsub_rn(g, mo[j]), omb1));
         chk += __fmul_rn(g, g) + fabsf(mn[j]);
       }
-      *reinterpret_cast<f32x4*>(m_w + o) = mn;
+      *reinterpret_cast<vec*>(m_w + o) = mn;
       if (!isfinite(chk)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CW; ++j) {
           const float g = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
           const bool poison = !isfinite(__fmul_rn(g, g));
           if (poison) v_w[o + j] = qnan;
@@ -291,6 +333,431 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
         }
       }
     }
+#ifdef A3D_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  A3D_STAMP(s_t5);
+  if (lane == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) {
+    unsigned long long* o = g_dense_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    o[0] = s_t0; o[1] = s_t1; o[2] = s_t2; o[3] = s_t3; o[4] = s_t4; o[5] = s_t5;
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); o[6] = hw;
+  }
+#endif
+}
+
+// The same update for batches of at most 32 rows, as a stream: a block keeps its 512 columns of dz in REGISTERS (64 per
+// lane) and walks down the weight rows, 32 at a time.  Measured on dense_0 with the kernel above: 87 us, and 56 us
+// (7.2 TB/s, the rate of an in-place multiply) with its contraction removed — the 64 KB of dz each tile re-read from L2
+// and the operand loads queued behind the m requests (loads return in order) cost more than the HBM stream itself.
+// Here dz is read once per block, and the next group's x rows and m tile are requested while the current group is
+// updated and stored, x FIRST, so that the contraction of the next group never waits on HBM.  Buffer loads and stores
+// throughout (rows and columns past the end go to the out-of-range offset): the loop body is straight-line code.
+template <int CW>
+__global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                      float* __restrict__ var_w, float* __restrict__ m_w,
+                                                                      float* __restrict__ v_w, float* __restrict__ var_b,
+                                                                      float* __restrict__ m_b, float* __restrict__ v_b,
+                                                                      int M, int K, int N, float omb1, float gscale,
+                                                                      int gpb) {
+  constexpr int G = 4 / CW, NI = 512 / (64 * CW);
+  typedef float vec __attribute__((ext_vector_type(CW)));
+  typedef uint32_t uvec __attribute__((ext_vector_type(CW)));
+  __shared__ __attribute__((aligned(16))) float tile[32 * kRowsLd];
+  __shared__ __attribute__((aligned(16))) float xs[32 * 32];        // x[batch row][weight row of the group]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int nb = blockIdx.x * 512, n0 = nb + wave * 128;
+  const int ngroups = (K + 31) / 32, g0 = blockIdx.y * gpb, g1 = min(g0 + gpb, ngroups);
+  const bool use_scale = gscale != 1.f;
+  const float qnan = __builtin_nanf("");
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned long long)M * K * 4);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(dz, (unsigned long long)M * N * 4);
+
+  // dz: lane's CW columns of group gq, batch rows 2u + lh
+  float bq[16][G][CW];
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      const int m = 2 * u + lh, col = n0 + (32 * gq + li) * CW;
+      load_vec_buf<CW>(rz, ((m < M) & (col < N)) ? (uint32_t)(((size_t)m * N + col) * 4) : kOOB, bq[u][gq]);
+    }
+  // x rows of a group: 32 batch rows x 32 weight rows = one 16-byte load per thread (K % 4 == 0)
+  const int xm = tid >> 3, xk = (tid & 7) * 4;
+  auto load_x = [&](float (&xv)[4], int g) {
+    const int krow = 32 * g + xk;
+    load_vec_buf<4>(rx, ((g < g1) & (xm < M) & (krow < K)) ? (uint32_t)(((size_t)xm * K + krow) * 4) : kOOB, xv);
+  };
+  // m tile of a group: this wave's rows 8*wave .. +7, NI pieces each.  One resource per row (scalar arithmetic: a row
+  // that does not exist gets zero records), one lane offset for all of them.
+  const int mcol = nb + lane * CW;
+  const uint32_t mvoff = mcol < N ? (uint32_t)mcol * 4u : kOOB;       // N % CW == 0; later pieces: + 256*CW bytes each
+  auto row_rsrc = [&](int g, int r) {
+    const int row = 32 * g + wave * 8 + r;
+    const bool ok = (g < g1) & (row < K);
+    return make_rsrc(m_w + (size_t)(ok ? row : 0) * N, ok ? (unsigned long long)N * 4 : 0ull);
+  };
+  auto piece_off = [&](int h) -> uint32_t { return nb + (h * 64 + lane) * CW < N ? mvoff + h * 256 * CW : kOOB; };
+  auto load_m = [&](float (&mo)[8 * NI][CW], int g) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const __amdgpu_buffer_rsrc_t rr = row_rsrc(g, r);
+#pragma unroll
+      for (int h = 0; h < NI; ++h) load_vec_buf<CW>(rr, piece_off(h), mo[NI * r + h]);
+    }
+  };
+
+  float xv[4], mreg[8 * NI][CW];
+  load_x(xv, g0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_m(mreg, g0);
+  *reinterpret_cast<f32x4v*>(&xs[xm * 32 + xk]) = (f32x4v){xv[0], xv[1], xv[2], xv[3]};
+
+  if (blockIdx.y == 0 && m_b != nullptr) {        // BiasAddGrad + its Adam step, two columns per thread
+    for (int col = nb + tid; col < nb + 512 && col < N; col += 256) {
+      float s = 0.f;
+      for (int m0 = 0; m0 < M; m0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = m0 + i < M ? dz[(size_t)(m0 + i) * N + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (m0 + i < M) s += t[i];
+      }
+      const float g = use_scale ? __fmul_rn(s, gscale) : s;
+      const float mo = m_b[col];
+      const float mn = __fadd_rn(mo, __fmul_rn(__fsub_rn(g, mo), omb1));
+      m_b[col] = mn;
+      const bool poison = !isfinite(__fmul_rn(g, g));
+      if (poison) v_b[col] = qnan;
+      if (poison || !isfinite(mn)) var_b[col] = qnan;
+    }
+  }
+  __syncthreads();
+
+  // one row group: contraction from xs / bq, tile through LDS, then row by row: update and store this group's m and
+  // request the next group's row INTO THE SAME REGISTERS (one m tile per lane, not two: the kernel fits 256 registers)
+  for (int g = g0; g < g1; ++g) {
+    f32x16 acc[G][CW];
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+      for (int j = 0; j < CW; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[gq][j][v] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float a = xs[(2 * u + lh) * 32 + li];
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+        for (int j = 0; j < CW; ++j)
+          acc[gq][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[u][gq][j], acc[gq][j], 0, 0, 0);
+    }
+    // gradient tile -> LDS: register v of group gq's CW accumulators = columns 128*wave + (32 gq + li)*CW .. of row
+    // (v&3) + 8*(v>>2) + 4*lh
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        vec t;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) t[j] = acc[gq][j][v];
+        *reinterpret_cast<vec*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * kRowsLd + wave * 128 + (32 * gq + li) * CW]) = t;
+      }
+    __syncthreads();
+    load_x(xv, g + 1);        // before the m requests: loads come back in issue order
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const __amdgpu_buffer_rsrc_t rr = row_rsrc(g, r), rn = row_rsrc(g + 1, r);
+      const int row = 32 * g + wave * 8 + r;
+#pragma unroll
+      for (int h = 0; h < NI; ++h) {
+        const int c = (h * 64 + lane) * CW;
+        const vec g4 = *reinterpret_cast<const vec*>(&tile[(wave * 8 + r) * kRowsLd + c]);
+        const uint32_t off = piece_off(h);
+        uvec mn;
+        float chk = 0.f;
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+          const float gr = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
+          const float mo = mreg[NI * r + h][j];
+          const float t = __fadd_rn(mo, __fmul_rn(__fsub_rn(gr, mo), omb1));
+          mn[j] = __float_as_uint(t);
+          chk += __fmul_rn(gr, gr) + fabsf(t);
+        }
+        if constexpr (CW == 4) __builtin_amdgcn_raw_buffer_store_b128(mn, rr, (int)off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(mn, rr, (int)off, 0, 0);
+        load_vec_buf<CW>(rn, off, mreg[NI * r + h]);
+        // ApplyAdam's v and var take a NaN where g*g or the new m is not finite (adam_frozen_kernel); a non-finite
+        // term makes the piece's sum non-finite, and the per-element work happens only behind that test
+        if (!isfinite(chk) & (off != kOOB) & (row < K)) {
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            const float gr = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
+            const bool poison = !isfinite(__fmul_rn(gr, gr));
+            const size_t o = (size_t)row * N + nb + c + j;
+            if (poison) v_w[o] = qnan;
+            if (poison || !isfinite(__uint_as_float(mn[j]))) var_w[o] = qnan;
+          }
+        }
+      }
+    }
+    *reinterpret_cast<f32x4v*>(&xs[xm * 32 + xk]) = (f32x4v){xv[0], xv[1], xv[2], xv[3]};
+    __syncthreads();
+  }
+}
+
+// ===================================================================================================================
+// forward  y[M][N] = act(x[M][K] W[K][N] + b) (* dropout)   and   bwd-data  dx[M][K] = (dz[M][N] W[K][N]^T) * act'(mask)
+// for M <= 64: one pass over W, 16 bytes per lane, the batch on the 32 rows of the fp32 MFMA.
+// ===================================================================================================================
+typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+
+struct DenseStreamParams {
+  const float* x;        // fwd: x [M][K];  bwd-data: dz [M][N]
+  const float* w;        // [K][N]
+  float* out;            // y / dx, or the split slabs [S][M][cols]
+  const float* bias;     // fwd
+  const uint8_t* keep;   // fwd: dropout keep mask [M][N]
+  const float* mask;     // bwd-data: activation whose gradient is applied, [M][K]
+  float scale;           // fwd: survivors' factor; bwd-data: gradient factor
+  int act;               // fwd: EPI_*; bwd-data: mask_act
+  int M, K, N, splits, span;      // span: rows of W (fwd) / columns (bwd-data) per split
+};
+
+// Forward.  Block = 4 waves on the same 128 columns, each taking a quarter of the block's K span in chunks of 16 rows
+// (8 KB of W in flight per wave beside the chunk being multiplied); lane li holds W[k][n0 + 4 li .. + 3] and feeds four
+// column-interleaved MFMAs.  The four partial tiles meet in LDS and leave as rows (bias / activation / dropout applied
+// when the launch is not split; otherwise one slab per split for splitk_reduce_kernel).
+template <int MB>
+__global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStreamParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 132];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 128, split = blockIdx.y;
+  const int kb0 = split * p.span, kb1 = min(p.K, kb0 + p.span);
+  const int wspan = ((kb1 - kb0 + 3) / 4 + 15) / 16 * 16;         // rows per wave, whole chunks
+  const int k0 = kb0 + wave * wspan, k1 = min(kb1, k0 + wspan);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned long long)p.K * p.N * 4ull);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned long long)p.M * p.K * 4ull);
+  const int col0 = n0 + 4 * li;
+
+  f32x16 acc[MB][4];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[b][c][v] = 0.f;
+
+  struct Chunk { float w[2][4][4]; float a[MB][2][4]; };
+  auto load = [&](Chunk& c, int kc) {            // rows kc .. kc+15: sub-chunk u, MFMA j, lane half lh -> row kc + 8u + 4lh + j
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kc + 8 * u + 4 * lh + j;               // N % 4 == 0: a lane's four columns exist together
+        load_vec_buf<4>(rw, (k < k1 && col0 < p.N) ? (uint32_t)(((size_t)k * p.N + col0) * 4) : kOOB, c.w[u][j]);
+      }
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const int m = 32 * b + li, k = kc + 8 * u + 4 * lh;   // K % 4 == 0 and spans of whole chunks: k .. k+3 < k1 together
+        load_vec_buf<4>(rx, (m < p.M && k < k1) ? (uint32_t)(((size_t)m * p.K + k) * 4) : kOOB, c.a[b][u]);
+      }
+    }
+  };
+  auto compute = [&](const Chunk& c) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[b][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[b][u][j], c.w[u][j][e], acc[b][e], 0, 0, 0);
+  };
+  if (k0 < k1) {
+    Chunk ca, cb;
+    load(ca, k0);
+    for (int kc = k0; kc < k1; kc += 32) {
+      load(cb, kc + 16);
+      compute(ca);
+      load(ca, kc + 32);
+      compute(cb);
+    }
+  }
+
+  // the four waves' tiles -> LDS -> rows (one 32-row block of the batch at a time)
+  for (int b = 0; b < MB; ++b) {
+    if (b) __syncthreads();
+    float* mine = red + wave * (32 * 132);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const f32x4 q = {acc[b][0][v], acc[b][1][v], acc[b][2][v], acc[b][3][v]};
+      *reinterpret_cast<f32x4*>(mine + ((v & 3) + 8 * (v >> 2) + 4 * lh) * 132 + 4 * li) = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int lr = wave * 8 + r, m = 32 * b + lr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h, col = n0 + c;
+        if (col >= p.N) continue;
+        float s = red[lr * 132 + c];
+        s += red[(32 + lr) * 132 + c];
+        s += red[(64 + lr) * 132 + c];
+        s += red[(96 + lr) * 132 + c];
+        if (p.splits > 1) {
+          p.out[((size_t)split * p.M + m) * p.N + col] = s;
+        } else {
+          if (p.bias) s += p.bias[col];
+          if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
+          else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
+          if (p.keep) s = p.keep[(size_t)m * p.N + col] ? s * p.scale : 0.f;
+          p.out[(size_t)m * p.N + col] = s;
+        }
+      }
+    }
+  }
+}
+
+// Bwd-data.  A wave owns 32 rows of W (32 outputs k) and walks its split's columns in stages of 128: the stage is read
+// row-contiguously (16 bytes per lane, 512-byte row segments), crosses a wave-private LDS tile (the MFMA wants a lane per
+// ROW of W), and is multiplied against dz read 16 bytes per lane from L2.  No block-level synchronisation.
+template <int MB>
+__global__ __launch_bounds__(256) void dense_bwd_data_stream_kernel(const DenseStreamParams p) {
+  __shared__ __attribute__((aligned(16))) float tile[4][32 * 132];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int k0 = (blockIdx.x * 4 + wave) * 32, split = blockIdx.y;
+  if (k0 >= p.K) return;                                  // wave-uniform; no block barrier below
+  const int nb0 = split * p.span, nb1 = min(p.N, nb0 + p.span);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned long long)p.K * p.N * 4ull);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.x, (unsigned long long)p.M * p.N * 4ull);
+  float* mine = tile[wave];
+
+  f32x16 acc[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+
+  // stage registers: 16 x 16 bytes per lane = rows (lane / 32) + 2 i of the stage, columns 4 (lane % 32) .. + 3
+  float sw[16][4];
+  auto load_stage = [&](int n) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = k0 + 2 * i + lh, col = n + 4 * li;       // N % 4 == 0, spans of whole stages
+      load_vec_buf<4>(rw, (k < p.K && col < nb1) ? (uint32_t)(((size_t)k * p.N + col) * 4) : kOOB, sw[i]);
+    }
+  };
+  if (nb0 < nb1) load_stage(nb0);
+  for (int n = nb0; n < nb1; n += 128) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 q = {sw[i][0], sw[i][1], sw[i][2], sw[i][3]};
+      *reinterpret_cast<f32x4*>(mine + (2 * i + lh) * 132 + 4 * li) = q;
+    }
+    load_stage(n + 128);                                  // next stage in flight under this stage's MFMAs
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                // dz of eight steps requested at once, then their MFMAs
+      float az[MB][8][4];
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const int u = 8 * half + uu;                      // 8 columns per step: lane half lh takes n + 8u + 4lh + j
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const int m = 32 * b + li, col = n + 8 * u + 4 * lh;
+          load_vec_buf<4>(rz, (m < p.M && col < nb1) ? (uint32_t)(((size_t)m * p.N + col) * 4) : kOOB, az[b][uu]);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < 8; ++uu) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(mine + li * 132 + 8 * (8 * half + uu) + 4 * lh);
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[b][uu][j], bq[j], acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // D[m][k]: column (lane % 32) = k, rows = batch
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    const int k = k0 + li;
+    if (k >= p.K) continue;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int m = 32 * b + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      float val = acc[b][v];
+      if (p.splits > 1) {
+        p.out[((size_t)split * p.M + m) * p.K + k] = val;
+      } else {
+        if (p.mask) val = apply_act_grad(val, p.mask[(size_t)m * p.K + k], p.act, p.scale);
+        p.out[(size_t)m * p.K + k] = val;
+      }
+    }
+  }
+}
+
+// split counts: about two blocks per CU, spans in whole chunks / stages
+static int pick_span(int extent, int groups, int quantum) {
+  const int want = std::max(1, 512 / std::max(1, groups));
+  int span = (extent + want - 1) / want;
+  span = std::max(quantum, (span + quantum - 1) / quantum * quantum);
+  return span;
+}
+bool dense_stream_applicable(int m, int k, int n) {
+  return m >= 1 && m <= 64 && (long)k * n >= (1L << 20) && k % 4 == 0 && n % 4 == 0;      // 16-byte rows of W, x and dz
+}
+size_t dense_stream_ws_bytes(int m, int k, int n) {
+  if (!dense_stream_applicable(m, k, n)) return 0;
+  const int sf = pick_span(k, (n + 127) / 128, 64), sd = pick_span(n, (k + 127) / 128, 128);
+  const size_t f = (size_t)((k + sf - 1) / sf) * m * n * 4, d = (size_t)((n + sd - 1) / sd) * m * k * 4;
+  return std::max(f, d);
+}
+int dense_fwd_stream(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
+                     const uint8_t* keep, float keep_scale, void* ws, size_t ws_bytes, hipStream_t st) {
+  DenseStreamParams p{};
+  p.x = x; p.w = w; p.bias = bias; p.keep = keep; p.scale = keep_scale; p.act = act; p.M = m; p.K = k; p.N = n;
+  p.span = pick_span(k, (n + 127) / 128, 64);
+  p.splits = (k + p.span - 1) / p.span;
+  if (p.splits > 1 && (size_t)p.splits * m * n * 4 > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_fwd: workspace too small");
+  p.out = p.splits > 1 ? static_cast<float*>(ws) : y;
+  clear_stale_error();
+  const dim3 grid((n + 127) / 128, p.splits);
+  if (m <= 32) hipLaunchKernelGGL(dense_fwd_stream_kernel<1>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(dense_fwd_stream_kernel<2>, grid, dim3(256), 0, st, p);
+  int rc = check_launch("dense_fwd_stream");
+  if (rc != A3D_OK || p.splits == 1) return rc;
+  ReduceParams r{};
+  r.ws = p.out; r.C = y; r.bias = bias; r.keep = keep; r.mask_scale = keep_scale; r.M = m; r.N = n; r.ldc = n;
+  r.splitk = p.splits; r.act = act; r.mode = MODE_FWD; r.slab = (size_t)m * n; r.sub_step = 1;
+  r.div_phw = make_fastdiv(1); r.div_pw = make_fastdiv(1);
+  return launch_splitk_reduce(r, st);
+}
+int dense_bwd_data_stream(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
+                          float scale, void* ws, size_t ws_bytes, hipStream_t st) {
+  DenseStreamParams p{};
+  p.x = dz; p.w = w; p.mask = mask; p.scale = scale; p.act = mask_act; p.M = m; p.K = k; p.N = n;
+  p.span = pick_span(n, (k + 127) / 128, 128);
+  p.splits = (n + p.span - 1) / p.span;
+  if (p.splits > 1 && (size_t)p.splits * m * k * 4 > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: workspace too small");
+  p.out = p.splits > 1 ? static_cast<float*>(ws) : dx;
+  clear_stale_error();
+  const dim3 grid((k + 127) / 128, p.splits);
+  if (m <= 32) hipLaunchKernelGGL(dense_bwd_data_stream_kernel<1>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(dense_bwd_data_stream_kernel<2>, grid, dim3(256), 0, st, p);
+  int rc = check_launch("dense_bwd_data_stream");
+  if (rc != A3D_OK || p.splits == 1) return rc;
+  ReduceParams r{};
+  r.ws = p.out; r.C = dx; r.mask = mask; r.mask_scale = scale; r.mask_act = mask_act; r.M = m; r.N = k; r.ldc = k;
+  r.splitk = p.splits; r.mode = MODE_BWD_D; r.slab = (size_t)m * k; r.sub_step = 1;
+  r.div_phw = make_fastdiv(1); r.div_pw = make_fastdiv(1);
+  return launch_splitk_reduce(r, st);
 }
 
 bool dense_dw_applicable(int m, int k, int n) { return m >= 1 && m <= 64 && k >= 1 && n >= 1; }
@@ -306,6 +773,13 @@ int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float*
 
 using namespace a3d;
 
+#ifdef A3D_STAMPS
+extern "C" int a3d_debug_dense_stamps(unsigned long long* out, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_stamps), std::min(bytes, sizeof(g_dense_stamps)));
+}
+#endif
+
 extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x, const float* dz, float* var_w, float* m_w,
                                              float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1,
                                              float beta2, float beta1_power, float beta2_power, float grad_scale,
@@ -319,10 +793,26 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
                 "a3d_dense_bwd_filter and a3d_adam_apply_tf1");
   clear_stale_error();
   static const int cw = getenv("A3D_DW_CW") ? atoi(getenv("A3D_DW_CW")) : 0;      // tuning aid
-  if (cw != 4 && cw != 2 && n % 4 == 0 && (reinterpret_cast<uintptr_t>(m_w) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0)
-    hipLaunchKernelGGL(dense_dw_adam_rows_kernel, dim3((n + 511) / 512, (k + 31) / 32), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, dz, var_w, m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1,
-                       grad_scale);
+  const uintptr_t slots = reinterpret_cast<uintptr_t>(m_w) | reinterpret_cast<uintptr_t>(dz);
+  const dim3 rows_grid((n + 511) / 512, (k + 31) / 32);
+  // stream form: two blocks per CU, each walking down its share of the row groups
+  static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
+  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * (int)rows_grid.x + 511) / 512);
+  const dim3 stream_grid(rows_grid.x, ((k + 31) / 32 + gpb - 1) / gpb);
+  static const bool no_stream = getenv("A3D_NO_DENSE_STREAM") && atoi(getenv("A3D_NO_DENSE_STREAM"));   // tuning aid
+  const bool stream_ok = m <= 32 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream;
+  if (cw != 4 && cw != 2 && stream_ok && n % 4 == 0 && (slots & 15) == 0)
+    hipLaunchKernelGGL(dense_dw_adam_stream_kernel<4>, stream_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz,
+                       var_w, m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb);
+  else if (cw != 4 && cw != 2 && stream_ok && n % 2 == 0 && (slots & 7) == 0)
+    hipLaunchKernelGGL(dense_dw_adam_stream_kernel<2>, stream_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz,
+                       var_w, m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb);
+  else if (cw != 4 && cw != 2 && n % 4 == 0 && (slots & 15) == 0)
+    hipLaunchKernelGGL(dense_dw_adam_rows_kernel<4>, rows_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz, var_w,
+                       m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale);
+  else if (cw != 4 && cw != 2 && n % 2 == 0 && (slots & 7) == 0)
+    hipLaunchKernelGGL(dense_dw_adam_rows_kernel<2>, rows_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz, var_w,
+                       m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale);
   else if (cw != 2)
     hipLaunchKernelGGL((dense_dw_kernel<true, 4>), dim3((n + 127) / 128, (k + 127) / 128), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, dz, nullptr, nullptr, var_w, m_w, v_w, var_b, m_b, v_b, m, k, n,

@@ -34,6 +34,9 @@ namespace a3d {
 #define A3D_STAMP(var) do { } while (0)
 #endif
 
+#ifndef A3D_PIPE_ALL
+#define A3D_PIPE_ALL 0
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -780,7 +783,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     // chunk u's MFMAs issue, in the requested interleave of one MFMA and its share of the next chunk's ds_reads
     // (bwd-filter 128x128 187 -> 182 us, bwd-data 170 -> 163 us).  The forward kernels and the other tiles are 0-4 %
     // slower that way and keep the plain read-then-multiply form below.
-    constexpr bool PIPE = (MODE != MODE_FWD) && NWAVES == 8 && BN == 128;
+    constexpr bool PIPE = A3D_PIPE_ALL ? (NWAVES == 8) : ((MODE != MODE_FWD) && NWAVES == 8 && BN == 128);
     if constexpr (PIPE) {
       f32x4 af[2][TM], bf[2][TN];
       auto read_frags = [&](int u, int buf) {

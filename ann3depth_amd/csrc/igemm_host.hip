@@ -247,6 +247,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
   }
 }
 
+int launch_splitk_reduce(const ReduceParams& r, hipStream_t st) {
+  const size_t total = (size_t)r.M * r.N;
+  const unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
+  clear_stale_error();
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
+  return check_launch("splitk_reduce");
+}
+
 int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams& p, void* ws, hipStream_t st) {
   if (mode == MODE_BWD_D && p.stride != 1)      // strided bwd-data always arrives as stride-1 parity classes
     return set_error(A3D_EINVAL, "igemm: bwd-data launches are stride-1 problems");
@@ -856,7 +864,7 @@ static a3d_conv_desc dense_desc(int m, int k, int n) {
 
 size_t a3d_dense_fwd_ws_bytes(int m, int k, int n) {
   a3d_conv_desc d = dense_desc(m, k, n);
-  return a3d_conv2d_fwd_ws_bytes(&d);
+  return std::max(a3d_conv2d_fwd_ws_bytes(&d), dense_stream_ws_bytes(m, k, n));
 }
 
 int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
@@ -873,6 +881,9 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
+  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) && aligned16(w) &&
+      !env_int("A3D_NO_DENSE_KERNELS", 0))
+    return dense_fwd_stream(m, k, n, x, w, bias, y, act, drop_keep, 2.f, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(&d);
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
@@ -894,7 +905,7 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
 
 size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n) {
   a3d_conv_desc d = dense_desc(m, k, n);
-  return a3d_conv2d_bwd_data_ws_bytes(&d);
+  return std::max(a3d_conv2d_bwd_data_ws_bytes(&d), dense_stream_ws_bytes(m, k, n));
 }
 
 int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
@@ -912,6 +923,9 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(dz && w && dx, "dense_bwd_data: null tensor");
+  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(dz) && aligned16(w) &&
+      !env_int("A3D_NO_DENSE_KERNELS", 0))
+    return dense_bwd_data_stream(m, k, n, dz, w, dx, mask, mask_act, scale, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = bwd_d_problem(&d);
   if (!aligned16(dz)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;

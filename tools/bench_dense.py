@@ -27,4 +27,4 @@ for name, k, n in (('dense_0', 12288, 4096), ('dense_1', 4096, 4070)):
             ('bwd_f+adam', lambda: ops.dense_bwd_filter_adam_tf1(x, dz, w, mw, vw, b, mb, vb, 0.1, 0.9, 1.0, 0.9, 1.0, 1.0), 2 * mb_w)]
     for mode, fn, mbytes in rows:
         t = timeit(fn)
-        print(f'{name} {mode:11s} {t:8.1f} us  {mbytes / t * 1e-3 * 1e3 / 1e3:6.2f} TB/s of weight-sized traffic', flush=True)
+        print(f'{name} {mode:11s} {t:8.1f} us  {mbytes / t:6.2f} TB/s of weight-sized traffic', flush=True)
