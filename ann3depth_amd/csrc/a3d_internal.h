@@ -56,8 +56,6 @@ bool dense_stream_applicable(int m, int k, int n);
 size_t dense_stream_ws_bytes(int m, int k, int n);
 int dense_fwd_stream(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                      const uint8_t* keep, float keep_scale, void* ws, size_t ws_bytes, hipStream_t st);
-int dense_bwd_data_stream(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
-                          float scale, void* ws, size_t ws_bytes, hipStream_t st);
 struct ReduceParams;
 int launch_splitk_reduce(const ReduceParams& r, hipStream_t st);
 int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, hipStream_t st);

@@ -556,13 +556,15 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = kc + 8 * u + 4 * lh + j;               // N % 4 == 0: a lane's four columns exist together
-        load_vec_buf<4>(rw, (k < k1 && col0 < p.N) ? (uint32_t)(((size_t)k * p.N + col0) * 4) : kOOB, c.w[u][j]);
+        // 16 bytes at dword alignment; where a lane's four columns run past N they are the next row's first (or
+        // past the buffer: zeros): accumulators of columns that do not exist, never stored
+        const int k = kc + 8 * u + 4 * lh + j;
+        load_vec_buf<4>(rw, ((k < k1) & (col0 < p.N)) ? (uint32_t)(((size_t)k * p.N + col0) * 4) : kOOB, c.w[u][j]);
       }
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
         const int m = 32 * b + li, k = kc + 8 * u + 4 * lh;   // K % 4 == 0 and spans of whole chunks: k .. k+3 < k1 together
-        load_vec_buf<4>(rx, (m < p.M && k < k1) ? (uint32_t)(((size_t)m * p.K + k) * 4) : kOOB, c.a[b][u]);
+        load_vec_buf<4>(rx, ((m < p.M) & (k < k1)) ? (uint32_t)(((size_t)m * p.K + k) * 4) : kOOB, c.a[b][u]);
       }
     }
   };
@@ -624,86 +626,6 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
   }
 }
 
-// Bwd-data.  A wave owns 32 rows of W (32 outputs k) and walks its split's columns in stages of 128: the stage is read
-// row-contiguously (16 bytes per lane, 512-byte row segments), crosses a wave-private LDS tile (the MFMA wants a lane per
-// ROW of W), and is multiplied against dz read 16 bytes per lane from L2.  No block-level synchronisation.
-template <int MB>
-__global__ __launch_bounds__(256) void dense_bwd_data_stream_kernel(const DenseStreamParams p) {
-  __shared__ __attribute__((aligned(16))) float tile[4][32 * 132];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int k0 = (blockIdx.x * 4 + wave) * 32, split = blockIdx.y;
-  if (k0 >= p.K) return;                                  // wave-uniform; no block barrier below
-  const int nb0 = split * p.span, nb1 = min(p.N, nb0 + p.span);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned long long)p.K * p.N * 4ull);
-  const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.x, (unsigned long long)p.M * p.N * 4ull);
-  float* mine = tile[wave];
-
-  f32x16 acc[MB];
-#pragma unroll
-  for (int b = 0; b < MB; ++b)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
-
-  // stage registers: 16 x 16 bytes per lane = rows (lane / 32) + 2 i of the stage, columns 4 (lane % 32) .. + 3
-  float sw[16][4];
-  auto load_stage = [&](int n) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = k0 + 2 * i + lh, col = n + 4 * li;       // N % 4 == 0, spans of whole stages
-      load_vec_buf<4>(rw, (k < p.K && col < nb1) ? (uint32_t)(((size_t)k * p.N + col) * 4) : kOOB, sw[i]);
-    }
-  };
-  if (nb0 < nb1) load_stage(nb0);
-  for (int n = nb0; n < nb1; n += 128) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const f32x4 q = {sw[i][0], sw[i][1], sw[i][2], sw[i][3]};
-      *reinterpret_cast<f32x4*>(mine + (2 * i + lh) * 132 + 4 * li) = q;
-    }
-    load_stage(n + 128);                                  // next stage in flight under this stage's MFMAs
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {                // dz of eight steps requested at once, then their MFMAs
-      float az[MB][8][4];
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {
-        const int u = 8 * half + uu;                      // 8 columns per step: lane half lh takes n + 8u + 4lh + j
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-          const int m = 32 * b + li, col = n + 8 * u + 4 * lh;
-          load_vec_buf<4>(rz, (m < p.M && col < nb1) ? (uint32_t)(((size_t)m * p.N + col) * 4) : kOOB, az[b][uu]);
-        }
-      }
-#pragma unroll
-      for (int uu = 0; uu < 8; ++uu) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(mine + li * 132 + 8 * (8 * half + uu) + 4 * lh);
-#pragma unroll
-        for (int b = 0; b < MB; ++b)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[b][uu][j], bq[j], acc[b], 0, 0, 0);
-      }
-    }
-  }
-  // D[m][k]: column (lane % 32) = k, rows = batch
-#pragma unroll
-  for (int b = 0; b < MB; ++b) {
-    const int k = k0 + li;
-    if (k >= p.K) continue;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int m = 32 * b + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      if (m >= p.M) continue;
-      float val = acc[b][v];
-      if (p.splits > 1) {
-        p.out[((size_t)split * p.M + m) * p.K + k] = val;
-      } else {
-        if (p.mask) val = apply_act_grad(val, p.mask[(size_t)m * p.K + k], p.act, p.scale);
-        p.out[(size_t)m * p.K + k] = val;
-      }
-    }
-  }
-}
-
-// split counts: about two blocks per CU, spans in whole chunks / stages
 static int pick_span(int extent, int groups, int quantum) {
   const int want = std::max(1, 512 / std::max(1, groups));
   int span = (extent + want - 1) / want;
@@ -711,13 +633,12 @@ static int pick_span(int extent, int groups, int quantum) {
   return span;
 }
 bool dense_stream_applicable(int m, int k, int n) {
-  return m >= 1 && m <= 64 && (long)k * n >= (1L << 20) && k % 4 == 0 && n % 4 == 0;      // 16-byte rows of W, x and dz
+  return m >= 1 && m <= 64 && (long)k * n >= (1L << 20) && k % 4 == 0;      // 16-byte rows of x; W rows of any length
 }
 size_t dense_stream_ws_bytes(int m, int k, int n) {
   if (!dense_stream_applicable(m, k, n)) return 0;
-  const int sf = pick_span(k, (n + 127) / 128, 64), sd = pick_span(n, (k + 127) / 128, 128);
-  const size_t f = (size_t)((k + sf - 1) / sf) * m * n * 4, d = (size_t)((n + sd - 1) / sd) * m * k * 4;
-  return std::max(f, d);
+  const int sf = pick_span(k, (n + 127) / 128, 64);
+  return (size_t)((k + sf - 1) / sf) * m * n * 4;
 }
 int dense_fwd_stream(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                      const uint8_t* keep, float keep_scale, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -739,27 +660,6 @@ int dense_fwd_stream(int m, int k, int n, const float* x, const float* w, const 
   r.div_phw = make_fastdiv(1); r.div_pw = make_fastdiv(1);
   return launch_splitk_reduce(r, st);
 }
-int dense_bwd_data_stream(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
-                          float scale, void* ws, size_t ws_bytes, hipStream_t st) {
-  DenseStreamParams p{};
-  p.x = dz; p.w = w; p.mask = mask; p.scale = scale; p.act = mask_act; p.M = m; p.K = k; p.N = n;
-  p.span = pick_span(n, (k + 127) / 128, 128);
-  p.splits = (n + p.span - 1) / p.span;
-  if (p.splits > 1 && (size_t)p.splits * m * k * 4 > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: workspace too small");
-  p.out = p.splits > 1 ? static_cast<float*>(ws) : dx;
-  clear_stale_error();
-  const dim3 grid((k + 127) / 128, p.splits);
-  if (m <= 32) hipLaunchKernelGGL(dense_bwd_data_stream_kernel<1>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(dense_bwd_data_stream_kernel<2>, grid, dim3(256), 0, st, p);
-  int rc = check_launch("dense_bwd_data_stream");
-  if (rc != A3D_OK || p.splits == 1) return rc;
-  ReduceParams r{};
-  r.ws = p.out; r.C = dx; r.mask = mask; r.mask_scale = scale; r.mask_act = mask_act; r.M = m; r.N = k; r.ldc = k;
-  r.splitk = p.splits; r.mode = MODE_BWD_D; r.slab = (size_t)m * k; r.sub_step = 1;
-  r.div_phw = make_fastdiv(1); r.div_pw = make_fastdiv(1);
-  return launch_splitk_reduce(r, st);
-}
-
 bool dense_dw_applicable(int m, int k, int n) { return m >= 1 && m <= 64 && k >= 1 && n >= 1; }
 
 int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, hipStream_t st) {

@@ -881,7 +881,7 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
-  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) && aligned16(w) &&
+  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) &&
       !env_int("A3D_NO_DENSE_KERNELS", 0))
     return dense_fwd_stream(m, k, n, x, w, bias, y, act, drop_keep, 2.f, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(&d);
@@ -905,7 +905,7 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
 
 size_t a3d_dense_bwd_data_ws_bytes(int m, int k, int n) {
   a3d_conv_desc d = dense_desc(m, k, n);
-  return std::max(a3d_conv2d_bwd_data_ws_bytes(&d), dense_stream_ws_bytes(m, k, n));
+  return a3d_conv2d_bwd_data_ws_bytes(&d);
 }
 
 int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask,
@@ -923,9 +923,6 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(dz && w && dx, "dense_bwd_data: null tensor");
-  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(dz) && aligned16(w) &&
-      !env_int("A3D_NO_DENSE_KERNELS", 0))
-    return dense_bwd_data_stream(m, k, n, dz, w, dx, mask, mask_act, scale, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = bwd_d_problem(&d);
   if (!aligned16(dz)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;

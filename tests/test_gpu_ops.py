@@ -141,7 +141,7 @@ def test_conv2d_strided_pixels(ops):
 
 
 DENSE_CASES = [(32, 12288, 4096), (4, 512, 4070), (32, 4096, 4070), (7, 130, 66), (48, 12544, 128), (48, 128, 16),
-               (48, 16, 1)]
+               (48, 16, 1), (9, 1024, 1031)]
 
 
 @pytest.mark.parametrize('m,k,n', DENSE_CASES)
