@@ -20,7 +20,7 @@ import time
 
 import torch
 
-from . import _lib, data, dp, models, summary, tfckpt
+from . import _lib, data, dp, models, summary, tfckpt, tracehook
 
 
 def main(argv=None):
@@ -43,6 +43,15 @@ def main(argv=None):
         logger.warning(f'No suitable job description found! {args.job_name}')
         return 0
 
+    run_id = args.model + ('' if not args.id else f'_{args.id}')
+    ckptdir = str(os.path.join(args.ckptdir, run_id))                    # src/ann3depth.py:73-75
+    if args.profiler == 'rocprofv3' and args.trace_every and not tracehook.under_profiler():
+        # TraceHook as a profiler capture: nothing above has touched the GPU, so this process may still start the
+        # profiled copy of itself as a child; from here on it only waits (ann3depth_amd/tracehook.py)
+        out = os.path.join(ckptdir, 'rocprof')
+        logger.info(f'Starting the training process under rocprofv3; traces of the traced steps go to {out}.')
+        return tracehook.respawn(sys.argv[1:] if argv is None else argv, out)
+
     rank, local_rank, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise RuntimeError('ann3depth_amd needs an MI355X: the training path has no CPU fallback')
@@ -50,8 +59,6 @@ def main(argv=None):
     chief = rank == 0
     logger.info(f'Task: {rank} of {world} -- Chief? {chief}')
 
-    run_id = args.model + ('' if not args.id else f'_{args.id}')
-    ckptdir = str(os.path.join(args.ckptdir, run_id))                    # src/ann3depth.py:73-75
     logger.info(f'Checkpoint dir is {ckptdir}.')
 
     logger.info(f'Loading model {args.model}.')
@@ -119,6 +126,8 @@ class Session:
         self.tf_checkpoints = tf_checkpoints
         self.stop = False
         self.trace_next = True               # TraceHook: the first step after every (re)start is traced
+        # under `--profiler rocprofv3` (this is then the profiled child): the traced steps are the profiler's regions
+        self.roctx = tracehook.Roctx() if tracehook.under_profiler() else None
         self.t_last_ckpt = time.time()
         self.t_last_sum, self.step_last_sum = time.time(), None
         self.summaries = None
@@ -149,8 +158,11 @@ class Session:
     def run(self, train_op):
         rep = train_op.replica
         tracing = self.trace_next and self.dir is not None
+        marking = self.trace_next and self.roctx is not None
         if tracing:
             _lib.load().a3d_timing_enable(1)
+        if marking:
+            self.roctx.begin(rep.global_step + 1)
         try:
             out = train_op.run()
         except data.OutOfRangeError as e:
@@ -158,6 +170,9 @@ class Session:
             self.stop = True
             return None
         finally:
+            if marking:
+                torch.cuda.synchronize()               # the step's kernels belong inside the region
+                self.roctx.end()
             if tracing:
                 self._write_trace(rep.global_step)
         step = rep.global_step
@@ -273,7 +288,7 @@ def latest_checkpoint(ckptdir):
 
 
 def parse_args(argv=None):
-    """The reference's flags verbatim (src/ann3depth.py:221-254), plus --beta2 / --seed / --trace-every."""
+    """The reference's flags verbatim (src/ann3depth.py:221-254), plus --beta2 / --seed / --trace-every / --profiler."""
     parser = argparse.ArgumentParser()
     parser.add_argument('dataset', default='nyu', type=str, help='The dataset to use.')
     parser.add_argument('--model', '-m', default='', type=str, help='Enter a model name.')
@@ -298,7 +313,10 @@ def parse_args(argv=None):
     parser.add_argument('--tf-checkpoints', action='store_true',
                         help='Also write every checkpoint as a TensorFlow V2 bundle (model.ckpt-N.index/.data-*).')
     parser.add_argument('--trace-every', default=5000, type=int,
-                        help='TraceHook period (src/ann3depth.py:105); traces are taken with rocprofv3 externally.')
+                        help='TraceHook period (src/ann3depth.py:105): the first step and every N-th global step.')
+    parser.add_argument('--profiler', default='launches', choices=['launches', 'rocprofv3'],
+                        help='What a traced step records: per-launch timings of the GEMM kernels (trace-N.json), or '
+                             'also a rocprofv3 kernel + marker trace (the process is started under the profiler).')
     return parser.parse_args(argv)
 
 

@@ -2,6 +2,7 @@
 // conv2d / dense entry points of include/a3d.h.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -28,9 +29,11 @@ struct TileCfg {
 static const TileCfg kCfgs[] = {{128, 128, 1.00f, 32}, {128, 96, 1.00f, 32}, {128, 64, 0.92f, 32}, {128, 32, 0.60f, 32},
                                 {64, 64, 0.98f, 32},   {32, 128, 0.90f, 32}, {64, 128, 1.00f, 32},
                                 {128, 128, 1.15f, 32}, {128, 64, 1.05f, 32},      // 8-wave blocks
-                                // LDS-DMA staged (igemm_glds.h), same order as A3D_GLDS_CFGS; forward only (sweep:
-                                // +3-5 % there, ties or loses in the other directions and on the other tiles)
-                                {128, 128, 1.19f, 32}, {128, 64, 1.09f, 32}};
+                                // LDS-DMA staged (igemm_glds.h), same order as A3D_GLDS_CFGS; forward only.  Round 1:
+                                // +3-5 % over the register-staged twins; since those stage through buffer loads with
+                                // addresses computed a tile ahead (round 2) they are the faster ones (fine/second
+                                // forward 245 vs 259 us, conv2d_1 325 vs 339 us: profiles/r02_sweep_hot.txt)
+                                {128, 128, 1.10f, 32}, {128, 64, 1.00f, 32}};
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -166,7 +169,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
         // blocks meeting in one tile: their slabs are added one after the other by the fixup, so few tiles with very
         // long K (bwd-filter of the 3-channel layers, dense layers) stay with classic split-K and its flat reduction
         const long meet = (nk + per - 1) / per + 1;
-        if (force_streamk <= 0 && (meet > 12 || tiles < 24)) continue;
+        if (force_streamk <= 0 && (meet > 16 || tiles < 24)) continue;
         double t = (double)bm * bn * per * 32.0 / (96.5e3 * kCfgs[c].eff) * (grid <= 256 ? 0.62 : 1.0);
         // ~1.5 slabs per block are written and read back, then the split tiles are written once more
         const double slabs = std::min<double>(1.5 * grid, 2.0 * tiles) * bm * bn * 4.0;
@@ -288,6 +291,10 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   g_stamp_grid = grid;
 #endif
   p.dbg = env_int("A3D_DBG", 0);
+  static const bool plan_log = env_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
+  if (plan_log)
+    fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d grid %u\n", mode, p.M, p.N, p.K,
+            plan.cfg, kCfgs[plan.cfg].bm, kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, grid);
   TimingSlot slot{};
   bool timed = false;
   {

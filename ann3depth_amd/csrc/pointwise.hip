@@ -544,6 +544,23 @@ int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* 
   return check_launch("maxpool_bwd");
 }
 
+int a3d_stream_create(int level, void** stream) {
+  A3D_CHECK_ARG(stream != nullptr, "stream_create: null output");
+  int least = 0, greatest = 0;                        // numerically: greatest priority <= least priority
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return set_error(A3D_ELAUNCH, "stream_create: no priority range");
+  const int prio = std::min(least, std::max(greatest, level));
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess)
+    return set_error(A3D_ELAUNCH, "stream_create: hipStreamCreateWithPriority failed");
+  *stream = st;
+  return A3D_OK;
+}
+
+int a3d_stream_destroy(void* stream) {
+  A3D_CHECK_ARG(stream != nullptr, "stream_destroy: null stream");
+  return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? A3D_OK : set_error(A3D_ELAUNCH, "stream_destroy failed");
+}
+
 int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream) {
   A3D_CHECK_ARG(count > 0 && src && dst, "cast_bf16: bad arguments");
   A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "cast_bf16: 16-byte aligned buffers");

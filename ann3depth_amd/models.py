@@ -9,13 +9,14 @@ optimizer on the current stream.  Variable names are the reference's TF variable
 """
 import collections
 import contextlib
+import ctypes
 import math
 import os
 
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 NET_H, NET_W = 228, 304          # src/models.py:282
 OUT_H, OUT_W = 55, 74            # src/models.py:283
@@ -150,7 +151,14 @@ class MSDNReplica:
         # conv + ReLU + max pool in one kernel inside step(): the pre-pool activations c0, c1, f1 are never written
         # (the network being trained keeps one byte per pool window instead, see forward())
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
-        self.side = torch.cuda.Stream(device=dev) if self.overlap and dev.type == 'cuda' else None
+        self.side = None
+        if self.overlap and dev.type == 'cuda':
+            # below the main stream's queue priority: a CU slot that frees up goes to the HBM-bound kernel first
+            handle = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                ops.check(_lib.load().a3d_stream_create(int(os.environ.get('A3D_SIDE_PRIORITY', '1')), ctypes.byref(handle)),
+                          'a3d_stream_create')
+            self.side = torch.cuda.ExternalStream(handle.value, device=dev)
         shapes = collections.OrderedDict()
         for c in MSDN_CONVS:
             shapes[c.name + '/kernel'] = (c.k, c.k, c.cin, c.cout)

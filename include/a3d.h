@@ -65,6 +65,14 @@ typedef struct a3d_conv_desc {
 const char* a3d_version(void);
 int a3d_last_error(char* buf, size_t len);
 
+/* A HIP stream of a given queue priority (hipStreamCreateWithPriority, non-blocking): `level` -1 = above, 0 = the same
+ * as, +1 = below the streams the host framework hands out, clamped to what the device offers.  For the second stream of
+ * a training step (src/models.py:289-305 builds coarse and fine in one graph; here the MFMA-bound fine forward runs
+ * beside the HBM-bound dense stretch of the coarse chain): with the lower priority the dispatcher gives a freed CU slot
+ * to the HBM-bound kernel first.  *stream is a hipStream_t for every `void* stream` argument of this header. */
+int a3d_stream_create(int level, void** stream);
+int a3d_stream_destroy(void* stream);
+
 /* Conv2D + BiasAdd (+ Relu)  — tf.layers.conv2d forward.  bias may be NULL. */
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y,

@@ -212,3 +212,42 @@ def test_dcnf_unary_matches_oracle():
     g = OD.unary_backward(params, a_gpu, dz)
     for n, gref in g.items():
         assert rel(net.group.view(net.group.grad, n).cpu().numpy(), gref) < 1e-4, n
+
+
+def test_tracehook_as_a_rocprofv3_capture(tmp_path):
+    """--profiler rocprofv3: the driver runs itself under rocprofv3 as a child (this test's process has long initialised the
+    GPU: it only starts the driver, which starts the profiler); the kernel trace then holds the traced steps — the
+    first and every `--trace-every`-th — and no others."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which('rocprofv3') and not os.path.exists('/opt/rocm/bin/rocprofv3'):
+        pytest.skip('no rocprofv3')
+    write_shard(str(tmp_path))
+    ck = str(tmp_path / 'ckpt')
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    env.pop('A3D_UNDER_ROCPROF', None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'ann3depth_amd.ann3depth', '--model', 'msdn', '--batchsize', '4', '--ckptdir', ck,
+           '--datadir', str(tmp_path), '--steps', '3', '--trace-every', '2', '--profiler', 'rocprofv3', 'nyu']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = os.path.join(ck, 'msdn')
+    assert ann3depth_latest(d).endswith('model.ckpt-3.pt')
+    traces = glob.glob(os.path.join(d, 'rocprof', '**', '*kernel_trace.csv'), recursive=True)
+    assert traces, os.listdir(os.path.join(d, 'rocprof'))
+    names = [row['Kernel_Name'] for row in csv.DictReader(open(traces[0]))]
+    # one loss gradient per training step: steps 1 and 2 are traced ((step + 1) % 2 == 0 after step 1), step 3 is not
+    assert sum('silog_bwd' in n for n in names) == 2
+    assert any('igemm' in n for n in names)
+    markers = glob.glob(os.path.join(d, 'rocprof', '**', '*marker*trace.csv'), recursive=True)
+    assert markers
+    text = open(markers[0]).read()
+    assert 'global_step 1' in text and 'global_step 2' in text and 'global_step 3' not in text
+
+
+def ann3depth_latest(d):
+    from ann3depth_amd import ann3depth
+    return ann3depth.latest_checkpoint(d)
