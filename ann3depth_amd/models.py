@@ -336,8 +336,12 @@ class MSDNReplica:
 
     def load_tf_variables(self, tensors):
         """Restore from the tensors of a TensorFlow checkpoint (tfckpt.read_bundle): every model variable by its TF
-        name; Adam slots `<var>/<Optimizer>` / `<var>/<Optimizer>_1`, `<Optimizer>/beta{1,2}_power` and `global_step`
-        when present.  Beta powers that are absent are rebuilt from global_step and the phase schedule."""
+        name; Adam slots `<var>/<Optimizer>` / `<var>/<Optimizer>_1` and `global_step` when present.
+        Beta powers: `<Optimizer>/beta{1,2}_power` is THIS build's name for them (tf_variables below).  TensorFlow 1.3
+        creates them as plain variables `beta1_power`, `beta1_power_1`, ... under whatever name scope apply_gradients
+        ran in (for the reference: inside the tf.cond of src/models.py:340-345), so a reference checkpoint's powers are
+        not looked up; they are rebuilt from global_step and the phase schedule instead — exactly, since the power is
+        beta multiplied into itself once per applied step in float32 (and beta2 = 1 keeps its power at 1)."""
         missing = [n for n in self.shapes if n not in tensors]
         if missing:
             raise KeyError(f'TensorFlow checkpoint lacks {len(missing)} model variables, e.g. {missing[:3]}')

@@ -132,3 +132,113 @@ def test_partitioned_variables_are_refused(tmp_path):
         tfckpt.write_table(f, [(b'', tfckpt.encode_header()), (b'unary/w', entry)])
     with pytest.raises(ValueError, match='partitioned'):
         tfckpt.read_bundle(prefix)
+
+
+# ---- an index + data pair assembled here byte by byte, by code that shares nothing with tfckpt.py -------------------------
+# Layout per the LevelDB table format document (leveldb/doc/table_format.md) and tensorflow/core/protobuf/tensor_bundle.proto
+# (TF 1.3): what TensorFlow's BundleWriter emits differs from write_table's output in ways a reader must not care about —
+# a `version` message in the header, two data shards, every key a restart point in one block and prefix-compressed keys in
+# the next, index separators that are not keys of the table, fields of an entry in another order.
+def _crc32c_bitwise(data):
+    crc = 0xffffffff
+    for byte in bytes(data):
+        crc ^= byte
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82f63b78 & -(crc & 1))
+    return crc ^ 0xffffffff
+
+
+def _mask(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def _vi(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _block(entries, restarts):
+    """entries: (shared, unshared key bytes, value); restarts: byte offsets of the restart points."""
+    body = b''.join(_vi(s) + _vi(len(k)) + _vi(len(v)) + k + v for s, k, v in entries)
+    body += b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+    return body, body + b'\x00' + struct.pack('<I', _mask(_crc32c_bitwise(body + b'\x00')))
+
+
+def test_crc32c_known_answer():
+    assert _crc32c_bitwise(b'123456789') == 0xe3069283                  # RFC 3720 B.4 check value
+    assert tfckpt._masked_crc(b'123456789') == _mask(0xe3069283)
+
+
+def test_reads_a_bundle_assembled_outside_this_package(tmp_path):
+    bias = (np.arange(96, dtype='<f4') - 40) / 7
+    step = np.array(62500, '<i8')
+    b1p = np.array(0.9 ** 3, '<f4')
+    kern = np.linspace(-1, 1, 2 * 3 * 5, dtype='<f4').reshape(2, 3, 5)
+    shard0 = bias.tobytes() + b'\x00' * 8 + step.tobytes()              # a gap between tensors: offsets, not order, count
+    shard1 = b'\xee' * 12 + kern.tobytes() + b1p.tobytes()
+
+    def shape(dims):
+        return b''.join(b'\x12' + _vi(len(_vi(d)) + 1) + b'\x08' + _vi(d) for d in dims)
+
+    def entry(dtype, dims, shard, off, size, payload, reorder=False):
+        f = [b'\x08' + _vi(dtype), b'\x12' + _vi(len(shape(dims))) + shape(dims)]
+        if shard:
+            f.append(b'\x18' + _vi(shard))
+        if off:
+            f.append(b'\x20' + _vi(off))
+        f += [b'\x28' + _vi(size), b'\x35' + struct.pack('<I', _mask(_crc32c_bitwise(payload)))]
+        return b''.join(reversed(f) if reorder else f)
+    header = b'\x08\x02' + b'\x10\x00' + b'\x1a\x02\x08\x01'            # num_shards 2, little endian, version {producer: 1}
+    e_b1p = entry(1, [], 1, 12 + kern.nbytes, 4, b1p.tobytes())
+    e_bias = entry(1, [96], 0, 0, 384, bias.tobytes(), reorder=True)
+    e_kern = entry(1, [2, 3, 5], 1, 12, kern.nbytes, kern.tobytes())
+    e_step = entry(9, [], 0, 392, 8, step.tobytes())
+    # block 1: '', 'beta1_power' — every entry a restart point
+    ents1 = [(0, b'', header), (0, b'beta1_power', e_b1p)]
+    off2 = len(_vi(0) * 2 + _vi(len(header)) + header)
+    body1, raw1 = _block(ents1, [0, off2])
+    # block 2: 'coarse/conv/conv2d_0/bias', '.../kernel' (shares 'coarse/conv/conv2d_0/'), 'global_step' — one restart point
+    ents2 = [(0, b'coarse/conv/conv2d_0/bias', e_bias), (21, b'kernel', e_kern), (0, b'global_step', e_step)]
+    body2, raw2 = _block(ents2, [0])
+    meta_body, meta_raw = _block([], [0])
+    h1 = _vi(0) + _vi(len(body1))
+    h2 = _vi(len(raw1)) + _vi(len(body2))
+    # index block: separators 'c' (>= 'beta1_power', < 'coarse/...') and 'h' (>= 'global_step'): neither is a key
+    idx_body, idx_raw = _block([(0, b'c', h1), (0, b'h', h2)], [0])
+    meta_off = len(raw1) + len(raw2)
+    idx_off = meta_off + len(meta_raw)
+    footer = _vi(meta_off) + _vi(len(meta_body)) + _vi(idx_off) + _vi(len(idx_body))
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57)
+    prefix = str(tmp_path / 'model.ckpt-62500')
+    with open(prefix + '.index', 'wb') as f:
+        f.write(raw1 + raw2 + meta_raw + idx_raw + footer)
+    with open(prefix + '.data-00000-of-00002', 'wb') as f:
+        f.write(shard0)
+    with open(prefix + '.data-00001-of-00002', 'wb') as f:
+        f.write(shard1)
+
+    assert tfckpt.is_bundle(prefix)
+    entries, shards = tfckpt.list_bundle(prefix)
+    assert shards == 2 and list(entries) == ['beta1_power', 'coarse/conv/conv2d_0/bias', 'coarse/conv/conv2d_0/kernel',
+                                              'global_step']
+    got = tfckpt.read_bundle(prefix)
+    np.testing.assert_array_equal(got['coarse/conv/conv2d_0/bias'], bias)
+    np.testing.assert_array_equal(got['coarse/conv/conv2d_0/kernel'], kern)
+    assert got['global_step'].dtype == np.int64 and int(got['global_step']) == 62500 and got['global_step'].shape == ()
+    assert got['beta1_power'] == b1p
+    # a flipped data byte and a flipped index byte are both noticed
+    with open(prefix + '.data-00001-of-00002', 'r+b') as f:
+        f.seek(20)
+        f.write(b'\x01')
+    with pytest.raises(ValueError, match='checksum'):
+        tfckpt.read_bundle(prefix)
+    assert 'global_step' in tfckpt.read_bundle(prefix, names=['global_step'])       # shard 0 is intact
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[len(raw1) + 5] ^= 0x40
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum'):
+        tfckpt.list_bundle(prefix)
