@@ -1,9 +1,11 @@
 // igemm_host.hip — tile/split-K planning, dispatch, split-K reduction, bias-gradient column sums, and the
 // conv2d / dense entry points of include/a3d.h.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -52,6 +54,11 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 // A/B switches of the staging fast paths (tools/bench_layers.py); read once
+// The A3D_FORCE_* / A3D_NO_* / A3D_BF16_BN switches of the sweep and fuzz tools are consulted on every launch ONLY in
+// a process started with A3D_TUNING=1 (the tools set it); otherwise nothing below reads the environment after its first
+// call, and plans are cached per problem (plan_gemm).
+static bool tuning() { static const bool v = env_int("A3D_TUNING", 0) != 0; return v; }
+static int tune_int(const char* name, int dflt) { return tuning() ? env_int(name, dflt) : dflt; }
 static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
 static bool env_flag_no_streamk() { static const bool v = env_int("A3D_NO_STREAMK", 0) != 0; return v; }
 static bool env_flag_no_kperm() { static const bool v = env_int("A3D_NO_KPERM", 0) != 0; return v; }
@@ -75,13 +82,13 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   GemmPlan pl{};
   pl.prec = precision;
   pl.bf16_bn = g.N <= 64 ? 64 : 128;
-  if (env_int("A3D_BF16_BN", 0) == 64 || env_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = env_int("A3D_BF16_BN", 0);
+  if (tune_int("A3D_BF16_BN", 0) == 64 || tune_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = tune_int("A3D_BF16_BN", 0);
   pl.tiles_m = (g.M + 127) / 128;
   pl.tiles_n = (g.N + pl.bf16_bn - 1) / pl.bf16_bn;
   const int nk = std::max(1, (g.K + 31) / 32);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk / 12));
-  if (env_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(env_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
+  if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
   pl.splitk = (nk + kps - 1) / kps;
@@ -90,13 +97,30 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   return pl;
 }
 
+static GemmPlan plan_gemm_search(const GemmProblem& g, int precision);
+
+// The search below walks 11 tile configurations x ~50 split factors: once per distinct problem, not once per launch
+// (a training step launches the same ~50 problems over and over).
 GemmPlan plan_gemm(const GemmProblem& g, int precision) {
+  if (tuning()) return plan_gemm_search(g, precision);
+  static std::mutex mu;
+  static std::map<std::array<int, 9>, GemmPlan> cache;
+  const std::array<int, 9> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision};
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const GemmPlan plan = plan_gemm_search(g, precision);
+  cache.emplace(key, plan);
+  return plan;
+}
+
+static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
   if (precision != A3D_PREC_F32 && g.avec == 4 && g.bvec == 4) return plan_gemm_bf16(g, precision);
   GemmPlan best{};
   double best_t = 1e300;
   const int nk = std::max(1, (g.K + 31) / 32);
-  const int force_cfg = env_int("A3D_FORCE_CFG", -1), force_split = env_int("A3D_FORCE_SPLITK", -1);
-  const int force_streamk = env_int("A3D_FORCE_STREAMK", 0);      // tuning aid: stream-K with this many blocks
+  const int force_cfg = tune_int("A3D_FORCE_CFG", -1), force_split = tune_int("A3D_FORCE_SPLITK", -1);
+  const int force_streamk = tune_int("A3D_FORCE_STREAMK", 0);      // tuning aid: stream-K with this many blocks
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
@@ -290,7 +314,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   p.stamps = grid * 8ull * 16 * 8 <= kStampBytes ? g_stamps : nullptr;
   g_stamp_grid = grid;
 #endif
-  p.dbg = env_int("A3D_DBG", 0);
+  p.dbg = tune_int("A3D_DBG", 0);
   static const bool plan_log = env_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
   if (plan_log)
     fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d grid %u\n", mode, p.M, p.N, p.K,
@@ -366,7 +390,7 @@ struct RunForm {
 };
 static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
   if (d->pad_t || d->pad_l || d->ldx != d->c || d->c % 4 == 0 || d->c > 4) return false;
-  if (env_int("A3D_NO_RUNFORM", 0)) return false;
+  if (tune_int("A3D_NO_RUNFORM", 0)) return false;
   const int step = d->stride * d->c, row = d->w * d->c;
   int vec = 0;
   if (step % 4 == 0 && row % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) vec = 4;
@@ -698,8 +722,8 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   unsigned multi_grid = 0;
   long multi_tiles = 0;
   double multi_flops = 0;
-  const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !d->storage && !env_int("A3D_NO_MULTI", 0) &&
-                         env_int("A3D_FORCE_CFG", -1) < 0;
+  const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !d->storage && !tune_int("A3D_NO_MULTI", 0) &&
+                         tune_int("A3D_FORCE_CFG", -1) < 0;
   for (int ph = 0; ph < d->stride; ++ph) {
     for (int pw = 0; pw < d->stride; ++pw) {
       BwdDClass c;
@@ -889,7 +913,7 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
   if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) &&
-      !env_int("A3D_NO_DENSE_KERNELS", 0))
+      !tune_int("A3D_NO_DENSE_KERNELS", 0))
     return dense_fwd_stream(m, k, n, x, w, bias, y, act, drop_keep, 2.f, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(&d);
   if (!aligned16(x)) g.avec = 1;
@@ -959,7 +983,7 @@ size_t a3d_dense_bwd_filter_ws_bytes(int m, int k, int n) {
 int a3d_dense_bwd_filter(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, void* ws,
                          size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_filter: bad dims");
-  if (dense_dw_applicable(m, k, n) && (long)k * n >= (1L << 16) && !env_int("A3D_NO_DENSE_KERNELS", 0)) {      // small batch: stream dw once (dense.hip)
+  if (dense_dw_applicable(m, k, n) && (long)k * n >= (1L << 16) && !tune_int("A3D_NO_DENSE_KERNELS", 0)) {      // small batch: stream dw once (dense.hip)
     A3D_CHECK_ARG(x && dz && dw, "dense_bwd_filter: null tensor");
     return dense_dw_launch(m, k, n, x, dz, dw, db, static_cast<hipStream_t>(stream));
   }

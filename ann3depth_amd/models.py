@@ -468,6 +468,7 @@ class MSDNReplica:
         ops.resize_bilinear_tf1(images, self.x)
         ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
+        self.dropout_on = keep_mask is not None            # None: the plugin was called with train=False
         fused = self.fuse_pool and phase in (1, 2, 3)
         self.pooled_fwd = phase if fused else None
         lean_fine = fused
@@ -543,7 +544,8 @@ class MSDNReplica:
         if after_dense1 is not None:
             after_dense1()         # dense_1's gradient (67 MB) is complete: first piece of the dense bucket
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
-        ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0)
+        # (train=False, src/models.py:230: tf.layers.dropout is the identity; only the ReluGrad remains)
+        ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
         n = 'coarse/dense/dense_0'
         flat = (self.c4_32 if self.bf16s else self.c4).view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
@@ -603,7 +605,7 @@ class MSDNReplica:
         """images [B,H,W,3], depths [B,H',W',1] float32, keep_mask [B,4096] bool/uint8, all on this device.
         Both forwards and both losses run in every phase; gradients + Adam only for the active phase;
         global_step += 1 always (src/models.py:329,343,356)."""
-        if keep_mask.dtype != torch.uint8:
+        if keep_mask is not None and keep_mask.dtype != torch.uint8:
             keep_mask = keep_mask.to(torch.uint8)
         phase = phase_of(self.global_step, self.B)
         self.forward(images, depths, keep_mask, join=False, phase=phase)
@@ -1032,6 +1034,7 @@ class _MultiScaleDeepNetwork:
         replica = MSDNReplica(images.pipeline.B, device=torch.device('cuda', torch.cuda.current_device()),
                               seed=self.seed, beta2=self.beta2, reducer=self.reducer, precision=self.precision,
                               keep_dense_grads=False)        # one GPU + the reference's optimizer: dW feeds ApplyAdam directly
+        replica.uses_dropout = bool(train)                   # train=False: tf.layers.dropout(training=False), src/models.py:230
         if self.reducer is not None:                         # replicas start from rank 0's weights
             for g in replica.groups.values():
                 self.reducer.broadcast(g.var)

@@ -123,23 +123,21 @@ def roofline_from(recs):
     return roof, table
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (numpy + OpenBLAS, 'port') on this box's host cores: coarse-phase train steps at B=8 on the same
-    synthetic data shape; bounded to ~seconds_budget of CPU work."""
+def cpu_baseline(B=32, seconds_budget=25.0):
+    """The oracle (numpy + OpenBLAS, 'port') on this box's host cores: the SAME workload as the GPU line — coarse-phase
+    train steps at the same batch, on synth_batch's images and depths and keep_masks' dropout masks — bounded to about
+    seconds_budget of CPU work (a step at B=32 takes ~5 s: a handful of steps)."""
     from oracle import msdn as O
-    B = 8
-    rng = np.random.default_rng(1000)
-    img = (rng.integers(0, 256, (B, 480, 640, 3)) / 255).astype(np.float32)
-    dep = (rng.integers(0, 256, (B, 480, 640, 1)) / 255).astype(np.float32)
-    keep = rng.random((B, 4096)) >= 0.5
+    img, dep = (t.numpy() for t in synth_batch(B, 0, 'cpu'))
     tr = O.Trainer(O.init_params(3000), B)
+    keeps = [k.numpy().astype(bool) for k in keep_masks(B, 8, 0, 'cpu')]
     t0 = time.perf_counter()
-    tr.step(img, dep, keep)                       # warm-up (BLAS threads, page faults)
+    tr.step(img, dep, keeps[0])                   # warm-up (BLAS threads, page faults)
     first = time.perf_counter() - t0
-    n = max(1, min(8, int(seconds_budget / max(first, 1e-3)) - 1))
+    n = max(1, min(7, int(seconds_budget / max(first, 1e-3)) - 1))
     t0 = time.perf_counter()
-    for _ in range(n):
-        tr.step(img, dep, keep)
+    for i in range(n):
+        tr.step(img, dep, keeps[1 + i])
     dt = time.perf_counter() - t0
     threads = os.cpu_count()
     try:                                            # the BLAS pool is what actually does the work (OpenBLAS caps it)
@@ -150,8 +148,9 @@ def cpu_baseline(seconds_budget=25.0):
     except Exception:                               # noqa: BLE001 - reporting only
         pass
     return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} coarse-phase train steps at batch {B} (480x640 stored -> 228x304 net), numpy oracle with '
-                      f'{threads} OpenBLAS threads on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
+            'sample': f'{n} coarse-phase train steps at batch {B}, same synthetic inputs and step definition as the GPU line '
+                      f'(480x640 stored -> 228x304 net); numpy oracle with {threads} OpenBLAS threads (the pool\'s '
+                      f'compiled-in cap) on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
 
 
 def hbm_bytes_bf16_storage(B):
@@ -340,7 +339,7 @@ def main():
         line.update(extra)
         line.update(comm)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(B)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

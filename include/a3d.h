@@ -7,8 +7,14 @@
  * Conventions
  *   - Layouts are TensorFlow's: activations NHWC, conv filters HWIO ([R][S][Cin][Cout]), dense kernels [in][out].
  *   - All tensors are float32 device pointers owned by the caller (PyTorch is only the allocator).  The library
- *     allocates nothing, keeps no global state, and never synchronises: every call only enqueues work on the
- *     caller's hipStream_t (passed as void*), so it is stream-ordered and graph-capturable.
+ *     allocates no device memory and never synchronises: every compute call only enqueues work on the caller's
+ *     hipStream_t (passed as void*), so it is stream-ordered and graph-capturable.
+ *   - Process-wide state, all of it host-side: the thread-local error message; a cache of launch plans keyed by
+ *     problem shape (mutex-guarded, never invalidated: a plan depends on nothing else); the launch-timing list of
+ *     a3d_timing_enable / a3d_timing_collect, which is ONE list for every stream and thread — enable it from one
+ *     place, and not during graph capture (it records hipEvents); and the environment switches, read once per process
+ *     (A3D_NO_STREAMK, A3D_NO_UNI, A3D_NO_KPERM, A3D_PLAN_LOG, A3D_TUNING; with A3D_TUNING=1 the sweep tools'
+ *     A3D_FORCE_* switches are read on every launch instead).
  *   - `ws` is caller-provided scratch of at least the size the matching *_ws_bytes() query returns.
  *   - Return value: 0 (A3D_OK) or a negative A3D_E* code; a3d_last_error() gives a thread-local message.
  *     Nothing throws across the ABI and nothing calls exit().

@@ -94,7 +94,8 @@ def forward(p, images, depths, keep_mask):
     a['flat'] = a['c4'].reshape(B, -1)                           # NHWC flatten, 12288
     a['d0'] = T.dense_fwd(a['flat'], p['coarse/dense/dense_0/kernel'], p['coarse/dense/dense_0/bias'], 'relu')
     a['keep_mask'] = keep_mask
-    a['drop'] = T.dropout_fwd(a['d0'], keep_mask)
+    # keep_mask None = the plugin called with train=False: tf.layers.dropout(training=False) is the identity (:230)
+    a['drop'] = a['d0'] if keep_mask is None else T.dropout_fwd(a['d0'], keep_mask)
     a['d1'] = T.dense_fwd(a['drop'], p['coarse/dense/dense_1/kernel'], p['coarse/dense/dense_1/bias'])
     a['coarse'] = coarse = a['d1'].reshape(B, OUT_H, OUT_W, 1)
     # fine (src/models.py:238-253)
@@ -125,7 +126,7 @@ def backward_coarse(p, a):
     dz1 = dcoarse.reshape(B, -1)
     ddrop, g['coarse/dense/dense_1/kernel'], g['coarse/dense/dense_1/bias'] = \
         T.dense_bwd(a['drop'], p['coarse/dense/dense_1/kernel'], dz1)
-    dd0 = T.dropout_bwd(ddrop, a['keep_mask'])
+    dd0 = ddrop if a['keep_mask'] is None else T.dropout_bwd(ddrop, a['keep_mask'])
     dz0 = T.relu_grad(dd0, a['d0'])
     dflat, g['coarse/dense/dense_0/kernel'], g['coarse/dense/dense_0/bias'] = \
         T.dense_bwd(a['flat'], p['coarse/dense/dense_0/kernel'], dz0)

@@ -1,5 +1,6 @@
 """Times the dense-layer entry points (a3d_dense_*) at MSDN's shapes: [B, 12288] x [12288, 4096] and [B, 4096] x [4096, 4070]."""
 import os
+os.environ.setdefault('A3D_TUNING', '1')   # the library reads its A3D_FORCE_* switches per launch only then
 import sys
 
 import torch

@@ -3,6 +3,7 @@ suite; the shapes that ever failed live in tests/test_gpu_ops.py).     python to
 Shapes are drawn to hit the planner's corners: odd sizes, K tails, split-K factors that are not powers of two, strides
 1/2/4, SAME and VALID, channel counts that are / are not multiples of 4, and problems big enough for every tile class."""
 import os
+os.environ.setdefault('A3D_TUNING', '1')   # the library reads its A3D_FORCE_* switches per launch only then
 import sys
 import time
 

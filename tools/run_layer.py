@@ -1,6 +1,7 @@
 """Runs one MSDN layer/direction a few times (optionally with a forced tile config) — target for rocprofv3 --pmc.
     python tools/run_layer.py conv2d_1 fwd [cfg [splitk [reps]]]"""
 import os
+os.environ.setdefault('A3D_TUNING', '1')   # the library reads its A3D_FORCE_* switches per launch only then
 import sys
 
 import torch

@@ -3,6 +3,7 @@ the -DA3D_STAMPS build (tools/ab/liba3d_stamps.so; see csrc/Makefile).  Not a ti
     A3D_LIB=tools/ab/liba3d_stamps.so python tools/stamps_layer.py conv2d_1 fwd [cfg [splitk]]"""
 import ctypes
 import os
+os.environ.setdefault('A3D_TUNING', '1')   # the library reads its A3D_FORCE_* switches per launch only then
 import sys
 
 import numpy as np

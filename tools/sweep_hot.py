@@ -1,5 +1,6 @@
 """Compact re-fit sweep: hot MSDN layers x direction x {tile config} x a few split / stream-K choices."""
 import os, sys, json
+os.environ['A3D_TUNING'] = '1'   # the library reads its A3D_FORCE_* switches per launch only then
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ann3depth_amd import ops

@@ -1,6 +1,7 @@
 """Times every MSDN layer (B=32) x direction under each tile config / split-K of the implicit-GEMM kernel.
 Tuning aid for csrc/igemm_host.hip:plan_gemm; run on the GPU box:  python tools/sweep_igemm.py > gpurun_out/sweep.txt"""
 import os
+os.environ.setdefault('A3D_TUNING', '1')   # the library reads its A3D_FORCE_* switches per launch only then
 import sys
 
 import torch
