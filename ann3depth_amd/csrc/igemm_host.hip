@@ -274,10 +274,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
   }
 }
 
+// Many slabs, few outputs (conv2d_0's bwd-filter: 128 slabs of 36 k floats, and its 96 bias sums): one thread per output
+// means 35 blocks on 256 CUs, each walking 128 dependent-latency rounds — 28 us for 18 MB.  Here sixteen threads share
+// an output: thread `part` adds its contiguous sixteenth of the slabs in slab order, the sixteen partial sums meet in
+// LDS and are added in part order.  A fixed order, so still the same bits on every run (a different order than the
+// one-thread sum above: a launch uses one or the other by shape alone, never by timing).
+template <typename V>
+__device__ __forceinline__ void reduce_wide(const V* src, V* dst, size_t slab, size_t count, int splitk, size_t first,
+                                            V* lds) {
+  const int tid = threadIdx.x, out = tid & 15, part = tid >> 4;
+  const size_t i = first + out;
+  const int per = (splitk + 15) / 16, z0 = part * per, z1 = min(splitk, z0 + per);
+  V s = V(0.f);
+  if (i < count) {
+    int z = z0;
+    for (; z + 4 <= z1; z += 4) {
+      const V a = src[(size_t)z * slab + i], b = src[(size_t)(z + 1) * slab + i];
+      const V c = src[(size_t)(z + 2) * slab + i], d = src[(size_t)(z + 3) * slab + i];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; z < z1; ++z) s += src[(size_t)z * slab + i];
+  }
+  lds[part * 16 + out] = s;
+  __syncthreads();
+  if (part == 0 && i < count) {
+    V t = lds[out];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += lds[q * 16 + out];
+    dst[i] = t;
+  }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const ReduceParams p, unsigned blocks_c) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ f4 lds[256];
+  if (blockIdx.x < blocks_c)
+    reduce_wide<f4>(reinterpret_cast<const f4*>(p.ws), reinterpret_cast<f4*>(p.C), p.slab / 4, (size_t)p.M * p.N / 4,
+                    p.splitk, (size_t)blockIdx.x * 16, lds);
+  else
+    reduce_wide<float>(p.dbias_ws, p.dbias_out, (size_t)p.N, (size_t)p.N, p.splitk, (size_t)(blockIdx.x - blocks_c) * 16,
+                       reinterpret_cast<float*>(lds));
+}
+
 int launch_splitk_reduce(const ReduceParams& r, hipStream_t st) {
   const size_t total = (size_t)r.M * r.N;
-  const unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
   clear_stale_error();
+  static const bool no_wide = env_int("A3D_NO_WIDE_REDUCE", 0) != 0;      // A/B aid
+  if (!no_wide && r.vec4 && r.splitk >= 16 && total / 4 <= (size_t)1 << 16) {
+    const unsigned blocks_c = (unsigned)((total / 4 + 15) / 16), blocks_b = r.dbias_out ? (unsigned)((r.N + 15) / 16) : 0u;
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(blocks_c + blocks_b), dim3(256), 0, st, r, blocks_c);
+    return check_launch("splitk_reduce_wide");
+  }
+  const unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
   return check_launch("splitk_reduce");
 }
@@ -365,13 +412,9 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.vec4 = mode == MODE_BWD_F && p.ldc == p.N && (p.slab % 4) == 0 && aligned16(final_c) && aligned16(ws);
     r.sub_step = p.sub_step; r.sub_ph = p.sub_ph; r.sub_pw = p.sub_pw; r.outW = p.outW; r.outHW = p.outHW;
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
-    size_t total = (size_t)p.M * p.N;
-    unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
     r.dbias_ws = final_dbias ? p.dbias : nullptr;
     r.dbias_out = final_dbias;
-    clear_stale_error();
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
-    rc = check_launch("splitk_reduce");
+    rc = launch_splitk_reduce(r, st);
   }
   return rc;
 }

@@ -92,6 +92,10 @@ def test_msdn_step_matches_oracle(models, phase, global_step):
         np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])
         opt = tr.opt[net.group_of[n]]
         if n in opt.m:
+            # m = 0 + (g - 0) * (1 - beta1) in separate fp32 operations (ApplyAdam, training_ops.cc): bit for bit from
+            # the gradient the chain test above pinned at 1e-4; against the oracle's own m only as loosely as its g
+            g32 = net.grad(n).cpu().numpy()
+            np.testing.assert_array_equal(net.slot(n, 'm').cpu().numpy(), g32 * (np.float32(1) - np.float32(0.9)))
             assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < GRAD_TOL_END_TO_END, n
             assert (net.slot(n, 'v').cpu().numpy() == 0).all()
 
@@ -199,6 +203,24 @@ def test_msdn_bf16_modes_keep_the_depth_tolerance(models, prec, tol):
         g = O.backward_coarse(params, a_gpu)
         for n, gref in g.items():
             assert rel(net.grad(n).cpu().numpy(), gref) < 2e-4, n
+
+
+def test_msdn_without_dropout_when_the_plugin_is_called_with_train_false(models):
+    """models.msdn(images, depths, train=False) (src/models.py:277 -> :230): tf.layers.dropout is the identity, the
+    optimizers still run.  keep_mask None is that mode of the replica."""
+    B = 2
+    img, dep, _ = synth(B, 1003)
+    params = O.init_params(3000)
+    net = models.MSDNReplica(B, params=params)
+    out = net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), None)
+    torch.cuda.synchronize()
+    a = O.forward(params, img, dep, None)
+    assert rel(net.drop.cpu().numpy(), a['d0']) < 1e-4 and rel(net.coarse.cpu().numpy(), a['coarse']) < DEPTH_TOL
+    assert abs(out['coarse_loss'].item() - a['loss_coarse']) < LOSS_TOL * abs(a['loss_coarse'])
+    a_gpu = gpu_activations(net)
+    a_gpu['keep_mask'] = None
+    for n, gref in O.backward_coarse(params, a_gpu).items():
+        assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
 
 
 @pytest.mark.parametrize('B', [1, 5])
