@@ -217,13 +217,22 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
 
 // Sums the split-K slabs in slab order (deterministic) and applies the epilogue.  Slab reads are issued four at a
 // time into independent registers: a thread's serial chain of `splitk` dependent loads was the cost of this kernel.
-__device__ __forceinline__ float slab_sum(const float* ws, size_t slab, int splitk, size_t i) {
-  float s = 0.f;
+template <typename V>
+__device__ __forceinline__ V slab_sum(const V* ws, size_t slab, int splitk, size_t i) {
+  V s = V(0.f);
   int z = 0;
-  for (; z + 4 <= splitk; z += 4) {
-    const float a = ws[(size_t)z * slab + i], b = ws[(size_t)(z + 1) * slab + i];
-    const float c = ws[(size_t)(z + 2) * slab + i], d = ws[(size_t)(z + 3) * slab + i];
+  for (; z + 8 <= splitk; z += 8) {       // eight slabs in flight, added in slab order
+    V t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = ws[(size_t)(z + u) * slab + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  if (z + 4 <= splitk) {
+    const V a = ws[(size_t)z * slab + i], b = ws[(size_t)(z + 1) * slab + i];
+    const V c = ws[(size_t)(z + 2) * slab + i], d = ws[(size_t)(z + 3) * slab + i];
     s += a; s += b; s += c; s += d;
+    z += 4;
   }
   for (; z < splitk; ++z) s += ws[(size_t)z * slab + i];
   return s;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
   const size_t total = (size_t)p.M * p.N;
   if (p.dbias_out) {       // N sums of `splitk` values: the grid's first threads do them on the side
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.N; i += (size_t)gridDim.x * 256)
-      p.dbias_out[i] = slab_sum(p.dbias_ws, (size_t)p.N, p.splitk, i);
+      p.dbias_out[i] = slab_sum<float>(p.dbias_ws, (size_t)p.N, p.splitk, i);
   }
   if (p.vec4) {   // plain sum of 16-byte columns: bwd-filter slabs (no epilogue, contiguous output)
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -241,20 +250,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
     const f4* ws4 = reinterpret_cast<const f4*>(p.ws);
     const size_t slab4 = p.slab / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-      f4 s = {0.f, 0.f, 0.f, 0.f};
-      int z = 0;
-      for (; z + 4 <= p.splitk; z += 4) {
-        const f4 a = ws4[(size_t)z * slab4 + i], b = ws4[(size_t)(z + 1) * slab4 + i];
-        const f4 c = ws4[(size_t)(z + 2) * slab4 + i], d = ws4[(size_t)(z + 3) * slab4 + i];
-        s += a; s += b; s += c; s += d;
-      }
-      for (; z < p.splitk; ++z) s += ws4[(size_t)z * slab4 + i];
-      reinterpret_cast<f4*>(p.C)[i] = s;
+      reinterpret_cast<f4*>(p.C)[i] = slab_sum<f4>(ws4, slab4, p.splitk, i);
     }
     return;
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    float s = slab_sum(p.ws, p.slab, p.splitk, i);
+    float s = slab_sum<float>(p.ws, p.slab, p.splitk, i);
     const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
     const size_t o = remap_row(row, p.mode == MODE_BWD_D ? p.sub_step : 1, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw,
                                p.div_pw) * p.ldc + col;

@@ -312,10 +312,23 @@ __global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict_
   const float* o = out + (size_t)b * npix;
   const float* t = tgt + (size_t)b * npix;
   float s2 = 0.f, s1 = 0.f;
-  for (int i = threadIdx.x; i < npix; i += 256) {
-    const float d = __fsub_rn(masked_log(o[i]), masked_log(t[i]));
-    s2 += d * d;
-    s1 += d;
+  // eight elements per thread and round, all sixteen loads issued before the first logarithm: a block is alone on its
+  // CU with one sample (4070 pixels at MSDN's size), so what this loop costs is its chain of load latencies
+  for (int i0 = threadIdx.x; i0 < npix; i0 += 8 * 256) {
+    float ov[8], tv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      ov[u] = i < npix ? o[i] : 0.f;
+      tv[u] = i < npix ? t[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u * 256 >= npix) break;
+      const float d = __fsub_rn(masked_log(ov[u]), masked_log(tv[u]));
+      s2 += d * d;
+      s1 += d;
+    }
   }
   s2 = wave_sum(s2);
   s1 = wave_sum(s1);
