@@ -317,7 +317,8 @@ def main():
         dta, _ = run_phase(alt, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
         extra.setdefault('other_precisions', {})[prec] = {
             'value': round(world * B * args.steps / dta, 1), 'ms_per_step': round(1e3 * dta / args.steps, 3),
-            'note': 'conv contractions on the bf16 matrix cores; NOT the headline: parity is stated for fp32'}
+            'note': ('the reference arithmetic (fp32 MFMA), same batch' if prec == 'fp32' else
+                     'conv contractions on the bf16 matrix cores; NOT the headline: parity is stated for fp32')}
         del alt
     comm = {}
     if world > 1:
