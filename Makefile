@@ -34,7 +34,22 @@ TIMEOUT ?= 4200
 GPUS ?= 1
 WORKERS ?= 8
 
-# `make convert nyu make3d1`: dataset names as extra goals, like the reference (Makefile:74-78)
+# Preprocessing sizes (the reference's Makefile:46-59)
+WIDTH ?= 640
+HEIGHT ?= 480
+DHEIGHT ?= 55
+DWIDTH ?= $(shell echo $$(( ${DHEIGHT} * ${WIDTH} / ${HEIGHT} )))
+FORCE ?=
+START ?= 0
+LIMIT ?=
+
+# `make convert nyu make3d1` / `make preprocess nyu`: dataset names as extra goals, like the reference (Makefile:68-78)
+ifeq (preprocess,$(firstword $(MAKECMDGOALS)))
+    ifneq (,$(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS)))
+        DATASET := $(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS))
+        $(eval $(DATASET):;@:)
+    endif
+endif
 ifeq (convert,$(firstword $(MAKECMDGOALS)))
     ifneq (,$(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS)))
         DATASET := $(wordlist 2,$(words $(MAKECMDGOALS)),$(MAKECMDGOALS))
@@ -56,6 +71,12 @@ endif
 .PHONY: train
 train: ${DATA_DIR}
 	${SCRIPT} ${SCRIPT_PARAMETERS} ${DATASET}
+
+# raw downloads -> PNG pairs of one size (the reference's `make preprocess`, Makefile:118-121), without h5py / scipy.misc;
+# NYU only (tools/data_preprocessor.py)
+.PHONY: preprocess
+preprocess: ${DATA_DIR}
+	DATA_DIR=${DATA_DIR} WIDTH=${WIDTH} HEIGHT=${HEIGHT} DHEIGHT=${DHEIGHT} DWIDTH=${DWIDTH} FORCE=${FORCE} START=${START} LIMIT=${LIMIT} python3 tools/data_preprocessor.py $(DATASET)
 
 # convert preprocessed PNG pairs to TFRecord shards (the reference's `make convert`, Makefile:123-126), TF-free
 .PHONY: convert
