@@ -456,12 +456,13 @@ static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
 }
 
 // filter [R*RL][N] <-> padded [R*RLP][N] (pad rows zero)
-__global__ __launch_bounds__(256) void pad_filter_kernel(const float* w, float* wp, int r, int rl, int rlp, int n) {
-  const int total = r * rlp * n;
+// (forward: the copy's rows are also padded to `np` >= n columns, zeros: fine/first's 63 filters become 16-byte rows)
+__global__ __launch_bounds__(256) void pad_filter_kernel(const float* w, float* wp, int r, int rl, int rlp, int n, int np) {
+  const int total = r * rlp * np;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int col = i % n, row = i / n;
+    const int col = i % np, row = i / np;
     const int q = row % rlp, rr = row / rlp;
-    wp[i] = q < rl ? w[(size_t)(rr * rl + q) * n + col] : 0.f;
+    wp[i] = (q < rl && col < n) ? w[(size_t)(rr * rl + q) * n + col] : 0.f;
   }
 }
 __global__ __launch_bounds__(256) void unpad_filter_kernel(const float* wp, float* w, int r, int rl, int rlp, int n) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void unpad_filter_kernel(const float* wp, floa
   }
 }
 static size_t run_filter_bytes(const a3d_conv_desc* d, const RunForm& rf) {
-  return ((size_t)rf.kp * d->k * 4 + 255) / 256 * 256;
+  return ((size_t)rf.kp * ((d->k + 3) / 4 * 4) * 4 + 255) / 256 * 256;      // forward: rows padded to 16 bytes
 }
 
 // ---- descriptor checks / parameter assembly ----
@@ -656,17 +657,20 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
   size_t ws_used = 0;
   const float* filter = w;
+  int run_ldb = d->k;
   if (run) {                                   // window-run form: K = (r, padded run), filter padded into the workspace
     g.K = rf.kp; g.avec = rf.vec;
     ws_used = run_filter_bytes(d, rf);
     float* wp = static_cast<float*>(ws);
     clear_stale_error();
-    hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * d->k + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
-                       rf.rlp, d->k);
+    const int np = d->storage ? d->k : (d->k + 3) / 4 * 4;       // (the bf16 paths keep the filter's own row length)
+    hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
+                       rf.rlp, d->k, np);
     rc = check_launch("pad_filter");
     if (rc != A3D_OK) return rc;
     filter = wp;
-    g.bvec = (d->k % 4 == 0) ? 4 : 1;           // the padded copy is 256-byte aligned
+    run_ldb = np;
+    g.bvec = (np % 4 == 0) ? 4 : 1;             // the padded copy is 256-byte aligned
   }
   IgemmParams p;
   fill_common(p, g);
@@ -693,7 +697,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(p.S);
   p.div_c_half = make_fastdiv(std::max(1, p.Cg / 2));
-  p.ldb = d->k; p.ldc = d->ldy;
+  p.ldb = run ? run_ldb : d->k; p.ldc = d->ldy;
   if (pool) {
     p.pool = 1;
     p.argmax = argmax;
@@ -703,7 +707,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   {
     // nocheck needs the LAST window inside the image: rows (ho-1)*stride + r - 1 < h; columns: the last gathered float
     const bool inside = (d->ho - 1) * d->stride + d->r <= d->h && (d->wo - 1) * d->stride + d->s <= d->w;
-    fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * d->ldx, (unsigned long long)g.K * d->k,
+    fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * d->ldx, (unsigned long long)g.K * (run ? run_ldb : d->k),
                  run ? d->r : d->r, run ? 1 : d->s, inside ? d->r : 0, inside ? d->s : 0);
   }
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
