@@ -351,21 +351,25 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
 // Here dz is read once per block, and the next group's x rows and m tile are requested while the current group is
 // updated and stored, x FIRST, so that the contraction of the next group never waits on HBM.  Buffer loads and stores
 // throughout (rows and columns past the end go to the out-of-range offset): the loop body is straight-line code.
-template <int CW>
+template <int CW, int MB>
 __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                       float* __restrict__ var_w, float* __restrict__ m_w,
                                                                       float* __restrict__ v_w, float* __restrict__ var_b,
                                                                       float* __restrict__ m_b, float* __restrict__ v_b,
                                                                       int M, int K, int N, float omb1, float gscale,
                                                                       int gpb) {
-  constexpr int G = 4 / CW, NI = 512 / (64 * CW);
+  // MB = 1: up to 32 batch rows, a block owns 512 columns (128 per wave); MB = 2: up to 64 rows and 256 columns, so that
+  // the dz registers stay at 64 per lane (batch rows x columns per wave is the same in both)
+  constexpr int BCOLS = 512 / MB, WCOLS = 128 / MB, TSTEPS = 16 * MB, TLD = BCOLS + 4;
+  constexpr int G = WCOLS / (32 * CW), NI = BCOLS / (64 * CW);
+  static_assert(G >= 1 && NI >= 1, "columns per lane");
   typedef float vec __attribute__((ext_vector_type(CW)));
   typedef uint32_t uvec __attribute__((ext_vector_type(CW)));
-  __shared__ __attribute__((aligned(16))) float tile[32 * kRowsLd];
-  __shared__ __attribute__((aligned(16))) float xs[32 * 32];        // x[batch row][weight row of the group]
+  __shared__ __attribute__((aligned(16))) float tile[32 * TLD];
+  __shared__ __attribute__((aligned(16))) float xs[32 * MB * 32];   // x[batch row][weight row of the group]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int nb = blockIdx.x * 512, n0 = nb + wave * 128;
+  const int nb = blockIdx.x * BCOLS, n0 = nb + wave * WCOLS;
   const int ngroups = (K + 31) / 32, g0 = blockIdx.y * gpb, g1 = min(g0 + gpb, ngroups);
   const bool use_scale = gscale != 1.f;
   const float qnan = __builtin_nanf("");
@@ -373,19 +377,27 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
   const __amdgpu_buffer_rsrc_t rz = make_rsrc(dz, (unsigned long long)M * N * 4);
 
   // dz: lane's CW columns of group gq, batch rows 2u + lh
-  float bq[16][G][CW];
+  float bq[TSTEPS][G][CW];
 #pragma unroll
-  for (int u = 0; u < 16; ++u)
+  for (int u = 0; u < TSTEPS; ++u)
 #pragma unroll
     for (int gq = 0; gq < G; ++gq) {
       const int m = 2 * u + lh, col = n0 + (32 * gq + li) * CW;
       load_vec_buf<CW>(rz, ((m < M) & (col < N)) ? (uint32_t)(((size_t)m * N + col) * 4) : kOOB, bq[u][gq]);
     }
-  // x rows of a group: 32 batch rows x 32 weight rows = one 16-byte load per thread (K % 4 == 0)
+  // x rows of a group: 32*MB batch rows x 32 weight rows = MB 16-byte loads per thread (K % 4 == 0)
   const int xm = tid >> 3, xk = (tid & 7) * 4;
-  auto load_x = [&](float (&xv)[4], int g) {
+  auto load_x = [&](float (&xv)[MB][4], int g) {
     const int krow = 32 * g + xk;
-    load_vec_buf<4>(rx, ((g < g1) & (xm < M) & (krow < K)) ? (uint32_t)(((size_t)xm * K + krow) * 4) : kOOB, xv);
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      load_vec_buf<4>(rx, ((g < g1) & (xm + 32 * b < M) & (krow < K)) ? (uint32_t)(((size_t)(xm + 32 * b) * K + krow) * 4) : kOOB,
+                      xv[b]);
+  };
+  auto park_x = [&](const float (&xv)[MB][4]) {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      *reinterpret_cast<f32x4v*>(&xs[(xm + 32 * b) * 32 + xk]) = (f32x4v){xv[b][0], xv[b][1], xv[b][2], xv[b][3]};
   };
   // m tile of a group: this wave's rows 8*wave .. +7, NI pieces each.  One resource per row (scalar arithmetic: a row
   // that does not exist gets zero records), one lane offset for all of them.
@@ -406,14 +418,14 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
     }
   };
 
-  float xv[4], mreg[8 * NI][CW];
+  float xv[MB][4], mreg[8 * NI][CW];
   load_x(xv, g0);
   __builtin_amdgcn_sched_barrier(0);
   load_m(mreg, g0);
-  *reinterpret_cast<f32x4v*>(&xs[xm * 32 + xk]) = (f32x4v){xv[0], xv[1], xv[2], xv[3]};
+  park_x(xv);
 
   if (blockIdx.y == 0 && m_b != nullptr) {        // BiasAddGrad + its Adam step, two columns per thread
-    for (int col = nb + tid; col < nb + 512 && col < N; col += 256) {
+    for (int col = nb + tid; col < nb + BCOLS && col < N; col += 256) {
       float s = 0.f;
       for (int m0 = 0; m0 < M; m0 += 8) {
         float t[8];
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[gq][j][v] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < TSTEPS; ++u) {
       const float a = xs[(2 * u + lh) * 32 + li];
 #pragma unroll
       for (int gq = 0; gq < G; ++gq)
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
         vec t;
 #pragma unroll
         for (int j = 0; j < CW; ++j) t[j] = acc[gq][j][v];
-        *reinterpret_cast<vec*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * kRowsLd + wave * 128 + (32 * gq + li) * CW]) = t;
+        *reinterpret_cast<vec*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * TLD + wave * WCOLS + (32 * gq + li) * CW]) = t;
       }
     __syncthreads();
     load_x(xv, g + 1);        // before the m requests: loads come back in issue order
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
 #pragma unroll
       for (int h = 0; h < NI; ++h) {
         const int c = (h * 64 + lane) * CW;
-        const vec g4 = *reinterpret_cast<const vec*>(&tile[(wave * 8 + r) * kRowsLd + c]);
+        const vec g4 = *reinterpret_cast<const vec*>(&tile[(wave * 8 + r) * TLD + c]);
         const uint32_t off = piece_off(h);
         uvec mn;
         float chk = 0.f;
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
         }
       }
     }
-    *reinterpret_cast<f32x4v*>(&xs[xm * 32 + xk]) = (f32x4v){xv[0], xv[1], xv[2], xv[3]};
+    park_x(xv);
     __syncthreads();
   }
 }
@@ -550,10 +562,13 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[b][c][v] = 0.f;
 
-  struct Chunk { float w[2][4][4]; float a[MB][2][4]; };
-  auto load = [&](Chunk& c, int kc) {            // rows kc .. kc+15: sub-chunk u, MFMA j, lane half lh -> row kc + 8u + 4lh + j
+  // a chunk = U sub-chunks of 8 rows; two chunks in registers (one being multiplied, one in flight).  With 64 batch rows
+  // the accumulators take 128 registers: chunks of 8 rows then keep the kernel out of scratch
+  constexpr int U = MB == 1 ? 2 : 1, ROWS = 8 * U;
+  struct Chunk { float w[U][4][4]; float a[MB][U][4]; };
+  auto load = [&](Chunk& c, int kc) {            // rows kc .. kc+ROWS-1: sub-chunk u, MFMA j, lane half lh -> row kc + 8u + 4lh + j
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // 16 bytes at dword alignment; where a lane's four columns run past N they are the next row's first (or
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
   };
   auto compute = [&](const Chunk& c) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -582,15 +597,16 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
   if (k0 < k1) {
     Chunk ca, cb;
     load(ca, k0);
-    for (int kc = k0; kc < k1; kc += 32) {
-      load(cb, kc + 16);
+    for (int kc = k0; kc < k1; kc += 2 * ROWS) {
+      load(cb, kc + ROWS);
       compute(ca);
-      load(ca, kc + 32);
+      load(ca, kc + 2 * ROWS);
       compute(cb);
     }
   }
 
   // the four waves' tiles -> LDS -> rows (one 32-row block of the batch at a time)
+#pragma unroll
   for (int b = 0; b < MB; ++b) {
     if (b) __syncthreads();
     float* mine = red + wave * (32 * 132);
@@ -695,18 +711,22 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
   static const int cw = getenv("A3D_DW_CW") ? atoi(getenv("A3D_DW_CW")) : 0;      // tuning aid
   const uintptr_t slots = reinterpret_cast<uintptr_t>(m_w) | reinterpret_cast<uintptr_t>(dz);
   const dim3 rows_grid((n + 511) / 512, (k + 31) / 32);
-  // stream form: two blocks per CU, each walking down its share of the row groups
-  static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
-  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * (int)rows_grid.x + 511) / 512);
-  const dim3 stream_grid(rows_grid.x, ((k + 31) / 32 + gpb - 1) / gpb);
+  // stream form: two blocks per CU, each walking down its share of the row groups; 512 columns per block for batches of
+  // at most 32 rows, 256 for up to 64
   static const bool no_stream = getenv("A3D_NO_DENSE_STREAM") && atoi(getenv("A3D_NO_DENSE_STREAM"));   // tuning aid
-  const bool stream_ok = m <= 32 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream;
-  if (cw != 4 && cw != 2 && stream_ok && n % 4 == 0 && (slots & 15) == 0)
-    hipLaunchKernelGGL(dense_dw_adam_stream_kernel<4>, stream_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz,
-                       var_w, m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb);
-  else if (cw != 4 && cw != 2 && stream_ok && n % 2 == 0 && (slots & 7) == 0)
-    hipLaunchKernelGGL(dense_dw_adam_stream_kernel<2>, stream_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz,
-                       var_w, m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb);
+  static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
+  const int bcols = m <= 32 ? 512 : 256, colblocks = (n + bcols - 1) / bcols;
+  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + 511) / 512);
+  const dim3 stream_grid(colblocks, ((k + 31) / 32 + gpb - 1) / gpb);
+  const bool stream_ok = m <= 64 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream && cw != 4 && cw != 2;
+  const hipStream_t hst = static_cast<hipStream_t>(stream);
+#define A3D_DW_STREAM(CWV, MBV)                                                                                          \
+  hipLaunchKernelGGL((dense_dw_adam_stream_kernel<CWV, MBV>), stream_grid, dim3(256), 0, hst, x, dz, var_w, m_w, v_w, var_b, \
+                     m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb)
+  if (stream_ok && m <= 32 && n % 4 == 0 && (slots & 15) == 0) A3D_DW_STREAM(4, 1);
+  else if (stream_ok && m <= 32 && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 1);
+  else if (stream_ok && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 2);
+#undef A3D_DW_STREAM
   else if (cw != 4 && cw != 2 && n % 4 == 0 && (slots & 15) == 0)
     hipLaunchKernelGGL(dense_dw_adam_rows_kernel<4>, rows_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz, var_w,
                        m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale);

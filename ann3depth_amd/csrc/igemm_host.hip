@@ -663,7 +663,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     ws_used = run_filter_bytes(d, rf);
     float* wp = static_cast<float*>(ws);
     clear_stale_error();
-    const int np = d->storage ? d->k : (d->k + 3) / 4 * 4;       // (the bf16 paths keep the filter's own row length)
+    const int np = (d->storage & A3D_STORE_W_BF16) ? d->k : (d->k + 3) / 4 * 4;
     hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
                        rf.rlp, d->k, np);
     rc = check_launch("pad_filter");

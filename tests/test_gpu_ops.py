@@ -309,7 +309,7 @@ def test_adam_frozen_path_poison_semantics(ops):
 
 # the last two are large enough for the streaming kernel to walk several row groups per block (16- and 8-byte rows)
 @pytest.mark.parametrize('m,k,n', [(32, 384, 520), (5, 130, 4070), (64, 512, 256), (1, 512, 257), (32, 4488, 1540),
-                                   (17, 4488, 1538)])
+                                   (17, 4488, 1538), (64, 4488, 1030), (47, 1028, 772)])
 def test_dense_bwd_filter_adam_fused_equals_two_passes(ops, m, k, n):
     """a3d_dense_bwd_filter_adam_tf1 (gradient never written) against a3d_dense_bwd_filter + a3d_adam_apply_tf1 and the
     oracle's ApplyAdam, over two steps, with non-finite gradients in both the kernel and the bias: m, v and var must agree
