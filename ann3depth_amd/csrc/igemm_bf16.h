@@ -188,41 +188,180 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   const int a_cq = tid % ATile::CPR;
   const int b_cq = tid % BTile::CPR;
 
-  if (MODE == MODE_BWD_F) {
+  // ===== staging, as in igemm_body (igemm.h): whatever does not change from k-tile to k-tile is computed once per lane,
+  // the filter tap is decoded with scalar instructions when it is wave-uniform, and every global access is a raw buffer
+  // load whose out-of-range offset reads as zero — no predicated branches, no zero-line selects.  A bf16 tensor is seen
+  // through its float view (pA / pB: half the channels), so the same code serves fp32 and bf16 operands.
+  constexpr int A_CPR = ATile::CPR, A_RPP = ATile::RPP, A_NL = ATile::NL;
+  constexpr int SGN = TRANSPOSED ? -1 : 1;
+  const int a_r0 = tid / A_CPR;
+  const int pW = p.W, pldA = pA.ld;
+  const float* Abase = p.A;
+  const unsigned long long a_total = A16 ? p.a_elems / 2 : p.a_elems;      // extent of A in view floats
+  const unsigned long long b_total = B16 ? p.b_elems / 2 : p.b_elems;
+  auto image_of = [&](int pixel) -> uint32_t {
+    const int px = pixel < p.npix ? pixel : p.npix - 1;
+    return fdiv((uint32_t)px, p.div_phw);
+  };
+  auto row_entry = [&](int pixel, uint32_t nf) -> int4 {      // {byte offset from image nf, y0, x0, valid}
+    int4 e = make_pix<TRANSPOSED>(p, pixel);
+    e.x = ((e.x - (int)(nf * (uint32_t)p.pHW)) + e.y * pW + e.z) * pldA * 4;
+    return e;
+  };
+  int a_rowoff[A_NL], a_y0[A_NL], a_x0[A_NL];
+  int a_dy = 0, a_dx = 0, a_coloff = 0;
+  bool a_cvalid = true;
+  const float* a_base = Abase;
+  unsigned long long a_bytes = 0;
+  if constexpr (MODE == MODE_BWD_F) {
     if (tid < 2 * Cfg::PIX) {
-      int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
-      pixtab[which * Cfg::PIX + e] = make_pix<false>(p, (kt_begin + which) * BK + e);
+      const int which = tid / Cfg::PIX, e = tid % Cfg::PIX;
+      const int pix0 = (kt_begin + which) * BK;
+      pixtab[which * Cfg::PIX + e] = row_entry(pix0 + e, image_of(pix0));
     }
+    const ColDec d = decode_col(pA, (A16 ? m0 / 2 : m0) + a_cq * 4);
+    a_dy = d.r; a_dx = d.s;
+    a_coloff = ((d.r * pW + d.s) * pldA + d.c) * 4;
+    a_cvalid = d.valid;
   } else {
-    if (tid < Cfg::PIX) pixtab[tid] = make_pix<TRANSPOSED>(p, m0 + tid);
+    const uint32_t nf = image_of(m0);
+    if (tid < Cfg::PIX) pixtab[tid] = row_entry(m0 + tid, nf);
+    const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pldA;
+    a_base = Abase + boff;
+    a_bytes = (a_total - boff) * 4ull;
   }
   __syncthreads();
-
-  ColDec cdec;
-  if (MODE == MODE_BWD_F) cdec = decode_col(pA, (A16 ? m0 / 2 : m0) + a_cq * 4);
+  if constexpr (MODE != MODE_BWD_F) {
+#pragma unroll
+    for (int j = 0; j < A_NL; ++j) {
+      const int4 pt = pixtab[a_r0 + j * A_RPP];
+      a_rowoff[j] = pt.x + (p.uni ? a_cq * 16 : 0);
+      a_y0[j] = pt.w ? pt.y : -(1 << 30);
+      a_x0[j] = pt.z;
+    }
+  }
+  struct TapPos { uint32_t rs, chunk; };
+  auto tap_of = [&](int kt) -> TapPos {
+    const uint32_t c1 = fdiv((uint32_t)kt, p.div_taps), r1 = (uint32_t)kt - c1 * (uint32_t)p.ntaps;
+    const uint32_t r2 = fdiv((uint32_t)kt, p.div_cpt), c2 = (uint32_t)kt - r2 * (uint32_t)p.cpt;
+    TapPos t;
+    t.rs = p.kperm ? r1 : r2;
+    t.chunk = p.kperm ? c1 : c2;
+    return t;
+  };
   // a bf16 B tile is read in 16-byte chunks up to its row stride: pad columns (fine/first's 64th channel) are zeros
   const int ldb_v = B16 ? p.ldb / 2 : p.ldb, n0_v = B16 ? n0 / 2 : n0, nn_v = B16 ? p.ldb / 2 : p.N;
+  constexpr int B_CPR = BTile::CPR;
+  uint32_t b_voff[BTile::NL];
+  if constexpr (MODE == MODE_BWD_D) {
+    const int r0 = tid / B_CPR;
+#pragma unroll
+    for (int j = 0; j < BTile::NL; ++j) {
+      const int row = r0 + j * BTile::RPP;
+      const bool ok = (!BTile::PARTIAL || r0 < Cfg::B_ROWS) && n0 + row < p.N;
+      b_voff[j] = ok ? (uint32_t)((row * pB.Cg + b_cq * 4) * 4) : kOOB;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < BTile::NL; ++j) {
+      const int idx = tid + j * NT;
+      const int r = idx / B_CPR, cq = idx % B_CPR;
+      const bool ok = (BTile::TOTAL % NT == 0 || idx < BTile::TOTAL) && n0_v + cq * 4 < nn_v;
+      b_voff[j] = ok ? (uint32_t)((r * ldb_v + cq * 4) * 4) : kOOB;
+    }
+  }
 
-  auto load_tiles = [&](int kt, int pbuf) {
+  // loads of k-tile kt into ra / rb (slot: row-table buffer of that tile, BWD_F); live = false: a tile that does not exist
+  auto stage = [&](auto uni_c, int kt, int slot, bool live) {
+    constexpr bool UNI = decltype(uni_c)::value;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    // ---------- A ----------
     if constexpr (MODE == MODE_BWD_F) {
-      ATile::load(ra, pA, pixtab + pbuf * Cfg::PIX, cdec, tid);
-      BTile::load(rb, p.B, ldb_v, kt * BK, n0_v, p.K, nn_v, tid);
-      if (do_bias) {
+      const int pix0 = kt * BK;
+      const uint32_t nf = image_of(pix0);
+      const unsigned long long boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pldA;
+      rsA = make_rsrc(Abase + boff, live ? (a_total - boff) * 4ull : 0ull);
+      const int4* ptab = pixtab + slot * Cfg::PIX;
 #pragma unroll
-        for (int j = 0; j < BTile::NL; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (B16) { bsum[2 * e] += bf16_lo(rb[j][e]); bsum[2 * e + 1] += bf16_hi(rb[j][e]); }
-            else bsum[e] += rb[j][e];
-          }
+      for (int j = 0; j < A_NL; ++j) {
+        const int4 pt = ptab[a_r0 + j * A_RPP];
+        const int y = pt.y + a_dy, x = pt.z + a_dx;
+        const bool ok = a_cvalid & (pt.w != 0) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        load_vec_buf<4>(rsA, ok ? (uint32_t)(pt.x + a_coloff) : kOOB, ra[j]);
       }
     } else {
-      ColDec cd = decode_col(pA, kt * AKS + a_cq * 4);
-      ATile::load(ra, pA, pixtab, cd, tid);
-      if constexpr (MODE == MODE_FWD)
-        BTile::load(rb, p.B, ldb_v, kt * BK, n0_v, p.K, nn_v, tid);
-      else
-        BTile::load(rb, pB, n0, kt * BKS + b_cq * 4, tid);
+      int dy, dx, coloff;
+      bool cv = true;
+      if constexpr (UNI) {
+        const TapPos t = tap_of(kt);
+        const uint32_t r = fdiv(t.rs, p.div_s), sx = t.rs - r * p.div_s.d;
+        dy = SGN * (int)r; dx = SGN * (int)sx;
+        coloff = ((dy * pW + dx) * pldA + (int)t.chunk * AKS) * 4;
+      } else {
+        const ColDec d = decode_col(pA, kt * AKS + a_cq * 4);
+        dy = SGN * d.r; dx = SGN * d.s;
+        coloff = ((dy * pW + dx) * pldA + d.c) * 4;
+        cv = d.valid;
+      }
+      rsA = make_rsrc(a_base, live ? a_bytes : 0ull);
+#pragma unroll
+      for (int j = 0; j < A_NL; ++j) {
+        const int y = a_y0[j] + dy, x = a_x0[j] + dx;
+        const bool ok = cv & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        load_vec_buf<4>(rsA, ok ? (uint32_t)(a_rowoff[j] + coloff) : kOOB, ra[j]);
+      }
+    }
+    // ---------- B ----------
+    if constexpr (MODE == MODE_BWD_D) {
+      // filter W[rs][cin][cout] read as rows = cin, columns = k = (rs, cout), in view floats
+      if constexpr (UNI) {
+        const TapPos t = tap_of(kt);
+        const uint32_t rp = fdiv(t.rs, p.div_s), sp = t.rs - rp * p.div_s.d;
+        const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
+        const unsigned long long boff = (unsigned long long)rs * (unsigned long long)(p.Cn * pB.Cg) +
+                                        (unsigned long long)n0 * pB.Cg + t.chunk * BKS;
+        rsB = make_rsrc(p.B + boff, live ? (b_total - boff) * 4ull : 0ull);
+#pragma unroll
+        for (int j = 0; j < BTile::NL; ++j) load_vec_buf<4>(rsB, b_voff[j], rb[j]);
+      } else {
+        const int kcol = kt * BKS + b_cq * 4;
+        const bool kvalid = kcol < pB.K;
+        const uint32_t k = kvalid ? (uint32_t)kcol : 0u;
+        const uint32_t rs0 = fdiv(k, pB.div_c);
+        const int ko = (int)(k - rs0 * pB.div_c.d);
+        const uint32_t rp = fdiv(rs0, p.div_s), sp = rs0 - rp * p.div_s.d;
+        const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
+        const uint32_t base = (rs * (uint32_t)(p.Cn * pB.Cg) + (uint32_t)n0 * (uint32_t)pB.Cg + (uint32_t)ko) * 4u;
+        rsB = make_rsrc(p.B, live ? b_total * 4ull : 0ull);
+#pragma unroll
+        for (int j = 0; j < BTile::NL; ++j)
+          load_vec_buf<4>(rsB, (kvalid && b_voff[j] != kOOB) ? base + (b_voff[j] - (uint32_t)(b_cq * 16)) : kOOB, rb[j]);
+      }
+    } else {
+      // plain [K][ldb] tile at rows row0.., columns n0..: the descriptor is re-based and ends with row K-1
+      int row0 = kt * BK;
+      if constexpr (MODE == MODE_FWD && UNI) {
+        const TapPos t = tap_of(kt);
+        row0 = (int)(t.rs * (uint32_t)p.Cg + t.chunk * BK);
+      }
+      const int rows = p.K - row0;
+      const long long rec = ((long long)(rows > 0 ? rows : 0) * ldb_v - n0_v) * 4ll;
+      rsB = make_rsrc(p.B + ((unsigned long long)row0 * (unsigned long long)ldb_v + (unsigned long long)n0_v),
+                      (unsigned long long)((live && rec > 0) ? rec : 0ll));
+#pragma unroll
+      for (int j = 0; j < BTile::NL; ++j) load_vec_buf<4>(rsB, b_voff[j], rb[j]);
+    }
+  };
+  // BiasAddGrad (BWD_F): summed from the staged dz registers when they are parked in LDS (their data has arrived then)
+  auto add_bias = [&]() {
+    if (MODE == MODE_BWD_F && do_bias) {
+#pragma unroll
+      for (int j = 0; j < BTile::NL; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (B16) { bsum[2 * e] += bf16_lo(rb[j][e]); bsum[2 * e + 1] += bf16_hi(rb[j][e]); }
+          else bsum[e] += rb[j][e];
+        }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -232,8 +371,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     else store_bf16<BTile, X3, B_PLAIN>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
   };
 
+  auto k_loop = [&](auto uni_c) {
   if (nkt > 0) {
-    load_tiles(kt_begin, 0);
+    stage(uni_c, kt_begin, 0, true);
+    add_bias();
     store_tiles(0);
   }
   __syncthreads();
@@ -242,9 +383,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   for (int it = 0; it < nkt; ++it) {
     const int kt = kt_begin + it;
     const bool more = it + 1 < nkt;
-    if (more) load_tiles(kt + 1, (it + 1) & 1);
+    stage(uni_c, kt + 1, (it + 1) & 1, more);        // a tile that does not exist: descriptors of 0 records
+    __builtin_amdgcn_sched_barrier(0);
     if (MODE == MODE_BWD_F) {
-      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = make_pix<false>(p, (kt + 2) * BK + tid);
+      if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = row_entry((kt + 2) * BK + tid, image_of((kt + 2) * BK));
     }
     const __bf16* ah = A_hi(cur);
     const __bf16* al = A_lo(cur);
@@ -272,7 +414,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
           if (X3) b_lo[b] = frag_tr(bl, Cfg::B_LD, bcol0, 16 * s, lane);
         }
       }
-      if (s == BK / 16 - 1 && more) store_tiles(cur ^ 1);
+      if (s == BK / 16 - 1 && more) {
+        add_bias();
+        store_tiles(cur ^ 1);
+      }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         if (X3) {
@@ -284,6 +429,13 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     }
     __syncthreads();
     cur ^= 1;
+  }
+  };
+  if constexpr (MODE == MODE_BWD_F) {
+    k_loop(std::false_type{});
+  } else {
+    if (p.uni) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
   }
 
   // ---- epilogue (as igemm_kernel) ----

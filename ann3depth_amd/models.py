@@ -190,7 +190,7 @@ class MSDNReplica:
         # activations
         self.x = buf(B, NET_H, NET_W, 3)
         self.t = buf(B, OUT_H, OUT_W, 1)
-        self.c0 = buf(B, 55, 74, 96) if not self.bf16s else None; self.p0 = abuf(B, 27, 37, 96)
+        self.c0 = abuf(B, 55, 74, 96); self.p0 = abuf(B, 27, 37, 96)
         self.c1 = abuf(B, 27, 37, 256); self.p1 = abuf(B, 13, 18, 256)
         self.c2 = abuf(B, 13, 18, 384); self.c3 = abuf(B, 13, 18, 384); self.c4 = abuf(B, 6, 8, 256)
         self.drop = buf(B, 4096)
@@ -210,7 +210,7 @@ class MSDNReplica:
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
         self.dc4 = abuf(B, 6, 8, 256); self.dc3 = abuf(B, 13, 18, 384); self.dc2 = abuf(B, 13, 18, 384)
         self.dp1 = abuf(B, 13, 18, 256); self.dc1 = abuf(B, 27, 37, 256)
-        self.dp0 = abuf(B, 27, 37, 96); self.dc0 = buf(B, 55, 74, 96)
+        self.dp0 = abuf(B, 27, 37, 96); self.dc0 = abuf(B, 55, 74, 96)
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = buf(B, OUT_H, OUT_W, 64)
         self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
         if self.bf16s:
@@ -236,10 +236,16 @@ class MSDNReplica:
             X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
             for n in ('coarse/conv/conv2d_1', 'coarse/conv/conv2d_2', 'coarse/conv/conv2d_3', 'coarse/conv/conv2d_4'):
                 self.store[n] = {'fwd': X | W | Y, 'bwd_d': X | W | Y, 'bwd_f': X | Y}
-            # the two 3-channel layers (15 % of the FLOPs) take the fp32 image and keep fp32 arithmetic: conv + ReLU + max
-            # pool in one kernel, of which only the pooled map (bf16) and an argmax byte per window reach HBM — c0 / f1,
-            # the largest activations of the model, are never written; their gradient comes back fp32
-            for n in ('coarse/conv/conv2d_0', 'fine/first/conv2d'):
+            # conv2d_0 takes the fp32 image through the bf16 kernel (window runs of 36 floats, 16-byte loads) and writes c0
+            # as bf16; its filter stays fp32 (padded per call).  At B = 64: forward 93 us + pool against 204 us for the fp32
+            # conv + pool fusion, bwd-filter 108 us against 221 us.
+            n = 'coarse/conv/conv2d_0'
+            self.store[n] = {'fwd': Y, 'bwd_d': 0, 'bwd_f': Y}
+            # fine/first keeps fp32 arithmetic (its window runs start 24 bytes apart: 8-byte loads only, which the bf16
+            # kernel does not take): conv + ReLU + max pool in one kernel, of which only the pooled map (bf16) and an argmax
+            # byte per window reach HBM — f1, the largest activation of the model, is never written; its gradient comes
+            # back fp32
+            for n in ('fine/first/conv2d',):
                 self.d[n] = ops.with_storage(self.d[n], 0)
                 self.d[n].precision = ops.PREC['fp32']
                 self.store[n] = {'fwd': Y, 'bwd_d': 0, 'bwd_f': 0}
@@ -441,7 +447,7 @@ class MSDNReplica:
         src = {'c0': (self.c0, self.p0, self.a0, 1), 'c1': (self.c1, self.p1, self.a1, 1),
                'f1': (self.f1, self.cat, self.af1, 2)}[which]
         full, pooled, arg, phase = src
-        if self.pooled_fwd != phase and not (self.bf16s and which in ('c0', 'f1')):
+        if self.pooled_fwd != phase and not (self.bf16s and which == 'f1'):
             return full
         if full is None:          # 'bf16s': the tensor does not exist at all
             full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'f1': (110, 148, 63)}[which], device=self.device)
@@ -477,7 +483,8 @@ class MSDNReplica:
             self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0 if train else None)
             self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1 if train else None)
         elif self.bf16s:
-            self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0)
+            self._conv('coarse/conv/conv2d_0', self.x, self.c0)
+            self._pool(self.c0, self.p0)
             self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
             self._pool(self.c1, self.p1)
         else:
@@ -576,7 +583,7 @@ class MSDNReplica:
         n = 'coarse/conv/conv2d_1'
         self._bwd_filter(n, self.p0, self.dc1)
         self._bwd_data(n, self.dc1, self.dp0)
-        if self.pooled_fwd == 1 or self.bf16s:
+        if self.pooled_fwd == 1:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:
             self._pool_bwd(self.c0, self.dp0, self.dc0)

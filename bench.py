@@ -167,12 +167,12 @@ def hbm_bytes_bf16_storage(B):
         # forward activations, written once and read once by the next layer (bf16): p0, c1, p1, c2, c3, c4, cat; f2 fp32
         + 2 * (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
                + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4)
-        + px(27, 37, 96, 1)                                        # argmax bytes of conv2d_0's pool (a0), written
+        + 2 * px(55, 74, 96, b2)                                   # c0 (bf16): written by conv2d_0, read by its pool
         # backward of coarse/*: each stored activation read again (bwd-filter A operand / ReLU mask), each activation
         # gradient written once and read by bwd-filter and bwd-data of the layer below (2 reads)
         + (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
         + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
-        + px(27, 37, 96, 1) + 2 * px(55, 74, 96, f4)               # a0 read; dc0 (fp32) written + read
+        + px(55, 74, 96, b2) + 2 * px(55, 74, 96, b2)              # c0 read by the pool gradient; dc0 (bf16) written + read
         + 6 * 4096 * f4 + 6 * 4070 * f4                            # dense side tensors (drop, coarse, dz0, dz1, ...)
     )
     conv_w = 34944 + 614656 + 885120 + 1327488 + 884992            # coarse/conv parameters
