@@ -169,6 +169,9 @@ struct IgemmParams {
   int a16, b16, c16;
   FastDiv div_c_half;
   FastDiv div_cpt, div_taps;
+  // the same tap decode for k-tiles of 64 (the bf16 kernel): uniform when Cg % 64 == 0
+  int uni64, kperm64, cpt64;
+  FastDiv div_cpt64;
   // stream-K (p.streamk): the (tile, k-tile) iterations, tile-major, are dealt to the blocks in equal contiguous shares
   // (no tile quantisation: 177 tiles x 4 splits = 708 blocks on 512 slots was a 1.4-round launch).  A block that owns a
   // whole tile writes it with the fused epilogue; shares that end inside a tile leave their accumulators, in register

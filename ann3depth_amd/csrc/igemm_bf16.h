@@ -22,7 +22,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, int BM, int BN, bool X3>
 struct Bf16Cfg {
-  static constexpr int BK = 32;
+  // k-tile: 64 for the plain bf16 kernel (half as many barriers and LDS round trips per MAC as 32; 78 KB of LDS, two
+  // blocks per CU), 32 for the two-plane x3 variant (its planes would not fit otherwise)
+  static constexpr int BK = X3 ? 32 : 64;
   static constexpr int NWAVES = 8, NT = 512, WAVES_M = 4, WAVES_N = 2;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int TM = WM / 32, TN = WN / 32;
@@ -194,6 +196,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   // through its float view (pA / pB: half the channels), so the same code serves fp32 and bf16 operands.
   constexpr int A_CPR = ATile::CPR, A_RPP = ATile::RPP, A_NL = ATile::NL;
   constexpr int SGN = TRANSPOSED ? -1 : 1;
+  // wave-uniform filter tap of a k-tile: the host's decode parameters for this kernel's k-tile length
+  const bool t_uni = BK == 64 ? p.uni64 != 0 : p.uni != 0, t_kperm = BK == 64 ? p.kperm64 != 0 : p.kperm != 0;
+  const int t_cpt = BK == 64 ? p.cpt64 : p.cpt;
+  const FastDiv t_div_cpt = BK == 64 ? p.div_cpt64 : p.div_cpt;
   const int a_r0 = tid / A_CPR;
   const int pW = p.W, pldA = pA.ld;
   const float* Abase = p.A;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
 #pragma unroll
     for (int j = 0; j < A_NL; ++j) {
       const int4 pt = pixtab[a_r0 + j * A_RPP];
-      a_rowoff[j] = pt.x + (p.uni ? a_cq * 16 : 0);
+      a_rowoff[j] = pt.x + (t_uni ? a_cq * 16 : 0);
       a_y0[j] = pt.w ? pt.y : -(1 << 30);
       a_x0[j] = pt.z;
     }
@@ -243,10 +249,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   struct TapPos { uint32_t rs, chunk; };
   auto tap_of = [&](int kt) -> TapPos {
     const uint32_t c1 = fdiv((uint32_t)kt, p.div_taps), r1 = (uint32_t)kt - c1 * (uint32_t)p.ntaps;
-    const uint32_t r2 = fdiv((uint32_t)kt, p.div_cpt), c2 = (uint32_t)kt - r2 * (uint32_t)p.cpt;
+    const uint32_t r2 = fdiv((uint32_t)kt, t_div_cpt), c2 = (uint32_t)kt - r2 * (uint32_t)t_cpt;
     TapPos t;
-    t.rs = p.kperm ? r1 : r2;
-    t.chunk = p.kperm ? c1 : c2;
+    t.rs = t_kperm ? r1 : r2;
+    t.chunk = t_kperm ? c1 : c2;
     return t;
   };
   // a bf16 B tile is read in 16-byte chunks up to its row stride: pad columns (fine/first's 64th channel) are zeros
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   if constexpr (MODE == MODE_BWD_F) {
     k_loop(std::false_type{});
   } else {
-    if (p.uni) k_loop(std::true_type{});
+    if (t_uni) k_loop(std::true_type{});
     else k_loop(std::false_type{});
   }
 

@@ -85,9 +85,10 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   if (tune_int("A3D_BF16_BN", 0) == 64 || tune_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = tune_int("A3D_BF16_BN", 0);
   pl.tiles_m = (g.M + 127) / 128;
   pl.tiles_n = (g.N + pl.bf16_bn - 1) / pl.bf16_bn;
-  const int nk = std::max(1, (g.K + 31) / 32);
+  const int bk = precision == A3D_PREC_BF16X3 ? 32 : 64;        // Bf16Cfg::BK: the plain bf16 kernel takes k-tiles of 64
+  const int nk = std::max(1, (g.K + bk - 1) / bk);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
-  int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk / 12));
+  int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk * (bk / 32) / 12));
   if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
@@ -387,7 +388,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     a3d_timing_record& r = slot.rec;
     r.mode = mode; r.prec = plan.prec;
     if (plan.prec != A3D_PREC_F32) {
-      r.bm = 128; r.bn = plan.bf16_bn; r.waves_m = 4; r.nwaves = 8; r.bk = 32;
+      r.bm = 128; r.bn = plan.bf16_bn; r.waves_m = 4; r.nwaves = 8; r.bk = plan.prec == A3D_PREC_BF16X3 ? 32 : 64;
     } else {
       r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
       r.nwaves = kCfgNWaves[plan.cfg]; r.bk = kCfgs[plan.cfg].bk;
@@ -571,6 +572,10 @@ static void fill_staging(IgemmParams& p, int mode, unsigned long long a_elems, u
   p.kperm = p.uni && p.ntaps > 1 && p.cpt > 1 && !env_flag_no_kperm();
   p.div_cpt = make_fastdiv(p.cpt);
   p.div_taps = make_fastdiv(p.ntaps);
+  p.cpt64 = std::max(1, p.Cg / 64);
+  p.uni64 = p.uni && p.Cg % 64 == 0;
+  p.kperm64 = p.uni64 && p.ntaps > 1 && p.cpt64 > 1 && !env_flag_no_kperm();
+  p.div_cpt64 = make_fastdiv(p.cpt64);
   // forward-style gathers (FWD, BWD_F) of an unpadded conv whose last window ends inside the image never go out of range
   p.nocheck = mode != MODE_BWD_D && p.pad_t == 0 && p.pad_l == 0 && filt_r > 0 && filt_s > 0;
 }
