@@ -620,6 +620,8 @@ int a3d_timing_collect(a3d_timing_record* out, int cap) {
   return n;
 }
 
+static size_t bf16_image_filter_bytes(const a3d_conv_desc* d);
+
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
@@ -630,7 +632,67 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
     g.K = rf.kp; g.avec = rf.vec;
     need = std::max(need, run_filter_bytes(d, rf) + plan_gemm(g, d->precision).ws_bytes);
   }
+  if (d->storage & A3D_STORE_X_BF16 && d->c == 4 && d->ldx == 4) {      // bf16 image form (same test minus the pointer)
+    GemmProblem g = fwd_problem(d);
+    g.K = d->r * ((d->s * 2 + 3) / 4 * 4 * 2); g.avec = 4; g.bvec = 4; g.no_glds = 1;
+    need = std::max(need, bf16_image_filter_bytes(d) + plan_gemm(g, d->precision).ws_bytes);
+  }
   return need;
+}
+
+// ---- window-run form over a bf16 image of 8-byte pixels (4 channels; a3d_pad_channels_bf16) ----
+// Seen through its float view a pixel is 2 floats, so at an even stride the runs of a filter row start 16 bytes apart and
+// the bf16 kernel gathers them with its 16-byte loads: K = (r, run of s*4 bf16 padded to a multiple of 8), the filter
+// [r][s][4][k] float32 is repacked per call as bf16 [r][run][k padded to 8] (pad rows / columns zero).
+static bool bf16_image_form_ok(const a3d_conv_desc* d, const void* x) {
+  if (!(d->storage & A3D_STORE_X_BF16) || (d->storage & A3D_STORE_W_BF16) || d->precision != A3D_PREC_BF16) return false;
+  if (d->c != 4 || d->ldx != 4 || d->pad_t || d->pad_l || d->stride % 2 || (d->w * 2) % 4 || !aligned16(x)) return false;
+  const int rlv = (d->s * 2 + 3) / 4 * 4;                       // padded run in view floats
+  return (d->wo - 1) * d->stride * 2 + rlv <= d->w * 2;        // the last column's padded run stays inside its row
+}
+static size_t bf16_image_filter_bytes(const a3d_conv_desc* d) {
+  const int rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
+  return ((size_t)d->r * rlp * np * 2 + 255) / 256 * 256;
+}
+// filter [r][rl][n] float32 -> bf16 [r][rlp][np], pad rows / columns zero
+__global__ __launch_bounds__(256) void pad_filter_bf16_kernel(const float* w, __bf16* wp, int r, int rl, int rlp, int n, int np) {
+  const int total = r * rlp * np;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int col = i % np, row = i / np;
+    const int q = row % rlp, rr = row / rlp;
+    wp[i] = (__bf16)((q < rl && col < n) ? w[(size_t)(rr * rl + q) * n + col] : 0.f);
+  }
+}
+static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                               void* ws, size_t ws_bytes, hipStream_t st) {
+  const int rl = d->s * 4, rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
+  GemmProblem g = fwd_problem(d);
+  g.K = d->r * rlp; g.avec = 4; g.bvec = 4; g.no_glds = 1;
+  const size_t ws_used = bf16_image_filter_bytes(d);
+  GemmPlan plan = plan_gemm(g, d->precision);
+  if (!ws || ws_used + plan.ws_bytes > ws_bytes)
+    return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
+  A3D_CHECK_ARG(plan.prec == A3D_PREC_BF16 && aligned16(y), "conv2d_fwd: bf16 image form needs the bf16 kernel");
+  __bf16* wp = static_cast<__bf16*>(ws);
+  clear_stale_error();
+  hipLaunchKernelGGL(pad_filter_bf16_kernel, dim3((d->r * rlp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rl, rlp,
+                     d->k, np);
+  int rc = check_launch("pad_filter_bf16");
+  if (rc != A3D_OK) return rc;
+  IgemmParams p;
+  fill_common(p, g);
+  p.a16 = 1; p.b16 = 1; p.c16 = (d->storage & A3D_STORE_Y_BF16) ? 1 : 0;
+  p.A = x; p.B = reinterpret_cast<const float*>(wp); p.C = y; p.bias = bias; p.act = act;
+  p.npix = g.M; p.nrsc = g.K;
+  p.H = d->h; p.W = d->w; p.ld = 4; p.pHW = d->h * d->w;
+  p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = 0; p.pad_l = 0;
+  p.S = 1; p.Cg = rlp;
+  p.div_phw = make_fastdiv(d->ho * d->wo); p.div_pw = make_fastdiv(d->wo);
+  p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(1);
+  p.div_c_half = make_fastdiv(p.Cg / 2);
+  p.ldb = np; p.ldc = d->ldy;
+  fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * 4, (unsigned long long)g.K * np, d->r, 1, d->r, 1);
+  return launch_igemm(MODE_FWD, plan, 4, 4, p, static_cast<char*>(ws) + ws_used, st);
 }
 
 // conv2d forward; pool != 0: y is the 2x2 / stride-2 max pool of the activated conv output, [n, ho/2, wo/2, k] with
@@ -650,6 +712,8 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!pool && bf16_image_form_ok(d, x))
+    return conv_fwd_bf16_image(d, x, w, bias, y, act, ws, ws_bytes, st);
   GemmProblem g = fwd_problem(d);
   const int ph = d->ho / 2, pw = d->wo / 2;
   if (pool) {

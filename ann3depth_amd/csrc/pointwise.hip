@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_vec4_kernel(const uint8_t
 }
 
 // ------------------------------------------------------------------ bf16 storage (BASELINE config 5)
+// float32 [pixels][c_src] -> bf16 [pixels][4], missing channels zero: an 8-byte pixel, so that the window runs of a
+// few-channel conv start 16 bytes apart at even strides and the bf16 kernel can gather them (igemm_host.hip)
+__global__ __launch_bounds__(256) void pad_channels_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                size_t pixels, int c_src) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (size_t)gridDim.x * 256) {
+    bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    for (int c = 0; c < c_src; ++c) o[c] = (__bf16)src[i * c_src + c];
+    reinterpret_cast<bf16x4*>(dst)[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__ src, void* __restrict__ dst, size_t count,
                                                         int to_bf16) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -572,6 +584,15 @@ int a3d_stream_create(int level, void** stream) {
 int a3d_stream_destroy(void* stream) {
   A3D_CHECK_ARG(stream != nullptr, "stream_destroy: null stream");
   return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? A3D_OK : set_error(A3D_ELAUNCH, "stream_destroy failed");
+}
+
+int a3d_pad_channels_bf16(size_t pixels, int c_src, const float* src, int c_dst, void* dst, void* stream) {
+  A3D_CHECK_ARG(pixels > 0 && src && dst && c_src >= 1 && c_dst == 4 && c_src <= 4, "pad_channels_bf16: 1..4 channels to 4");
+  A3D_CHECK_ARG((reinterpret_cast<uintptr_t>(dst) & 7) == 0, "pad_channels_bf16: 8-byte aligned destination");
+  clear_stale_error();
+  hipLaunchKernelGGL(pad_channels_bf16_kernel, dim3(grid_for(pixels, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, static_cast<__bf16*>(dst), pixels, c_src);
+  return check_launch("pad_channels_bf16");
 }
 
 int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream) {

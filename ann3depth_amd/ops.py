@@ -265,6 +265,14 @@ def dense_bwd_data_ex(dz, w, dx, mask=None, mask_act='relu', scale=1.0, precisio
     return dx
 
 
+def pad_channels_bf16(src, dst):
+    """float32 [..., c] -> bfloat16 [..., 4], missing channels zero."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and dst.shape[-1] == 4 and src.shape[:-1] == dst.shape[:-1]
+    check(_lib.load().a3d_pad_channels_bf16(src.numel() // src.shape[-1], src.shape[-1], _ptr(src), 4, _ptr(dst), _stream()),
+          'a3d_pad_channels_bf16')
+    return dst
+
+
 def cast_bf16(src, dst):
     """float32 -> bfloat16 or back, by dst's dtype (round to nearest even)."""
     assert src.numel() == dst.numel() and {src.dtype, dst.dtype} == {torch.float32, torch.bfloat16}

@@ -173,6 +173,12 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
  * that cross between the bf16 conv stack and the float32 dense layers (to_bf16 != 0: src float32 -> dst bf16). */
 int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream);
 
+/* float32 [pixels][c_src] -> bf16 [pixels][4] with the missing channels zero (c_src <= 4): the network image as 8-byte
+ * pixels.  a3d_conv2d_fwd with A3D_STORE_X_BF16, c = ldx = 4, no padding, an even stride and precision A3D_PREC_BF16
+ * gathers such an image in whole window runs through the bf16 kernel (fine/first, src/models.py:241, whose float32
+ * window runs start 24 bytes apart and cannot); its filter is the float32 [r][s][4][k] one (channel 3: anything). */
+int a3d_pad_channels_bf16(size_t pixels, int c_src, const float* src, int c_dst, void* dst, void* stream);
+
 /* a3d_maxpool2x2_fwd / a3d_maxpool2x2_bwd on bf16 tensors (x, y, dy, dx bf16, pixel strides ldx / ldy / lddy >= c; `extra`, the concatenated channel, stays
  * float32: it is the coarse network's output).  Same semantics, first maximum in scan order. */
 int a3d_maxpool2x2_fwd_bf16(int n, int h, int w, int c, const void* x, int ldx, void* y, int ldy, const float* extra,

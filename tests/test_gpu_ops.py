@@ -140,6 +140,34 @@ def test_conv2d_strided_pixels(ops):
     assert (got[..., k:] == 7.0).all()
 
 
+@pytest.mark.parametrize('n,h,w,k,ks,st,y16', [(2, 23, 32, 63, 9, 2, True), (3, 17, 20, 16, 5, 2, False), (1, 40, 36, 8, 11, 4, True)])
+def test_conv_fwd_bf16_image_form(ops, n, h, w, k, ks, st, y16):
+    """A 3-channel image stored as bf16 pixels of 4 channels (a3d_pad_channels_bf16) through the bf16 kernel's window-run
+    form, against the fp32 kernel on the fp32 image: the arithmetic of BASELINE config 5 (bf16 operands, fp32 accumulate),
+    so 2e-2; the 4th channel of image and filter never contributes."""
+    rng = np.random.default_rng(n * 100 + k)
+    x = rng.random((n, h, w, 3)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, 3, k)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32) * 0.1
+    d32 = ops.conv_desc(n, h, w, 3, k, ks, ks, st, 'VALID')
+    y32 = torch.empty((n, d32.ho, d32.wo, k), device='cuda')
+    ops.conv2d_fwd(d32, dev(x), dev(wt), dev(bias), y32, 'relu')
+    x4 = torch.empty((n, h, w, 4), device='cuda', dtype=torch.bfloat16)
+    ops.pad_channels_bf16(dev(x), x4)
+    np.testing.assert_array_equal(x4[..., 3].float().cpu().numpy(), 0)
+    np.testing.assert_array_equal(x4[..., :3].float().cpu().numpy(), dev(x).to(torch.bfloat16).float().cpu().numpy())
+    w4 = np.concatenate([wt, np.full((ks, ks, 1, k), 7.0, np.float32)], axis=2)         # channel 3 of the filter: anything
+    ldy = (k + 7) // 8 * 8
+    d = ops.with_storage(ops.conv_desc(n, h, w, 4, k, ks, ks, st, 'VALID', ldy=ldy, precision='bf16'),
+                         ops.STORE_X | (ops.STORE_Y if y16 else 0))
+    y = torch.full((n, d.ho, d.wo, ldy), -3.0, device='cuda', dtype=torch.bfloat16 if y16 else torch.float32)
+    ops.conv2d_fwd(d, x4, dev(w4), dev(bias), y, 'relu')
+    torch.cuda.synchronize()
+    got = y[..., :k].float().cpu().numpy()
+    assert rel_l2(got, y32.cpu().numpy()) < 2e-2
+    assert (y[..., k:].float().cpu().numpy() == -3.0).all()                              # pad channels are not written
+
+
 DENSE_CASES = [(32, 12288, 4096), (4, 512, 4070), (32, 4096, 4070), (7, 130, 66), (48, 12544, 128), (48, 128, 16),
                (48, 16, 1), (9, 1024, 1031)]
 
