@@ -53,6 +53,7 @@ SIGNATURES = {
     'a3d_maxpool2x2_fwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P]),
     'a3d_maxpool2x2_bwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
     'a3d_resize_bilinear_tf1': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
+    'a3d_resize_bilinear_tf1_pair': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P]),
     'a3d_extract_patches': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     'a3d_silog_loss_fwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),
     'a3d_silog_loss_bwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),

@@ -254,26 +254,34 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const __bf16* __r
 }
 
 // ------------------------------------------------------------------ ResizeBilinear (legacy, align_corners=False)
-__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int h,
-                                                     int w, int c, int oh, int ow, float sy, float sx) {
-  const size_t total = (size_t)n * oh * ow * c;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ch = (int)(i % c);
-    size_t t = i / c;
-    const int ox = (int)(t % ow);
-    t /= ow;
-    const int oy = (int)(t % oh);
-    const int b = (int)(t / oh);
-    const float fy = __fmul_rn((float)oy, sy), fx = __fmul_rn((float)ox, sx);
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
-    const float* img = x + (size_t)b * h * w * c + ch;
-    const float tl = img[((size_t)y0 * w + x0) * c], tr = img[((size_t)y0 * w + x1) * c];
-    const float bl = img[((size_t)y1 * w + x0) * c], br = img[((size_t)y1 * w + x1) * c];
-    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), lx));
-    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), lx));
-    y[i] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ly));
+// One block per output row of one tensor (blockIdx.y selects the tensor of a pair: the step resizes the image and its
+// depth map, src/models.py:282-283, in ONE launch): the row's source lines and vertical weight are scalars, a thread walks
+// the row's (pixel, channel) elements with 32-bit arithmetic.  Same separate fp32 operations as before: bit-exact.
+struct ResizeOne { const float* x; float* y; int h, w, c, oh, ow; float sy, sx; };
+struct ResizePair { ResizeOne t[2]; int n; };
+__global__ __launch_bounds__(256) void resize_kernel(const ResizePair p) {
+  const ResizeOne& r = p.t[blockIdx.y];
+  const int rows = p.n * r.oh;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = row / r.oh, oy = row - b * r.oh;
+    const float fy = __fmul_rn((float)oy, r.sy);
+    const int y0 = (int)fy, y1 = min(y0 + 1, r.h - 1);
+    const float ly = __fsub_rn(fy, (float)y0);
+    const float* l0 = r.x + ((size_t)b * r.h + y0) * r.w * r.c;
+    const float* l1 = r.x + ((size_t)b * r.h + y1) * r.w * r.c;
+    float* out = r.y + (size_t)row * r.ow * r.c;
+    const int ne = r.ow * r.c;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+      const int ox = e / r.c, ch = e - ox * r.c;
+      const float fx = __fmul_rn((float)ox, r.sx);
+      const int x0 = (int)fx, x1 = min(x0 + 1, r.w - 1);
+      const float lx = __fsub_rn(fx, (float)x0);
+      const float tl = l0[x0 * r.c + ch], tr = l0[x1 * r.c + ch];
+      const float bl = l1[x0 * r.c + ch], br = l1[x1 * r.c + ch];
+      const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), lx));
+      const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), lx));
+      out[e] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ly));
+    }
   }
 }
 
@@ -626,14 +634,35 @@ int a3d_maxpool2x2_bwd_bf16(int n, int h, int w, int c, const void* x, int ldx, 
   return check_launch("maxpool_bwd_bf16");
 }
 
+static ResizeOne resize_one(int h, int w, int c, const float* x, int oh, int ow, float* y) {
+  ResizeOne r;
+  r.x = x; r.y = y; r.h = h; r.w = w; r.c = c; r.oh = oh; r.ow = ow;
+  r.sy = (float)h / (float)oh; r.sx = (float)w / (float)ow;
+  return r;
+}
+
 int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, int ow, float* y, void* stream) {
   A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0 && x && y, "resize: bad arguments");
-  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
-  const size_t total = (size_t)n * oh * ow * c;
+  ResizePair p;
+  p.n = n;
+  p.t[0] = p.t[1] = resize_one(h, w, c, x, oh, ow, y);
   clear_stale_error();
-  hipLaunchKernelGGL(resize_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, h,
-                     w, c, oh, ow, sy, sx);
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min(n * oh, 16384), 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("resize");
+}
+
+int a3d_resize_bilinear_tf1_pair(int n, int h, int w, int c0, const float* x0, int oh0, int ow0, float* y0, int c1,
+                                 const float* x1, int oh1, int ow1, float* y1, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c0 > 0 && c1 > 0 && oh0 > 0 && ow0 > 0 && oh1 > 0 && ow1 > 0 && x0 && y0 && x1 && y1,
+                "resize_pair: bad arguments");
+  ResizePair p;
+  p.n = n;
+  p.t[0] = resize_one(h, w, c0, x0, oh0, ow0, y0);
+  p.t[1] = resize_one(h, w, c1, x1, oh1, ow1, y1);
+  clear_stale_error();
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min(n * std::max(oh0, oh1), 16384), 2), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch("resize_pair");
 }
 
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream) {

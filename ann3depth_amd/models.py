@@ -481,8 +481,11 @@ class MSDNReplica:
         activations c0, c1, f1 are then NOT written.  The network being trained also records the position of each
         maximum (a0, a1 / af1): MaxPoolGrad routes dy to that position and the fused ReluGrad only asks whether the
         maximum is positive, so the backward needs nothing else of c0 / c1 / f1.  phase None keeps every activation."""
-        ops.resize_bilinear_tf1(images, self.x)
-        ops.resize_bilinear_tf1(depths, self.t)
+        if images.shape[:3] == depths.shape[:3]:
+            ops.resize_bilinear_tf1_pair(images, self.x, depths, self.t)
+        else:
+            ops.resize_bilinear_tf1(images, self.x)
+            ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
         self.dropout_on = keep_mask is not None            # None: the plugin was called with train=False
         fused = self.fuse_pool and phase in (1, 2, 3)

@@ -193,6 +193,15 @@ def resize_bilinear_tf1(x, y):
     return y
 
 
+def resize_bilinear_tf1_pair(x0, y0, x1, y1):
+    """Both resizes of a step in one launch: x0 -> y0 and x1 -> y1, stored tensors of the same batch and size."""
+    n, h, w, c0 = x0.shape
+    assert x1.shape[:3] == (n, h, w)
+    check(_lib.load().a3d_resize_bilinear_tf1_pair(n, h, w, c0, _ptr(x0), y0.shape[1], y0.shape[2], _ptr(y0), x1.shape[3],
+                                                   _ptr(x1), y1.shape[1], y1.shape[2], _ptr(y1), _stream()),
+          'a3d_resize_bilinear_tf1_pair')
+
+
 def extract_patches(x, k, stride, y):
     n, h, w, c = x.shape
     check(_lib.load().a3d_extract_patches(n, h, w, c, _ptr(x), k, stride, _ptr(y), _stream()), 'a3d_extract_patches')

@@ -145,6 +145,9 @@ int a3d_maxpool2x2_bwd(int n, int h, int w, int c, const float* x, const float* 
 /* tf.image.resize_images = ResizeBilinear(align_corners=False), legacy src = dst*in/out mapping
  * (src/models.py:180-181,282-283). */
 int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, int ow, float* y, void* stream);
+/* The two resizes of a training step (image and depth map of the same stored size, src/models.py:282-283) in one launch. */
+int a3d_resize_bilinear_tf1_pair(int n, int h, int w, int c0, const float* x0, int oh0, int ow0, float* y0, int c1,
+                                 const float* x1, int oh1, int ow1, float* y1, void* stream);
 
 /* tf.extract_image_patches(k x k, stride, SAME) + reshape (src/models.py:53-59): y [n*ph*pw, k, k, c]. */
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream);

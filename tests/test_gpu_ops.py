@@ -247,6 +247,17 @@ def test_resize_bitexact(ops, n, h, w, c, oh, ow):
     np.testing.assert_array_equal(y.cpu().numpy(), T.resize_bilinear_tf1(x, oh, ow))
 
 
+def test_resize_pair_is_the_two_resizes_in_one_launch(ops):
+    """Image and depth map of a step (src/models.py:282-283) in one launch, different output sizes and channel counts."""
+    rng = np.random.default_rng(3)
+    img = (rng.integers(0, 256, (3, 48, 64, 3)) / 255).astype(np.float32)
+    dep = (rng.integers(0, 256, (3, 48, 64, 1)) / 255).astype(np.float32)
+    y0, y1 = torch.empty((3, 23, 31, 3), device='cuda'), torch.empty((3, 55, 74, 1), device='cuda')
+    ops.resize_bilinear_tf1_pair(dev(img), y0, dev(dep), y1)
+    np.testing.assert_array_equal(y0.cpu().numpy(), T.resize_bilinear_tf1(img, 23, 31))
+    np.testing.assert_array_equal(y1.cpu().numpy(), T.resize_bilinear_tf1(dep, 55, 74))
+
+
 def test_extract_patches_bitexact(ops):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((2, 240, 320, 3)).astype(np.float32)
