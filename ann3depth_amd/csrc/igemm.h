@@ -162,9 +162,9 @@ struct IgemmParams {
   // and the fast column decode of layers whose gathered channel count is a multiple of BK: a K-tile then lies inside ONE
   // filter tap, so (r, s, first channel) are wave-uniform.  kperm walks the taps of a channel chunk before moving to the
   // next chunk (the 25 taps of a 5x5 layer re-read the same few KB of each pixel row: L1/L2-resident) instead of all
-  // channels of a tap first.  nocheck: unpadded forward / bwd-filter gathers never leave the image.
+  // channels of a tap first.
   unsigned long long a_elems, b_elems;
-  int uni, kperm, cpt, ntaps, nocheck;
+  int uni, kperm, cpt, ntaps;
   // bf16 storage (igemm_bf16_kernel<.., A16, B16, C16>): which operands are bf16 in HBM, and div_c for the float view
   int a16, b16, c16;
   FastDiv div_c_half;
