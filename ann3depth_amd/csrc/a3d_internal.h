@@ -34,6 +34,7 @@ struct GemmPlan {
   int ktiles_per_split;
   int tiles_m, tiles_n;
   int streamk;       // > 0: stream-K launch of this many blocks (splitk == 1)
+  int sk_sliced;     // stream-K shares cut per XCD from eighths of the K axis (bwd-filter; SkSpace in igemm.h)
   size_t ws_bytes;   // split-K / stream-K slabs (0 if neither)
 };
 

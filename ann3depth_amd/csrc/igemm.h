@@ -389,6 +389,27 @@ struct FilterTTile {
 __device__ __forceinline__ uint32_t sk_first(uint32_t b, uint32_t nblk, uint32_t total) {
   return (uint32_t)(((unsigned long long)b * total) / nblk);
 }
+// Iteration space a block's share is cut from.  streamk 1: all `tiles` x `nk` iterations, dealt to all blocks.
+// streamk 2 (bwd-filter, grid a multiple of 8): the K axis — the pixels — is cut into eight slices, one per XCD (the
+// remapped ids [x q, (x+1) q) are the blocks of XCD x), and the blocks of an XCD share tiles x (their slice): an XCD then
+// streams only its eighth of x and dz through its L2 instead of all of both (tile-major shares: 601 MB of fabric reads
+// per conv2d_1..3 bwd-filter launch against 47 MB algorithmic).  Every tile then has contributors on all eight XCDs;
+// ascending block id is still ascending k.  The host makes sure a share is no longer than a slice (per <= nk / 8), so a
+// block still ends up with at most two partial tiles = its two slab slots.
+struct SkSpace { uint32_t blocks, j, k0, nk, total; };
+__device__ __forceinline__ SkSpace sk_space(int streamk, uint32_t b, uint32_t nblk, uint32_t tiles, uint32_t nk_total) {
+  SkSpace s;
+  if (streamk == 2) {
+    const uint32_t q = nblk / 8, x = b / q;
+    s.blocks = q; s.j = b - x * q;
+    s.k0 = x * nk_total / 8;
+    s.nk = (x + 1) * nk_total / 8 - s.k0;
+  } else {
+    s.blocks = nblk; s.j = b; s.k0 = 0; s.nk = nk_total;
+  }
+  s.total = tiles * s.nk;
+  return s;
+}
 
 // accumulators of one wave <-> slab, register order: 16 bytes per lane, 1 KiB per wave-instruction
 template <int TM, int TN>
@@ -497,18 +518,20 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   }
   const int tiles_mn = p.tiles_m * p.tiles_n;
   const int nk_total = (p.K + BK - 1) / BK;      // p.ktiles_per_split is in units of this kernel's BK
-  // stream-K share of this block (iterations of the tile-major (tile, k-tile) order)
-  const uint32_t sk_total = (uint32_t)tiles_mn * (uint32_t)nk_total;
-  uint32_t sk_cur = p.streamk ? sk_first(bid, nwg, sk_total) : 0u;
-  const uint32_t sk_end = p.streamk ? sk_first(bid + 1, nwg, sk_total) : 1u;
+  // stream-K share of this block: a contiguous range of the tile-major (tile, k-tile) iterations of its iteration space —
+  // the whole problem (streamk 1), or (streamk 2, bwd-filter) the K slice of the block's XCD: see SkSpace
+  const SkSpace sp = sk_space(p.streamk, bid, nwg, (uint32_t)tiles_mn, (uint32_t)nk_total);
+  uint32_t sk_cur = p.streamk ? sk_first(sp.j, sp.blocks, sp.total) : 0u;
+  const uint32_t sk_end = p.streamk ? sk_first(sp.j + 1, sp.blocks, sp.total) : 1u;
   for (int seg = 0; sk_cur < sk_end; ++seg) {      // classic launches: exactly one pass
   int split = 0, tmn, kt_begin, kt_end;
   if (p.streamk) {
-    tmn = (int)fdiv(sk_cur, p.div_nk);
-    kt_begin = (int)(sk_cur - (uint32_t)tmn * (uint32_t)nk_total);
-    kt_end = kt_begin + (int)(sk_end - sk_cur);
-    if (kt_end > nk_total) kt_end = nk_total;
-    sk_cur += (uint32_t)(kt_end - kt_begin);
+    tmn = p.streamk == 1 ? (int)fdiv(sk_cur, p.div_nk) : (int)(sk_cur / sp.nk);
+    const uint32_t kl = sk_cur - (uint32_t)tmn * sp.nk;
+    const uint32_t n = min(sk_end - sk_cur, sp.nk - kl);
+    kt_begin = (int)(sp.k0 + kl);
+    kt_end = kt_begin + (int)n;
+    sk_cur += n;
   } else {
     split = bid / tiles_mn;
     tmn = bid - split * tiles_mn;
@@ -974,43 +997,61 @@ template <int MODE, int BM, int BN, int WAVES_M, int NWAVES>
 __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, const uint32_t nblk) {
   constexpr int WAVES_N = NWAVES / WAVES_M, WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
   constexpr int UNITS = NWAVES * TM * TN * 4;
+  constexpr int MAXC = 1024;                                // contributors of one tile: at most one per block (host: grid <= 1024)
+  __shared__ uint32_t slots[MAXC];
+  __shared__ uint32_t nslots;
   const int lane = threadIdx.x & 63;
   const int unit = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
   const uint32_t tile = blockIdx.x;
-  const uint32_t nk = p.div_nk.d, total = (uint32_t)(p.tiles_m * p.tiles_n) * nk;
-  const uint32_t t0 = tile * nk, t1 = t0 + nk - 1;        // first and last iteration of the tile
-  uint32_t bf = (uint32_t)(((unsigned long long)t0 * nblk) / total), bl = (uint32_t)(((unsigned long long)t1 * nblk) / total);
-  while (bf + 1 < nblk && sk_first(bf + 1, nblk, total) <= t0) ++bf;
-  while (bl + 1 < nblk && sk_first(bl + 1, nblk, total) <= t1) ++bl;
-  if (bf == bl) return;                                    // one owner: written by the GEMM kernel itself
+  const uint32_t nk = p.div_nk.d, tiles = (uint32_t)(p.tiles_m * p.tiles_n);
+  // the tile's contributors in block order (= ascending k), as slab slots: first share of the block if that share starts
+  // in this tile, else its last share.  One thread lists them; a launch with more blocks than iterations has blocks
+  // without work in between.
+  if (threadIdx.x == 0) {
+    uint32_t n = 0;
+    const uint32_t nx = p.streamk == 2 ? 8u : 1u;
+    for (uint32_t x = 0; x < nx; ++x) {
+      const SkSpace sp = sk_space(p.streamk, x * (nblk / nx), nblk, tiles, nk);
+      if (sp.nk == 0) continue;
+      const uint32_t t0 = tile * sp.nk, t1 = t0 + sp.nk - 1;
+      uint32_t jf = (uint32_t)(((unsigned long long)t0 * sp.blocks) / sp.total), jl = (uint32_t)(((unsigned long long)t1 * sp.blocks) / sp.total);
+      while (jf + 1 < sp.blocks && sk_first(jf + 1, sp.blocks, sp.total) <= t0) ++jf;
+      while (jl + 1 < sp.blocks && sk_first(jl + 1, sp.blocks, sp.total) <= t1) ++jl;
+      for (uint32_t j = jf; j <= jl; ++j) {
+        const uint32_t f = sk_first(j, sp.blocks, sp.total);
+        if (f == sk_first(j + 1, sp.blocks, sp.total)) continue;                      // idle block
+        const uint32_t b = x * (nblk / nx) + j;
+        if (n < MAXC) slots[n] = 2 * b + (f / sp.nk == tile ? 0u : 1u);
+        ++n;
+      }
+    }
+    nslots = n < MAXC ? n : MAXC;
+  }
+  __syncthreads();
+  const uint32_t n = nslots;
+  // one contributor that covered the whole K range wrote the tile itself (tile-major shares only)
+  if (n <= 1 && p.streamk == 1) return;
   const int tile_m = (int)tile / p.tiles_n, tile_n = (int)tile - tile_m * p.tiles_n;
-  // slab of contributor b (first share of the block if that share starts in this tile, else its last share)
-  auto slot_of = [&](uint32_t b) -> size_t {
-    return (size_t)2 * b + (fdiv(sk_first(b, nblk, total), p.div_nk) == tile ? 0 : 1);
-  };
   if (unit < UNITS) {
     const size_t uoff = ((size_t)unit * 64 + lane) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    // contributors in block order; a launch with more blocks than iterations has blocks without work in between
-    auto skip_idle = [&](uint32_t b) -> uint32_t {
-      while (b <= bl && sk_first(b, nblk, total) == sk_first(b + 1, nblk, total)) ++b;
-      return b;
+    auto slab_of = [&](uint32_t i) -> f32x4 {
+      return *reinterpret_cast<const f32x4*>(p.sk_ws + (size_t)slots[i] * (size_t)(BM * BN) + uoff);
     };
-    auto slab_of = [&](uint32_t b) -> f32x4 {
-      return *reinterpret_cast<const f32x4*>(p.sk_ws + slot_of(b) * (size_t)(BM * BN) + uoff);
-    };
-    uint32_t b0 = skip_idle(bf);
-    while (b0 <= bl) {
-      const uint32_t b1 = skip_idle(b0 + 1), b2 = b1 <= bl ? skip_idle(b1 + 1) : b1, b3 = b2 <= bl ? skip_idle(b2 + 1) : b2;
-      if (b3 <= bl) {                   // four slabs in flight
-        const f32x4 v0 = slab_of(b0), v1 = slab_of(b1), v2 = slab_of(b2), v3 = slab_of(b3);
-        s += v0; s += v1; s += v2; s += v3;
-        b0 = skip_idle(b3 + 1);
-      } else {
-        s += slab_of(b0);
-        b0 = b1;
-      }
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {          // eight slabs in flight, added in contributor order
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab_of(i + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    if (i + 4 <= n) {
+      const f32x4 v0 = slab_of(i), v1 = slab_of(i + 1), v2 = slab_of(i + 2), v3 = slab_of(i + 3);
+      s += v0; s += v1; s += v2; s += v3;
+      i += 4;
+    }
+    for (; i < n; ++i) s += slab_of(i);
     // unit -> (wave, a, b, q) -> rows / column, as slab_store laid them out
     const int q = unit & 3, ab = unit >> 2, bb = ab % TN, a = (ab / TN) % TM, wave = ab / (TN * TM);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
@@ -1020,8 +1061,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, c
   if (MODE == MODE_BWD_F && p.dbias != nullptr && tile_m == 0 && blockIdx.y == 0 && (int)threadIdx.x < BN) {
     static_assert(BN <= 256, "bias sums by the first 256 threads");
     float bsum = 0.f;
-    for (uint32_t b = bf; b <= bl; ++b)
-      if (sk_first(b, nblk, total) != sk_first(b + 1, nblk, total)) bsum += p.sk_bias[slot_of(b) * BN + threadIdx.x];
+    for (uint32_t i = 0; i < n; ++i) bsum += p.sk_bias[(size_t)slots[i] * BN + threadIdx.x];
     if (tile_n * BN + (int)threadIdx.x < p.N) p.dbias[tile_n * BN + threadIdx.x] = bsum;
   }
 }

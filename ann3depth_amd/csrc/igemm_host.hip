@@ -60,6 +60,21 @@ static int env_int(const char* name, int dflt) {
 static bool tuning() { static const bool v = env_int("A3D_TUNING", 0) != 0; return v; }
 static int tune_int(const char* name, int dflt) { return tuning() ? env_int(name, dflt) : dflt; }
 static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
+// K-sliced stream-K is built and fuzzed but OFF by default: it removes the bwd-filter launches' fabric over-fetch and
+// costs 0.7 % of the step; A3D_SK_SLICED=1 turns it on
+static bool env_flag_no_sliced() { static const bool v = env_int("A3D_SK_SLICED", 0) == 0; return v; }
+// K-sliced stream-K (SkSpace): a block's share must fit inside one slice of one tile's K range (at most two partial
+// tiles per block = its two slab slots) and a tile may not have more contributors than the fixup lists (96).
+static bool sk_sliced_ok(int mode, long tiles, int nk, int grid, long* meet_out) {
+  if (mode != MODE_BWD_F || grid % 8 != 0 || nk < 64) return false;
+  const long q = grid / 8, nk_lo = nk / 8, nk_hi = (nk + 7) / 8;
+  const long per = (tiles * nk_hi + q - 1) / q;                 // longest share of any XCD
+  if (per > nk_lo || per < 1) return false;
+  const long meet = 8 * ((nk_hi + per - 1) / per + 1);
+  if (meet > 256) return false;
+  if (meet_out) *meet_out = meet;
+  return true;
+}
 static bool env_flag_no_streamk() { static const bool v = env_int("A3D_NO_STREAMK", 0) != 0; return v; }
 static bool env_flag_no_kperm() { static const bool v = env_int("A3D_NO_KPERM", 0) != 0; return v; }
 
@@ -121,7 +136,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
   double best_t = 1e300;
   const int nk = std::max(1, (g.K + 31) / 32);
   const int force_cfg = tune_int("A3D_FORCE_CFG", -1), force_split = tune_int("A3D_FORCE_SPLITK", -1);
-  const int force_streamk = tune_int("A3D_FORCE_STREAMK", 0);      // tuning aid: stream-K with this many blocks
+  const int force_streamk = std::min(tune_int("A3D_FORCE_STREAMK", 0), 1024);      // tuning aid: stream-K with this many blocks (the fixup lists at most 1024 contributors per tile)
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
@@ -135,6 +150,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     if (force_streamk > 0 && force_cfg < kFirstGldsCfg && !g.plain) {
       best.splitk = 1; best.ktiles_per_split = nk; best.streamk = force_streamk;
       best.ws_bytes = (size_t)2 * force_streamk * ((size_t)bm * bn + bn) * 4;
+      best.sk_sliced = tune_int("A3D_FORCE_SK_SLICED", 0) &&
+                       sk_sliced_ok(g.mode, (long)best.tiles_m * best.tiles_n, nk, force_streamk, nullptr);
     }
     return best;
   }
@@ -180,6 +197,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
         best.tiles_n = tn;
         best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
         best.streamk = 0;
+        best.sk_sliced = 0;
       }
     }
     // stream-K: equal shares of the (tile, k-tile) iterations for one or two blocks per CU — no tile quantisation, and
@@ -193,8 +211,12 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
         const long per = (iters + grid - 1) / grid;
         // blocks meeting in one tile: their slabs are added one after the other by the fixup, so few tiles with very
         // long K (bwd-filter of the 3-channel layers, dense layers) stay with classic split-K and its flat reduction
-        const long meet = (nk + per - 1) / per + 1;
-        if (force_streamk <= 0 && (meet > 16 || tiles < 24)) continue;
+        long meet = (nk + per - 1) / per + 1;
+        // bwd-filter: K (the pixel axis) in eight slices, one per XCD — each XCD streams its own eighth of x and dz
+        long meet_sliced = 0;
+        const bool sliced = !env_flag_no_sliced() && sk_sliced_ok(g.mode, tiles, nk, grid, &meet_sliced);
+        if (force_streamk <= 0 && ((sliced ? meet_sliced > 48 : meet > 16) || tiles < 24)) continue;
+        if (sliced) meet = meet_sliced / 4;
         double t = (double)bm * bn * per * 32.0 / (96.5e3 * kCfgs[c].eff) * (grid <= 256 ? 0.62 : 1.0);
         // ~1.5 slabs per block are written and read back, then the split tiles are written once more
         const double slabs = std::min<double>(1.5 * grid, 2.0 * tiles) * bm * bn * 4.0;
@@ -208,6 +230,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
           best.tiles_m = tm;
           best.tiles_n = tn;
           best.streamk = grid;
+          best.sk_sliced = sliced ? 1 : 0;
           best.ws_bytes = (size_t)2 * grid * ((size_t)bm * bn + bn) * 4;
         }
       }
@@ -350,7 +373,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   if (plan.streamk > 0) {
     if (!ws) return set_error(A3D_EWORKSPACE, "igemm: stream-K needs a workspace");
     const size_t tile_elems = (size_t)kCfgs[plan.cfg].bm * kCfgs[plan.cfg].bn;
-    p.streamk = 1;
+    p.streamk = plan.sk_sliced ? 2 : 1;
     p.sk_ws = static_cast<float*>(ws);
     p.sk_bias = p.sk_ws + (size_t)2 * plan.streamk * tile_elems;
     p.div_nk = make_fastdiv((uint32_t)std::max(1, (p.K + 31) / 32));
@@ -366,8 +389,8 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   p.dbg = tune_int("A3D_DBG", 0);
   static const bool plan_log = env_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
   if (plan_log)
-    fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d grid %u\n", mode, p.M, p.N, p.K,
-            plan.cfg, kCfgs[plan.cfg].bm, kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, grid);
+    fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d%s grid %u\n", mode, p.M, p.N, p.K,
+            plan.cfg, kCfgs[plan.cfg].bm, kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, plan.sk_sliced ? " (K-sliced)" : "", grid);
   TimingSlot slot{};
   bool timed = false;
   {

@@ -591,3 +591,18 @@ def test_maxpool_bwd_from_recorded_argmax(ops, n, h, w, c, k, ks, st, pad, ld):
     assert rel_l2(dx.cpu().numpy(), want) < 1e-5
     ops.maxpool2x2_bwd_idx(arg, pooled, dyd, dx, relu_mask=False)
     assert rel_l2(dx.cpu().numpy(), T.maxpool2x2_bwd(y64, dy[..., :k].astype(np.float64))) < 1e-5
+
+
+def test_fuzz_of_forced_plans_in_a_tuning_process():
+    """tools/fuzz_ops.py for a few seconds in its own process (A3D_TUNING=1: the A3D_FORCE_* switches are read per launch):
+    random conv / dense problems with pinned tile configurations, split-K factors and stream-K grids — tile-major and
+    K-sliced shares, more blocks than iterations, up to 700 contributors per tile — against torch float64.  The planner's
+    own picks cover only a few of the combinations the kernels support."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '12', '77'], capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode == 0 and 'FAIL' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(r.stdout.strip().splitlines()[-1].split()[0]) > 200

@@ -104,7 +104,7 @@ def run_dense():
 def force_plan():
     """Half of the cases pin a tile config and either a split-K factor or a stream-K grid (the planner's own picks cover
     only a few of the combinations the kernels support)."""
-    for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK'):
+    for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK', 'A3D_FORCE_SK_SLICED'):
         os.environ.pop(v, None)
     u = rng.random()
     if u < 0.5:
@@ -113,8 +113,11 @@ def force_plan():
     if u < 0.75:
         os.environ['A3D_FORCE_SPLITK'] = str(int(rng.choice([1, 2, 3, 5, 8, 13])))
         return 'cfg%s sk%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_SPLITK'])
-    os.environ['A3D_FORCE_STREAMK'] = str(int(rng.choice([1, 2, 3, 7, 32, 100, 256, 512, 700])))
-    return 'cfg%s streamk%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_STREAMK'])
+    os.environ['A3D_FORCE_STREAMK'] = str(int(rng.choice([1, 2, 3, 7, 8, 32, 64, 100, 256, 512, 700])))
+    if rng.random() < 0.5:        # bwd-filter shares cut from per-XCD K slices (where the shape allows it)
+        os.environ['A3D_FORCE_SK_SLICED'] = '1'
+    return 'cfg%s streamk%s%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_STREAMK'],
+                                  ' sliced' if 'A3D_FORCE_SK_SLICED' in os.environ else '')
 
 
 t_end = time.time() + budget
@@ -135,3 +138,4 @@ while time.time() < t_end:
     if err > worst[0]:
         worst = (err, case)
 print(f'{count} cases, worst rel-L2 {worst[0]:.2e} at {worst[1]}')
+sys.exit(0 if worst[0] <= TOL else 1)
