@@ -159,6 +159,7 @@ class MSDNReplica:
                 ops.check(_lib.load().a3d_stream_create(int(os.environ.get('A3D_SIDE_PRIORITY', '1')), ctypes.byref(handle)),
                           'a3d_stream_create')
             self.side = torch.cuda.ExternalStream(handle.value, device=dev)
+            self._side_handle = handle.value       # ExternalStream does not own it: returned in __del__
         shapes = collections.OrderedDict()
         for c in MSDN_CONVS:
             shapes[c.name + '/kernel'] = (c.k, c.k, c.cin, c.cout)
@@ -262,6 +263,15 @@ class MSDNReplica:
                 if n == 'coarse/dense/dense_0' or self.store[n]['fwd'] & W:
                     self.wcopy[n] = torch.empty(self.shapes[n + '/kernel'], device=dev, dtype=torch.bfloat16)
             self.refresh_weight_copies()
+
+    def __del__(self):
+        handle, self._side_handle = getattr(self, '_side_handle', None), None
+        if handle:
+            try:
+                torch.cuda.synchronize(self.device)
+                _lib.load().a3d_stream_destroy(handle)
+            except Exception:          # noqa: BLE001 - interpreter shutdown: the driver reclaims the stream
+                pass
 
     def _desc(self, name, which):
         """The layer's conv descriptor for 'fwd' | 'bwd_d' | 'bwd_f', with that call's storage bits."""
