@@ -50,11 +50,74 @@ uint32_t crc32c_sw(const uint8_t* p, size_t n, uint32_t crc) {
 }
 
 #if defined(__x86_64__)
+// crc32q has a latency of three cycles and a throughput of one: a single chain checks 8 bytes per 3 cycles (~8 GB/s), and
+// a 4.9 MB record costs a reader thread 0.6 ms of CRC alone.  Three independent chains over three consecutive 8 KiB
+// pieces fill the pipeline; the pieces' registers are joined with the "append N zero bytes" operator of the CRC (a GF(2)
+// matrix, applied through four 256-entry tables) — the construction published with zlib's crc32_combine, for the
+// Castagnoli polynomial.
+constexpr size_t kCrcPiece = 8192;          // a power of two (the operator is built by repeated squaring)
+uint32_t g_shift[4][256];                   // register after kCrcPiece zero bytes, per byte of the register
+bool g_shift_ready = false;
+
+uint32_t gf2_times(const uint32_t* mat, uint32_t vec) {
+  uint32_t sum = 0;
+  for (; vec; vec >>= 1, ++mat)
+    if (vec & 1) sum ^= *mat;
+  return sum;
+}
+void gf2_square(uint32_t* square, const uint32_t* mat) {
+  for (int n = 0; n < 32; ++n) square[n] = gf2_times(mat, mat[n]);
+}
+void init_shift() {
+  uint32_t even[32], odd[32];
+  odd[0] = 0x82F63B78u;                     // operator for one zero BIT: the reflected polynomial, then the shifts
+  for (int n = 1; n < 32; ++n) odd[n] = 1u << (n - 1);
+  gf2_square(even, odd);                    // two zero bits
+  gf2_square(odd, even);                    // four
+  size_t len = kCrcPiece;                   // each further squaring doubles: 1 byte, 2 bytes, ...
+  uint32_t* cur = odd;
+  uint32_t* nxt = even;
+  for (;;) {
+    gf2_square(nxt, cur);                   // first pass: one zero byte
+    len >>= 1;
+    uint32_t* t = cur; cur = nxt; nxt = t;
+    if (len == 0) break;
+  }
+  for (uint32_t n = 0; n < 256; ++n)
+    for (int b = 0; b < 4; ++b) g_shift[b][n] = gf2_times(cur, n << (8 * b));
+  g_shift_ready = true;
+}
+struct ShiftInit {
+  ShiftInit() { init_shift(); }
+} g_shift_init;
+inline uint32_t shift_piece(uint32_t c) {
+  return g_shift[0][c & 0xFF] ^ g_shift[1][(c >> 8) & 0xFF] ^ g_shift[2][(c >> 16) & 0xFF] ^ g_shift[3][c >> 24];
+}
+
 __attribute__((target("sse4.2"))) uint32_t crc32c_hw(const uint8_t* p, size_t n, uint32_t crc) {
+  if (!g_shift_ready) init_shift();
   uint64_t c = ~crc;
   while (n && (reinterpret_cast<uintptr_t>(p) & 7)) {
     c = __builtin_ia32_crc32qi((uint32_t)c, *p++);
     --n;
+  }
+  while (n >= 3 * kCrcPiece) {              // three chains, joined: c0 || piece1 || piece2
+    uint64_t c1 = 0, c2 = 0;
+    const uint8_t* end = p + kCrcPiece;
+    do {
+      uint64_t v0, v1, v2;
+      memcpy(&v0, p, 8);
+      memcpy(&v1, p + kCrcPiece, 8);
+      memcpy(&v2, p + 2 * kCrcPiece, 8);
+      c = __builtin_ia32_crc32di(c, v0);
+      c1 = __builtin_ia32_crc32di(c1, v1);
+      c2 = __builtin_ia32_crc32di(c2, v2);
+      p += 8;
+    } while (p < end);
+    c = shift_piece((uint32_t)c) ^ c1;
+    c = shift_piece((uint32_t)c) ^ c2;
+    p += 2 * kCrcPiece;
+    n -= 3 * kCrcPiece;
   }
   while (n >= 8) {
     uint64_t v;
@@ -259,9 +322,9 @@ int a3d_record_decode(const uint8_t* frame, size_t len, int verify_crc, float* i
   };
   for (const Seg& s : {first, second}) {
     crc_range(cursor, (size_t)(s.p - cursor));
-    // decode in 64 KB blocks: CRC the block, then convert it while it is in cache
+    // decode in 72 KB blocks (three 3-chain CRC rounds): CRC the block, then convert it while it is in cache
     for (size_t done = 0; done < s.n;) {
-      const size_t blk = std::min<size_t>(s.n - done, 65536);
+      const size_t blk = std::min<size_t>(s.n - done, 73728);
       crc_range(s.p + done, blk);
       const size_t nf = blk / 4;
       float* d = s.dst + done / 4;
