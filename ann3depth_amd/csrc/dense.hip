@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
 }
 
 static int pick_span(int extent, int groups, int quantum) {
-  const int want = std::max(1, 512 / std::max(1, groups));
+  static const int target = getenv("A3D_DENSE_BLOCKS") ? atoi(getenv("A3D_DENSE_BLOCKS")) : 512;      // tuning aid
+  const int want = std::max(1, target / std::max(1, groups));
   int span = (extent + want - 1) / want;
   span = std::max(quantum, (span + quantum - 1) / quantum * quantum);
   return span;
