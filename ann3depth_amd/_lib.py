@@ -60,6 +60,8 @@ SIGNATURES = {
     'a3d_dropout_keep_mask': (c_int, [c_size_t, ctypes.c_uint64, ctypes.c_uint64, c_float, _P, _P]),
     'a3d_adam_apply_tf1': (c_int, [c_size_t, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
                                    c_float, _P]),
+    'a3d_adam_apply_tf1_flag': (c_int, [c_size_t, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_float,
+                                        c_float, _P, _P]),
     'a3d_dense_fwd_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     'a3d_dense_bwd_data_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P]),
     'a3d_cast_bf16': (c_int, [c_size_t, _P, _P, c_int, _P]),

@@ -150,7 +150,35 @@ class Session:
             self.summaries = open(os.path.join(self.dir, 'summaries.jsonl'), 'a')
             self.events = summary.EventFileWriter(self.dir)
         self.step_last_sum = rep.global_step
+        if self.world > 1:
+            # before the first step: a rank whose shard cannot fill even one batch (or whose reader already failed) must
+            # not leave the others waiting in step 1's collectives
+            self._decide(self.op)
         return self
+
+    def _decide(self, train_op, want_save=False):
+        """The replicas decide TOGETHER (dp.GradReducer.agree_all, one host collective): a signal reaches the ranks at
+        different steps, an input shard runs dry on one rank first, the chief's checkpoint timer fires on the chief only —
+        and the next step's collectives (and a sharded optimizer state's gather) need everyone.  Agreed values: the
+        signal number (exit code of every rank, src/ann3depth.py:129) or 1 when a rank's input has no batch left for
+        the next step; whether a rank's reader FAILED (CRC mismatch, malformed record: raised on every rank, never
+        mistaken for a clean end of input); whether the chief wants a checkpoint now."""
+        rep = train_op.replica
+        end = getattr(train_op, 'end', None)
+        due = end is not None and end[0] <= train_op.k
+        dry = due and isinstance(end[1], data.OutOfRangeError)
+        failed = due and not dry
+        stop, err, save = rep.reducer.agree_all([self.sig.signal_received or (1 if dry else 0), int(failed),
+                                                 int(want_save)])
+        if err:
+            if failed:
+                raise end[1]
+            raise RuntimeError('the input pipeline of another replica failed; stopping with it')
+        if stop:
+            self.stop = True
+            if stop > 1 and not self.sig.signal_received:
+                self.sig.signal_received = stop
+        return bool(save)
 
     def should_stop(self):
         return self.stop or self.op.replica.global_step >= self.last_step
@@ -178,16 +206,9 @@ class Session:
         step = rep.global_step
         # tfhelper.TraceHook (src/tfhelper.py:192-249): trace the first step and every `trace_every`-th global step
         self.trace_next = bool(self.trace_every) and (step + 1) % self.trace_every == 0
+        save_due = bool(self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs)
         if self.world > 1:
-            # The replicas decide TOGETHER (dp.GradReducer.agree): a signal reaches the ranks at different steps, and
-            # the next step's all-reduces need everyone.  The agreed value is the signal number (exit code of every
-            # rank, src/ann3depth.py:129), or 1 when a rank's input has no batch left for the next step.
-            dry = getattr(train_op, 'end', None) is not None and train_op.end[0] <= train_op.k
-            agreed = rep.reducer.agree(self.sig.signal_received or (1 if dry else 0))
-            if agreed:
-                self.stop = True
-                if agreed > 1 and not self.sig.signal_received:
-                    self.sig.signal_received = agreed
+            save_due = self._decide(train_op, save_due)
         elif self.sig.signal_received:                                   # StopAtSignalHook.after_run
             self.stop = True
         if self.sum_steps and step % self.sum_steps == 0:
@@ -204,7 +225,7 @@ class Session:
                     self.events.add_images(step, tag, t[:max_outputs].cpu().numpy(), max_outputs)
                 self.events.flush()
             self.t_last_sum, self.step_last_sum = now, step
-        if self.dir and self.ckpt_secs and time.time() - self.t_last_ckpt >= self.ckpt_secs:
+        if save_due:
             self.save()
         return out
 
@@ -223,7 +244,11 @@ class Session:
             json.dump({'global_step': step, 'launches': recs}, f)
 
     def save(self):
+        """Every replica calls this together (a sharded optimizer state is gathered first); the chief writes."""
         rep = self.op.replica
+        rep.gather_state()
+        if not self.dir:
+            return
         torch.cuda.synchronize()
         prefix = f'model.ckpt-{rep.global_step}'
         path = os.path.join(self.dir, prefix + '.pt')
@@ -263,7 +288,7 @@ class Session:
 
     def __exit__(self, exc_type, exc, tb):
         self.op.pipeline.close()
-        if self.dir and exc_type is None:
+        if exc_type is None:
             self.save()                                                  # session close saves a final checkpoint
         if self.summaries:
             self.summaries.close()

@@ -407,9 +407,11 @@ __device__ __forceinline__ void adam_one(float& var, float& m, float& v, float g
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m,
                                                    float* __restrict__ v, const float* __restrict__ g, size_t count,
-                                                   float omb1, float omb2, float alpha, float eps, float gscale) {
+                                                   float omb1, float omb2, float alpha, float eps, float gscale,
+                                                   unsigned int* __restrict__ poisoned) {
   const size_t nvec = count / 4;
   const bool use_scale = gscale != 1.f;
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     f32x4 w4 = reinterpret_cast<f32x4*>(var)[i], m4 = reinterpret_cast<f32x4*>(m)[i];
     f32x4 v4 = reinterpret_cast<f32x4*>(v)[i], g4 = reinterpret_cast<const f32x4*>(g)[i];
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
       float gj = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
       float wj = w4[j], mj = m4[j], vj = v4[j];
       adam_one(wj, mj, vj, gj, omb1, omb2, alpha, eps);
+      bad |= !isfinite(wj);
       w4[j] = wj; m4[j] = mj; v4[j] = vj;
     }
     reinterpret_cast<f32x4*>(var)[i] = w4;
@@ -429,8 +432,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
     if (i < count) {
       float gj = use_scale ? __fmul_rn(g[i], gscale) : g[i];
       adam_one(var[i], m[i], v[i], gj, omb1, omb2, alpha, eps);
+      bad |= !isfinite(var[i]);
     }
   }
+  if (poisoned && bad) atomicOr(poisoned, 1u);
 }
 
 // ApplyAdam specialised for alpha == 0 and 1-beta2 == 0 — what the reference's AdamOptimizer(rate, 0.9, 1) always is
@@ -440,10 +445,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, floa
 // foreign checkpoint; v is only ever written by these two kernels, which never produce one.)
 __global__ __launch_bounds__(256) void adam_frozen_kernel(float* __restrict__ var, float* __restrict__ m,
                                                           float* __restrict__ v, const float* __restrict__ g,
-                                                          size_t count, float omb1, float gscale) {
+                                                          size_t count, float omb1, float gscale,
+                                                          unsigned int* __restrict__ poisoned) {
   const size_t nvec = count / 4;
   const bool use_scale = gscale != 1.f;
   const float qnan = __builtin_nanf("");
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], g4 = reinterpret_cast<const f32x4*>(g)[i];
 #pragma unroll
@@ -451,8 +458,12 @@ __global__ __launch_bounds__(256) void adam_frozen_kernel(float* __restrict__ va
       const float gj = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
       m4[j] = __fadd_rn(m4[j], __fmul_rn(__fsub_rn(gj, m4[j]), omb1));
       const bool g_poison = !isfinite(__fmul_rn(gj, gj));
-      if (g_poison) v[4 * i + j] = qnan;
-      if (g_poison || !isfinite(m4[j])) var[4 * i + j] = qnan;
+      if (g_poison || !isfinite(m4[j])) {             // rare; `bad` only when it changes something (a NaN stays a NaN)
+        const size_t e = 4 * i + j;
+        bad |= !isnan(var[e]) || (g_poison && !isnan(v[e]));
+        if (g_poison) v[e] = qnan;
+        var[e] = qnan;
+      }
     }
     reinterpret_cast<f32x4*>(m)[i] = m4;
   }
@@ -463,10 +474,14 @@ __global__ __launch_bounds__(256) void adam_frozen_kernel(float* __restrict__ va
       const float mj = __fadd_rn(m[i], __fmul_rn(__fsub_rn(gj, m[i]), omb1));
       m[i] = mj;
       const bool g_poison = !isfinite(__fmul_rn(gj, gj));
-      if (g_poison) v[i] = qnan;
-      if (g_poison || !isfinite(mj)) var[i] = qnan;
+      if (g_poison || !isfinite(mj)) {
+        bad |= !isnan(var[i]) || (g_poison && !isnan(v[i]));
+        if (g_poison) v[i] = qnan;
+        var[i] = qnan;
+      }
     }
   }
+  if (poisoned && bad) atomicOr(poisoned, 1u);      // rare: a non-finite gradient reached this slice
 }
 
 // ------------------------------------------------------------------ dropout keep mask (Philox4x32-10)
@@ -708,6 +723,13 @@ int a3d_dropout_keep_mask(size_t count, uint64_t seed, uint64_t step, float rate
 int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
                        float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
                        void* stream) {
+  return a3d_adam_apply_tf1_flag(count, var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale,
+                                 nullptr, stream);
+}
+
+int a3d_adam_apply_tf1_flag(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
+                            float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
+                            unsigned int* poisoned, void* stream) {
   A3D_CHECK_ARG(count > 0 && var && m && v && g, "adam: bad arguments");
   A3D_CHECK_ARG(((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
                   reinterpret_cast<uintptr_t>(g)) & 15) == 0, "adam: buffers must be 16-byte aligned");
@@ -715,13 +737,13 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
   if (alpha == 0.f && 1.f - beta2 == 0.f) {
     clear_stale_error();
     hipLaunchKernelGGL(adam_frozen_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, grad_scale);
+                       static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, grad_scale, poisoned);
     return check_launch("adam_frozen");
   }
   clear_stale_error();
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count / 4 + 1, 256, 4096)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,
-                     grad_scale);
+                     grad_scale, poisoned);
   return check_launch("adam");
 }
 

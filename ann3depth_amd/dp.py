@@ -9,6 +9,14 @@ the conv backward kernels still run; `wait()` / `finish()` make the compute stre
 MSDNReplica keeps the dense bucket in flight across the step boundary: its ApplyAdam is only due before the next
 step's first dense layer, so the 268 MB reduction also overlaps the next step's conv forward.
 On CPU (tests) the same code runs over the gloo backend.
+
+The dense group under the reference's optimizer goes further (round 3).  AdamOptimizer(rate, 0.9, beta2 = 1)
+(src/models.py:309) has alpha = 0: the weights never move and a variable's `m` slot is read by nothing but its own next
+update.  No rank therefore needs the whole reduced gradient — `reduce_scatter()` leaves each rank with the sum of ONE
+slice (half the xGMI bytes of an all-reduce: no all-gather phase), the rank updates `m` on that slice only (1/world of
+the ApplyAdam traffic), and `all_gather()` reassembles `m` when somebody asks for it (checkpoints, tests).  This is the
+parameter server's division of labour (src/ann3depth.py:77-92: every variable lives on ONE ps task which applies the
+updates to it) without the server.
 """
 import os
 
@@ -39,6 +47,29 @@ class GradReducer:
             w.wait()
         self.pending = []
 
+    def reduce_scatter(self, flat):
+        """Begin the in-place reduce-scatter of one bucket (numel a multiple of world_size); returns (handle, own): after
+        wait(handle), `own` — this rank's 1/world slice of `flat` — holds the sum over ranks of that slice and the rest
+        of `flat` is stale.  RCCL runs it in place (recvbuff == sendbuff + rank * count), so does gloo."""
+        n = flat.numel() // self.world_size
+        assert n * self.world_size == flat.numel(), 'bucket length must be a multiple of the world size'
+        own = flat[self.rank * n:(self.rank + 1) * n]
+        work = dist.reduce_scatter_tensor(own, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append(work)
+        return work, own
+
+    def all_gather(self, flat):
+        """In place and synchronous: every rank contributes its own 1/world slice of `flat`, all end with all slices."""
+        n = flat.numel() // self.world_size
+        assert n * self.world_size == flat.numel()
+        dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
+
+    def any(self, flag):
+        """MAX of a small device tensor over the ranks (asynchronous; returns the handle)."""
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self.pending.append(work)
+        return work
+
     def broadcast(self, tensor, src=0):
         dist.broadcast(tensor, src, group=self.group)
 
@@ -47,14 +78,60 @@ class GradReducer:
         stop decision of the training loop.  Every step queues synchronous gradient all-reduces, so a rank that left the
         loop on its own (its signal handler fired, its input ran dry) would leave the others waiting in step k+1's
         collective until the watchdog kills them; with this, all ranks leave after the same global step."""
+        return self.agree_all([value])[0]
+
+    def agree_all(self, values):
+        """agree() for several integers at once (element-wise MAX): one host collective per training step."""
         if self.world_size == 1:
-            return int(value)
+            return [int(v) for v in values]
         if not hasattr(self, '_control'):
             backend = dist.get_backend(self.group)
             self._control = self.group if backend == 'gloo' else dist.new_group(backend='gloo')
-        t = torch.tensor([int(value)], dtype=torch.int64)
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._control)
-        return int(t.item())
+        return [int(v) for v in t.tolist()]
+
+
+class DetachedReducer:
+    """A reducer with the collectives taken out: a replica built with one runs exactly the kernels rank `rank` of a
+    `world_size`-way data-parallel job runs — dense gradients materialised, ApplyAdam of its own slice only — and no
+    communication.  bench.py times it on ONE GPU (`ms_per_step_dp_rank`): the local gradient stands in for the sum, so
+    the numbers it trains are meaningless and nothing but a timer should look at them."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self, world_size, rank=0):
+        self.world_size, self.rank, self.pending = world_size, rank, []
+
+    def start(self, flat_grad):
+        return self._Done()
+
+    def reduce_scatter(self, flat):
+        n = flat.numel() // self.world_size
+        return self._Done(), flat[self.rank * n:(self.rank + 1) * n]
+
+    def all_gather(self, flat):
+        pass
+
+    def any(self, flag):
+        return self._Done()
+
+    def wait(self, work):
+        pass
+
+    def finish(self):
+        pass
+
+    def broadcast(self, tensor, src=0):
+        pass
+
+    def agree(self, value):
+        return int(value)
+
+    def agree_all(self, values):
+        return [int(v) for v in values]
 
 
 def init_from_env(backend=None):

@@ -10,8 +10,10 @@ triangle filter, widened by the scale factor when shrinking (antialiasing), in f
 rounded to 22 fractional bits, accumulator started at one half, result `>> 22` and clamped; horizontal pass first, each
 pass through an 8-bit intermediate, a pass whose size does not change is skipped.
 
-Unpinned: restated from the two libraries' sources; neither is installed here.  tests/test_preprocessor.py holds the
-hand-computed cases.
+Pinned against Pillow itself where it is installed (tests/test_imresize_pillow.py: bit-identical to
+PIL.Image.resize(..., BILINEAR) on random 8-bit images, up and down, grey and RGB, including the preprocessor's
+480x640 -> 55x73); scipy.misc's part (bytescale / toimage) is restated from its source and checked on hand-computed
+cases (tests/test_hdf5.py).
 """
 import numpy as np
 

@@ -73,13 +73,16 @@ class ParamGroup:
     so the optimizer is a single streaming kernel and the data-parallel all-reduce a single bucket."""
     ALIGN = 64   # elements; keeps every tensor 256-byte aligned for 16-byte vector loads
 
-    def __init__(self, name, lr, shapes, device, beta1=0.9, beta2=1.0, eps=1e-8, slots=True):
+    def __init__(self, name, lr, shapes, device, beta1=0.9, beta2=1.0, eps=1e-8, slots=True, multiple=1):
+        """multiple: the flat length is padded (with zeros that stay zeros) to a multiple of multiple * ALIGN elements, so
+        that `multiple` data-parallel ranks can cut any bucket of it into equal, 256-byte-aligned slices."""
         self.name, self.lr, self.beta1, self.beta2, self.eps = name, lr, beta1, beta2, eps
         self.offsets = collections.OrderedDict()
         off = 0
         for n, shp in shapes.items():
             self.offsets[n] = (off, tuple(shp))
             off += -(-int(np.prod(shp)) // self.ALIGN) * self.ALIGN
+        off = -(-off // (multiple * self.ALIGN)) * (multiple * self.ALIGN)
         self.count = off
         self.var = torch.zeros(off, device=device)
         self.grad = torch.zeros(off, device=device)
@@ -98,6 +101,12 @@ class ParamGroup:
                            float(self.beta1_power), float(self.beta2_power), grad_scale)
         self.beta1_power = self.beta1_power * np.float32(self.beta1)
         self.beta2_power = self.beta2_power * np.float32(self.beta2)
+
+    def apply_slice(self, a, b, grad_scale=1.0, poisoned=None):
+        """ApplyAdam on elements [a, b) only (a data-parallel rank's slice of a reduce-scattered bucket); the caller
+        advances the beta powers once per step with advance()."""
+        ops.adam_apply_tf1(self.var[a:b], self.m[a:b], self.v[a:b], self.grad[a:b], self.lr, self.beta1, self.beta2,
+                           self.eps, float(self.beta1_power), float(self.beta2_power), grad_scale, poisoned=poisoned)
 
     def frozen(self):
         """True for the optimizer the reference builds, AdamOptimizer(rate, 0.9, beta2 = 1): alpha = 0, only m moves."""
@@ -148,6 +157,12 @@ class MSDNReplica:
         # is a quarter of the stretch, not all of it.  The dominant bwd-filter GEMMs run after the join, alone.
         self.overlap = os.environ.get('A3D_OVERLAP', '1') == '1'
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
+        # data-parallel replicas under the reference's frozen optimizer: the dense bucket is reduce-scattered and each
+        # rank keeps the Adam `m` slot of its own slices only (dp.py); gather_state() reassembles it
+        self._m_sharded = False
+        self._dense_pieces = None
+        self._poison = None       # device flag: a non-finite gradient reached one of this rank's slices
+        self._poison_seen = []    # [(event, pinned host copy of the all-rank MAX of the flag)] of earlier steps
         # conv + ReLU + max pool in one kernel inside step(): the pre-pool activations c0, c1, f1 are never written
         # (the network being trained keeps one byte per pool window instead, see forward())
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
@@ -173,7 +188,8 @@ class MSDNReplica:
         for gname, (lr, scopes) in MSDN_OPTIMIZERS.items():
             gshapes = collections.OrderedDict((n, s) for n, s in shapes.items()
                                               if any(n.startswith(sc + '/') for sc in scopes))
-            self.groups[gname] = ParamGroup(gname, lr, gshapes, dev, beta2=beta2)
+            world = reducer.world_size if (reducer is not None and gname == 'CoarseDense') else 1
+            self.groups[gname] = ParamGroup(gname, lr, gshapes, dev, beta2=beta2, multiple=world)
             for n in gshapes:
                 self.group_of[n] = gname
         if params is None:
@@ -269,6 +285,7 @@ class MSDNReplica:
         if handle:
             try:
                 torch.cuda.synchronize(self.device)
+                ops.drop_workspace(handle)
                 _lib.load().a3d_stream_destroy(handle)
             except Exception:          # noqa: BLE001 - interpreter shutdown: the driver reclaims the stream
                 pass
@@ -291,6 +308,12 @@ class MSDNReplica:
         if self.bf16s:
             self.w4[:, :, :3, :] = self._v('fine/first/conv2d/kernel')
 
+    def _weights_moved(self, *groups):
+        """After an ApplyAdam that can change `var` (any optimizer but the reference's frozen beta2 = 1 one): the bf16
+        copies the next forward / bwd-data read must follow the fp32 masters."""
+        if self.wcopy and not all(g.frozen() for g in groups):
+            self.refresh_weight_copies()
+
     # ---- variables ----
     def settle(self):
         """Finish what step() left in flight across the step boundary (the CoarseDense all-reduce and its ApplyAdam).
@@ -298,9 +321,82 @@ class MSDNReplica:
         if self._deferred is not None:
             works, group, scale = self._deferred
             self._deferred = None
+            if works and isinstance(works[0], tuple):          # reduce-scattered pieces: (handle, first, last) of my slice
+                self._poll_poison()
+                for work, a, b in works:
+                    self.reducer.wait(work)
+                    group.apply_slice(a, b, scale, poisoned=self._poison)
+                group.advance()
+                self._m_sharded = True
+                self._watch_poison()
+                return
             for work in works:
                 self.reducer.wait(work)
             group.apply(scale)
+            self._weights_moved(group)
+
+    def _dense_buckets(self):
+        """The CoarseDense flat buffer cut for reduce-scatter, in the order the backward completes it: (early, late) where
+        `early` = [(c, count)] holds dense_1's gradient only (c = its first element rounded UP to a slice boundary) and goes
+        out as soon as dense_1's bwd-filter is done, `late` = [0, c) in three pieces, complete after dense_0's."""
+        if self._dense_pieces is None:
+            gd = self.groups['CoarseDense']
+            q = self.reducer.world_size * ParamGroup.ALIGN
+            c = -(-gd.offsets['coarse/dense/dense_1/kernel'][0] // q) * q
+            third = -(-(c // 3) // q) * q
+            self._dense_pieces = ([(c, gd.count)], [(0, third), (third, 2 * third), (2 * third, c)])
+        return self._dense_pieces
+
+    def _my_slice(self, a, b):
+        n = (b - a) // self.reducer.world_size
+        return a + self.reducer.rank * n, a + (self.reducer.rank + 1) * n
+
+    def _watch_poison(self):
+        """The reference's optimizer changes a weight in exactly one case: a non-finite gradient turns it into NaN.  Under
+        sharding only the slice's owner sees that; the MAX of the per-rank flags (a 4-byte all-reduce per step) tells
+        everybody, read on the host two steps later (no stall), and _resync() then copies the owners' var / v slices."""
+        red = self.reducer
+        work = red.any(self._poison)
+        red.wait(work)
+        host = torch.empty(1, dtype=torch.int32).pin_memory() if self.device.type == 'cuda' else torch.empty(1, dtype=torch.int32)
+        host.copy_(self._poison, non_blocking=True)
+        ev = None
+        if self.device.type == 'cuda':
+            ev = torch.cuda.Event()
+            ev.record()
+        self._poison_seen.append((ev, host))
+
+    def _poll_poison(self, block=False):
+        while self._poison_seen and (block or len(self._poison_seen) >= 2):
+            ev, host = self._poison_seen.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            if int(host.item()):
+                self._resync()
+
+    def _resync(self):
+        """Every rank takes the slice owners' var and v (and m) of the dense group; clears the poison flag."""
+        gd = self.groups['CoarseDense']
+        early, late = self._dense_buckets()
+        for a, b in early + late:
+            for buf in (gd.var, gd.v, gd.m):
+                self.reducer.all_gather(buf[a:b])
+        self._poison.zero_()
+        self._poison_seen = []
+        self._m_sharded = False
+
+    def gather_state(self):
+        """COLLECTIVE under a data-parallel reducer (every rank must call it): reassembles the sharded Adam `m` slot of the
+        dense group on all ranks.  The driver calls it before the chief writes a checkpoint; a no-op otherwise."""
+        self.settle()
+        if self._m_sharded:
+            self._poll_poison(block=True)
+        if self._m_sharded:
+            gd = self.groups['CoarseDense']
+            early, late = self._dense_buckets()
+            for a, b in early + late:
+                self.reducer.all_gather(gd.m[a:b])
+            self._m_sharded = False
 
     def load_params(self, params):
         self.settle()
@@ -329,13 +425,14 @@ class MSDNReplica:
         return self._g(name)
 
     def slot(self, name, which):
-        self.settle()
+        self.gather_state()        # collective under a data-parallel reducer whose dense m slot is sharded
         g = self.groups[self.group_of[name]]
         return g.view(g.m if which == 'm' else g.v, name)
 
     def state_dict(self):
-        """name -> tensor for every variable, Adam slot (TF slot naming '<var>/<Optimizer>[_1]') and global_step."""
-        self.settle()
+        """name -> tensor for every variable, Adam slot (TF slot naming '<var>/<Optimizer>[_1]') and global_step.
+        Collective under a data-parallel reducer (gather_state)."""
+        self.gather_state()
         sd = collections.OrderedDict()
         for n in self.shapes:
             sd[n] = self.var(n)
@@ -348,7 +445,7 @@ class MSDNReplica:
         return sd
 
     def load_state_dict(self, sd):
-        self.settle()
+        self.gather_state()
         for n in self.shapes:
             self.var(n).copy_(sd[n])
             self.slot(n, 'm').copy_(sd[n + '/' + self.group_of[n]])
@@ -357,6 +454,8 @@ class MSDNReplica:
             g.beta1_power = np.float32(sd[gname + '/beta1_power'].item())
             g.beta2_power = np.float32(sd[gname + '/beta2_power'].item())
         self.global_step = int(sd['global_step'].item())
+        if self.wcopy:
+            self.refresh_weight_copies()
 
     uses_dropout = True
 
@@ -414,7 +513,7 @@ class MSDNReplica:
 
     def broadcast_state(self, dist, src=0):
         """Non-chief replicas take the chief's variables, slots, beta powers and global_step."""
-        self.settle()
+        self.gather_state()
         for g in self.groups.values():
             for buf in (g.var, g.m, g.v):
                 dist.broadcast(buf, src)
@@ -425,6 +524,8 @@ class MSDNReplica:
         self.global_step = int(st[0].item())
         for i, g in enumerate(self.groups.values()):
             g.beta1_power, g.beta2_power = np.float32(st[1 + 2 * i].item()), np.float32(st[2 + 2 * i].item())
+        if self.wcopy:
+            self.refresh_weight_copies()
 
     def _kb(self, name):
         return self._v(name + '/kernel'), self._v(name + '/bias')
@@ -529,7 +630,8 @@ class MSDNReplica:
                 self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
             else:
                 self._conv('fine/first/conv2d', self.x, self.f1)
-        self.settle()               # the previous step's dense-layer update is due now, not earlier
+        if not self._sharded_in_flight():
+            self.settle()           # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
         if self.bf16s:              # c4 crosses to the dense layers' fp32 side; dense_0 reads its 100 MB bf16 weight copy
             ops.cast_bf16(self.c4, self.c4_32)
@@ -550,6 +652,12 @@ class MSDNReplica:
         ops.silog_loss_fwd(self.coarse, self.t, self.loss_coarse, self.ws_c)
         if join:
             self._join()
+
+    def _sharded_in_flight(self):
+        """The deferred dense bucket is a reduce-scatter feeding only the m slot: nothing in the forward needs it, it is due
+        when the next backward is about to overwrite the gradient buffer it reads (backward_coarse settles first)."""
+        d = self._deferred
+        return d is not None and bool(d[0]) and isinstance(d[0][0], tuple)
 
     def _fused_dense_adam(self):
         return not self.keep_dense_grads and self.groups['CoarseDense'].frozen()
@@ -573,6 +681,7 @@ class MSDNReplica:
     def backward_coarse(self, after_dense=None, after_conv2=None, after_dense1=None):
         B = self.B
         ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1))
+        self.settle()              # a reduce-scatter of the previous step may still be reading the dense gradient buffer
         n = 'coarse/dense/dense_1'
         self._bwd_filter(n, self.drop, self.dz1)
         if after_dense1 is not None:
@@ -655,6 +764,7 @@ class MSDNReplica:
                     gd.advance()                       # ApplyAdam of coarse/dense/* already happened inside the backward
                 else:
                     gd.apply(scale)
+                self._weights_moved(gc, gd)
             else:
                 # dense bucket (268 MB): reduced while the conv backward runs AND, being due only before the next
                 # step's dense_0, while that step's conv forward runs (settle()); conv bucket (15 MB): waited for here
@@ -663,19 +773,33 @@ class MSDNReplica:
                 # the 2.6 MB head is reduced on the critical path
                 handle, tail = [], []
                 cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
-                # dense bucket in backward production order: dense_1 (67 MB) leaves as soon as its filter
-                # gradient exists, dense_0 (201 MB) in three pieces after its own — four collectives of 50-67 MB pipeline
-                # over the xGMI links where one 268 MB ring would serialise behind its own reduce-scatter
-                d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
-                third = -(-(d1 // 3) // ParamGroup.ALIGN) * ParamGroup.ALIGN
-                pieces0 = [(0, third), (third, 2 * third), (2 * third, d1)]
-                self.backward_coarse(after_dense1=lambda: handle.append(red.start(gd.grad[d1:])),
-                                     after_dense=lambda: handle.extend(red.start(gd.grad[a:b]) for a, b in pieces0),
+                if gd.frozen():
+                    # the reference's optimizer: reduce-scatter, each rank updates m on its own slices only (dp.py)
+                    early, late = self._dense_buckets()
+                    if self._poison is None:
+                        self._poison = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+                    def scatter(pieces):
+                        for a, b in pieces:
+                            work, _ = red.reduce_scatter(gd.grad[a:b])
+                            handle.append((work,) + self._my_slice(a, b))
+                    after_dense1, after_dense = (lambda: scatter(early)), (lambda: scatter(late))
+                else:
+                    # dense bucket in backward production order: dense_1 (67 MB) leaves as soon as its filter
+                    # gradient exists, dense_0 (201 MB) in three pieces after its own — four collectives of 50-67 MB
+                    # pipeline over the xGMI links where one 268 MB ring would serialise behind its own reduce-scatter
+                    d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
+                    third = -(-(d1 // 3) // ParamGroup.ALIGN) * ParamGroup.ALIGN
+                    pieces0 = [(0, third), (third, 2 * third), (2 * third, d1)]
+                    after_dense1 = lambda: handle.append(red.start(gd.grad[d1:]))
+                    after_dense = lambda: handle.extend(red.start(gd.grad[a:b]) for a, b in pieces0)
+                self.backward_coarse(after_dense1=after_dense1, after_dense=after_dense,
                                      after_conv2=lambda: tail.append(red.start(gc.grad[cut:])))
                 head = red.start(gc.grad[:cut])
                 red.wait(tail[0])
                 red.wait(head)
                 gc.apply(scale)
+                self._weights_moved(gc)
                 self._deferred = (handle, gd, scale)
         elif phase == 2:
             ga, gb = self.groups['FineA'], self.groups['FineB']
@@ -686,6 +810,7 @@ class MSDNReplica:
                 red.finish()
             ga.apply(scale)
             gb.apply(scale)
+            self._weights_moved(ga, gb)
         self._join()
         self.global_step += 1
         return {'coarse_loss': self.loss_coarse, 'fine_loss': self.loss_fine, 'phase': phase}
@@ -949,6 +1074,9 @@ class DCNFReplica:
         st = torch.tensor([self.global_step], dtype=torch.float64, device=self.device)
         dist.broadcast(st, src)
         self.global_step = int(st[0].item())
+
+    def gather_state(self):
+        """Nothing is sharded here (the driver calls this on every replica before a checkpoint)."""
 
     def state_dict(self):
         sd = collections.OrderedDict()

@@ -53,6 +53,12 @@ def _ws():
     return w
 
 
+def drop_workspace(stream_handle):
+    """Forget the workspace of a stream that is being destroyed (its split-K scratch goes back to the allocator, and a
+    later stream that happens to get the same handle value starts with a workspace of its own)."""
+    _WS.pop(stream_handle, None)
+
+
 def same_pad(in_size, k, stride):
     out = -(-in_size // stride)
     pad = max((out - 1) * stride + k - in_size, 0)
@@ -224,7 +230,13 @@ def silog_loss_bwd(out, tgt, ws, dout):
     return dout
 
 
-def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale=1.0):
+def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale=1.0, poisoned=None):
+    """poisoned: optional int32[1] device tensor; bit 0 is set when the update left a non-finite weight behind."""
+    if poisoned is not None:
+        check(_lib.load().a3d_adam_apply_tf1_flag(var.numel(), _ptr(var), _ptr(m), _ptr(v), _ptr(g), lr, beta1, beta2, eps,
+                                                  beta1_power, beta2_power, grad_scale, _ptr(poisoned), _stream()),
+              'a3d_adam_apply_tf1_flag')
+        return
     check(_lib.load().a3d_adam_apply_tf1(var.numel(), _ptr(var), _ptr(m), _ptr(v), _ptr(g), lr, beta1, beta2, eps,
                                          beta1_power, beta2_power, grad_scale, _stream()), 'a3d_adam_apply_tf1')
 

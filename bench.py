@@ -234,27 +234,39 @@ def comm_report(net, img, dep, masks, args, lib, world, dt):
     hide: ms/step with the reducer minus ms/step of the same replica without one (same kernels, no collectives)."""
     import torch.distributed as dist
     from ann3depth_amd import models
+    from ann3depth_amd import dp
     gd, gc = net.groups['CoarseDense'], net.groups['CoarseConv']
-    d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
     cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
-    buckets = {'dense_1': gd.grad[d1:], 'dense_0_piece': gd.grad[:d1 // 3], 'conv_tail': gc.grad[cut:],
-               'conv_head': gc.grad[:cut]}
+    if gd.frozen():       # the reference's optimizer: the dense bucket is reduce-scattered (models.MSDNReplica._dense_buckets)
+        (early,), late = net._dense_buckets()
+        buckets = {'dense_1': ('reduce_scatter', gd.grad[early[0]:early[1]]),
+                   'dense_0_piece': ('reduce_scatter', gd.grad[late[0][0]:late[0][1]])}
+    else:
+        d1 = gd.offsets['coarse/dense/dense_1/kernel'][0]
+        buckets = {'dense_1': ('all_reduce', gd.grad[d1:]), 'dense_0_piece': ('all_reduce', gd.grad[:d1 // 3])}
+    buckets.update({'conv_tail': ('all_reduce', gc.grad[cut:]), 'conv_head': ('all_reduce', gc.grad[:cut])})
     times = {}
-    for name, buf in buckets.items():
+    for name, (kind, buf) in buckets.items():
         scratch = buf.clone()
+        n = scratch.numel() // world
+        own = scratch[dist.get_rank() * n:(dist.get_rank() + 1) * n]
+        run = (lambda: dist.all_reduce(scratch)) if kind == 'all_reduce' else (lambda: dist.reduce_scatter_tensor(own, scratch))
         for _ in range(2):
-            dist.all_reduce(scratch)
+            run()
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(5):
-            dist.all_reduce(scratch)
+            run()
         torch.cuda.synchronize()
         t = torch.tensor([(time.perf_counter() - t0) / 5], device=img.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        times[name] = {'ms': round(1e3 * float(t.item()), 3), 'mbytes': round(scratch.numel() * 4 / 1e6, 1)}
-        del scratch
-    solo = models.MSDNReplica(net.B, device=img.device, seed=3000, reducer=None, precision=args.precision)
+        times[name] = {'ms': round(1e3 * float(t.item()), 3), 'mbytes': round(scratch.numel() * 4 / 1e6, 1),
+                       'collective': kind}
+        del scratch, own
+    # the same rank without its collectives: same kernels (dense gradients materialised, ApplyAdam of its own slices)
+    solo = models.MSDNReplica(net.B, device=img.device, seed=3000, reducer=dp.DetachedReducer(world, dist.get_rank()),
+                              precision=args.precision)
     n = max(3, args.steps // 2)
     dts, _ = run_phase(solo, img, dep, masks, n, 2, 0, lib, world, timed_kernels=False)
     return {'rccl_ranks': world, 'allreduce_ms': times,
@@ -273,6 +285,8 @@ def main():
                     help='conv arithmetic; the headline (and parity) mode is fp32')
     ap.add_argument('--also', default='bf16x3', help='comma list of extra precisions measured after the headline run')
     ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
+    ap.add_argument('--no-dp-rank', action='store_true', help='N = 1: skip timing the step a data-parallel rank would run')
+    ap.add_argument('--dp-world', type=int, default=8, help='world size assumed by the N = 1 dp_rank measurement')
     ap.add_argument('--model', default='msdn', choices=['msdn', 'dcnf'],
                     help="msdn = the headline (BASELINE config 2/3/5); dcnf = BASELINE config 4, the DCNF-lite unary stack "
                          "at batch 16 (768 patches): a separate line, 'step' = unary forward + backward")
@@ -324,6 +338,21 @@ def main():
     comm = {}
     if world > 1:
         comm = comm_report(net, img, dep, masks, args, lib, world, dt)
+    elif not args.no_dp_rank:
+        # The step a data-parallel rank runs is NOT the fused single-GPU step timed above (it must materialise the 268 MB
+        # of dense gradients for the reduce-scatter and applies Adam to its own 1/world of them).  Timed here on this one
+        # GPU with the collectives detached: the ceiling of 1 -> 8 scaling before any communication cost is
+        # 8 * ms_per_step / ms_per_step_dp_rank.
+        from ann3depth_amd import dp as _dp
+        dnet = models.MSDNReplica(B, device=device, seed=3000, reducer=_dp.DetachedReducer(args.dp_world, 0),
+                                  precision=args.precision)
+        dtd, _ = run_phase(dnet, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
+        extra['dp_rank'] = {
+            'ms_per_step_dp_rank': round(1e3 * dtd / args.steps, 3), 'world_assumed': args.dp_world,
+            'what': 'coarse-phase step of ONE rank of a data-parallel job, collectives detached (dp.DetachedReducer): '
+                    'dense dW written (268 MB), ApplyAdam on the rank\'s own slices; no RCCL time included',
+            'scaling_ceiling': round(args.dp_world * dt / dtd, 2)}
+        del dnet
     if rank == 0:
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

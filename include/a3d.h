@@ -215,6 +215,15 @@ int a3d_adam_apply_tf1(size_t count, float* var, float* m, float* v, const float
                        float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
                        void* stream);
 
+/* The same ApplyAdam over one rank's SLICE of a parameter group (data-parallel replicas that reduce-scatter their
+ * gradients instead of all-reducing them: each rank updates only the slice whose gradient sum it received — what
+ * replaces the parameter server's per-variable update of src/ann3depth.py:77-92).  `poisoned` (device, may be NULL)
+ * gets bit 0 set when the update left a non-finite value in var[0..count) — the only case in which the reference's
+ * frozen optimizer (beta2 = 1) changes a weight at all, and the one the other ranks must then be told about. */
+int a3d_adam_apply_tf1_flag(size_t count, float* var, float* m, float* v, const float* g, float lr, float beta1,
+                            float beta2, float eps, float beta1_power, float beta2_power, float grad_scale,
+                            unsigned int* poisoned, void* stream);
+
 /* ---- DCNF pairwise part + CRF negative log-likelihood (src/models.py:20-48,91-177,185-200) ----
  * Superpixels are the sp x sp (40 x 40) non-overlapping blocks of the 240x320 image, row-major (src/models.py:37-48). */
 

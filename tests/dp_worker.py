@@ -51,6 +51,45 @@ def main(out_path):
         rel = lambda x, y: float(np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y))
         with open(out_path, 'w') as f:
             f.write(f'{rel(dense.numpy(), d2)} {rel(conv.numpy(), c2)}\n')
+    # ---- the dense bucket as the product sends it under the reference's frozen optimizer: reduce-scatter, ApplyAdam of
+    # this rank's slice only, m gathered on demand (ann3depth_amd/dp.py, models.MSDNReplica._dense_buckets).  Two steps
+    # with different gradients; N ranks must equal ONE rank applying the summed gradient — bit for bit on m.
+    from oracle.tf13_ops import AdamTF1
+    local = torch.cat([torch.from_numpy(g[n]).reshape(-1) for n in sorted(g) if n.startswith('coarse/dense')])
+    q = world * 64
+    padded = -(-local.numel() // q) * q
+    cut = -(-(padded // 3) // q) * q
+    pieces = [(cut, padded), (0, cut)]                        # production order: the tail leaves first
+    m_sharded = np.zeros(padded, np.float32)
+    one = AdamTF1(0.1, 0.9, 1.0)                              # the reference: AdamOptimizer(rate, 0.9, 1)
+    var_one = {'w': np.zeros(padded, np.float32)}
+    mine = AdamTF1(0.1, 0.9, 1.0)
+    for step in range(2):
+        gl = torch.nn.functional.pad(local * (1.0 + step) * (1 + rank), (0, padded - local.numel()))
+        total = gl.clone()
+        torch.distributed.all_reduce(total)                   # what ONE rank holding every sample's gradient would sum
+        handles = [(red.reduce_scatter(gl[a:b]), a, b) for a, b in pieces]
+        for (work, own), a, b in handles:
+            red.wait(work)
+            n = (b - a) // world
+            lo = a + rank * n
+            assert own.data_ptr() == gl[lo:lo + n].data_ptr()              # in place: my slice of the bucket itself
+            assert torch.equal(own, total[lo:lo + n])
+            var = {'s': np.zeros(n, np.float32)}
+            mine.m['s'], mine.v['s'] = m_sharded[lo:lo + n], np.zeros(n, np.float32)
+            p1, p2 = mine.beta1_power, mine.beta2_power
+            mine.apply(var, {'s': own.numpy() * np.float32(1.0 / world)})
+            mine.beta1_power, mine.beta2_power = p1, p2                      # powers advance once per step, not per slice
+            assert not var['s'].any()                                        # alpha == 0: the weights do not move
+        mine.beta1_power, mine.beta2_power = mine.beta1_power * mine.beta1, mine.beta2_power * mine.beta2
+        assert red.pending == []
+        one.apply(var_one, {'w': total.numpy() * np.float32(1.0 / world)})
+    gathered = torch.from_numpy(m_sharded.copy())
+    for a, b in pieces:
+        red.all_gather(gathered[a:b])                          # every rank contributes its slice of every piece
+    assert np.array_equal(gathered.numpy(), one.m['w']), 'sharded m differs from one rank on the summed gradient'
+    assert float(np.abs(one.m['w']).max()) > 0
+    assert red.agree_all([rank, 5 - rank, 0]) == [1, 5, 0]
     # collective stop decision (dp.GradReducer.agree): SIGUSR1 reaches rank 1 only, during its third "step"; both ranks
     # must leave the loop after the same step with the signal number as the agreed value
     import signal

@@ -26,6 +26,24 @@ def test_two_ranks_one_gpu(tmp_path):
     assert open(out).read() == '1'
 
 
+def test_two_ranks_at_batch_32_each_match_the_oracle_on_all_64(tmp_path):
+    """the step a data-parallel rank actually runs, at BASELINE config 3's per-rank batch (32, stored
+    480x640), both trained phases, against the oracle on the concatenated batch (tests/dp_gpu_worker.py::main_b32)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'ok.txt')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out, 'b32'], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    assert open(out).read() == '1'
+
+
 @pytest.mark.parametrize('model,batch,steps', [('msdn', 4, 5), ('dcnf', 1, 3)])
 def test_make_train_two_replicas(tmp_path, model, batch, steps):
     """`make train GPUS=2` as the driver runs it (two processes of ann3depth_amd.ann3depth; gloo because both ranks share

@@ -183,6 +183,82 @@ def test_msdn_full_batch_matches_oracle(models, phase, global_step):
         assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
 
 
+def shifted_params(seed=3000, shift=1.0):
+    """The seed weights with both output biases at +shift: the depth maps then lie in [0.7, 1.3] instead of straddling
+    zero, d loss / d o_i = (...) / (o_i + 1e-8) is well conditioned, and a gradient can be compared END TO END at the
+    tolerance of the fp32 accumulation order instead of GRAD_TOL_END_TO_END."""
+    params = O.init_params(seed)
+    params['coarse/dense/dense_1/bias'] = np.full_like(params['coarse/dense/dense_1/bias'], shift)
+    params['fine/third/bias'] = np.full_like(params['fine/third/bias'], shift)
+    return params
+
+
+@pytest.mark.parametrize('phase,global_step', [(1, 0), (2, 2000000 // 32)])
+def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, global_step):
+    """The replica bench.py and `make train` build on one GPU — keep_dense_grads=False: dense dW goes from the matrix
+    cores straight into ApplyAdam's m slot — at BASELINE config 2 (B = 32, 480x640 stored), against the oracle END TO
+    END (its own forward, its own backward, its own ApplyAdam): depth maps, losses, every gradient that exists and every
+    m slot at 1e-4; weights untouched (beta2 = 1).  Outputs are shifted away from zero (shifted_params) so that the loss
+    gradient does not amplify last-bit differences of the forward."""
+    B = 32
+    img, dep, keep = synth(B, 4321)
+    params = shifted_params()
+    net = models.MSDNReplica(B, params=params, global_step=global_step, keep_dense_grads=False)
+    assert net._fused_dense_adam()
+    out = net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    torch.cuda.synchronize()
+    tr = O.Trainer({k: v.copy() for k, v in params.items()}, B, global_step=global_step)
+    a, g, ph = tr.step(img, dep, keep)
+    assert ph == phase == out['phase']
+    assert a['coarse'].min() > 0.5 and a['fine'].min() > 0.5                 # the point of the shift
+    assert rel(net.coarse.cpu().numpy(), a['coarse']) < 1e-5
+    assert rel(net.fine.cpu().numpy(), a['fine']) < 1e-5
+    assert abs(out['coarse_loss'].item() - a['loss_coarse']) < 1e-5 * abs(a['loss_coarse'])
+    assert abs(out['fine_loss'].item() - a['loss_fine']) < 1e-5 * abs(a['loss_fine'])
+    omb1 = np.float32(1) - np.float32(0.9)
+    fused = ('coarse/dense/dense_0/kernel', 'coarse/dense/dense_0/bias', 'coarse/dense/dense_1/kernel',
+             'coarse/dense/dense_1/bias')
+    for n, gref in g.items():
+        if n not in fused:                                                   # the fused layers never write their gradient
+            assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
+        opt = tr.opt[net.group_of[n]]
+        assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < GRAD_TOL, n  # m = (1 - beta1) g, the oracle's ApplyAdam
+        np.testing.assert_array_equal(opt.m[n], gref * omb1)
+        assert (net.slot(n, 'v').cpu().numpy() == 0).all()
+        np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])
+    if phase == 1:
+        assert set(fused) <= set(g)
+
+
+def test_msdn_learning_mode_tracks_the_oracles_adam_slots(models):
+    """beta2 = 0.999 (flagged non-reference mode), three steps on well-conditioned outputs (shifted_params): Adam's m and v
+    of every trained variable against the oracle's ApplyAdam — at 1e-5 after the first step (a pure function of the
+    gradient: a wrong beta, epsilon or bias-correction constant cannot hide), and the weight update itself; later steps
+    compound through alpha * m / sqrt(v), whose sign for a near-zero gradient element is decided by fp32 summation order,
+    so they are held to 1e-3 on the slots."""
+    B = 2
+    params = shifted_params()
+    net = models.MSDNReplica(B, params=params, beta2=0.999)
+    tr = O.Trainer({k: v.copy() for k, v in params.items()}, B, beta2=0.999)
+    for step in range(3):
+        img, dep, keep = synth(B, 1000 + step, 96, 128)
+        net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+        tr.step(img, dep, keep)
+        tol = 1e-5 if step == 0 else 1e-3
+        for n in params:
+            if not n.startswith('coarse'):
+                continue
+            opt = tr.opt[net.group_of[n]]
+            assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < tol, (step, n, 'm')
+            assert rel(net.slot(n, 'v').cpu().numpy(), opt.v[n]) < 2 * tol, (step, n, 'v')
+            if step == 0:
+                # var -= alpha * m / (sqrt(v) + eps): compare the UPDATE where the gradient is clear of the epsilon
+                upd, ref = net.var(n).cpu().numpy() - params[n], tr.p[n] - params[n]
+                big = np.abs(opt.m[n]) > 1e-6
+                assert big.mean() > 0.3, n
+                assert rel(upd[big], ref[big]) < 1e-4, n
+
+
 @pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 5e-2)])
 def test_msdn_bf16_modes_keep_the_depth_tolerance(models, prec, tol):
     """The bf16-MFMA modes end to end: bf16x3 stays far inside the north-star 1e-3 depth tolerance; plain bf16
@@ -328,3 +404,35 @@ def test_msdn_bf16_storage_at_config5_batch(models):
     a_gpu = gpu_activations(net2)
     for n, gref in O.backward_fine(params, a_gpu).items():
         assert rel(net2.grad(n).cpu().numpy(), gref) < 6e-2, n
+
+
+@pytest.mark.parametrize('global_step', [0, 2000000 // 2])
+def test_bf16_storage_weight_copies_follow_the_masters(models, global_step):
+    """under precision 'bf16s' every conv / dense_0 kernel has a bf16 copy beside its fp32 master.  With
+    an optimizer that moves the weights (--beta2 < 1) the copies must be refreshed after every ApplyAdam, and after a
+    checkpoint restore — otherwise forward and bwd-data keep computing with the initial weights."""
+    B = 2
+    params = shifted_params()
+    net = models.MSDNReplica(B, params=params, beta2=0.999, precision='bf16s', global_step=global_step)
+    assert net.wcopy
+    for step in range(2):
+        img, dep, keep = synth(B, 1000 + step, 96, 128)
+        net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    moved = 0
+    for n, c in net.wcopy.items():
+        master = net.var(n + '/kernel')
+        moved += int(not torch.equal(master.cpu(), torch.from_numpy(params[n + '/kernel'])))
+        assert torch.equal(c, master.to(torch.bfloat16)), n                 # round-to-nearest-even, like a3d_cast_bf16
+    assert moved >= (4 if global_step == 0 else 1)
+    assert torch.equal(net.w4[:, :, :3, :], net.var('fine/first/conv2d/kernel')) and not net.w4[:, :, 3, :].any()
+    # restore into a replica that was initialised with OTHER weights: copies follow, and the next step is the same step
+    other = models.MSDNReplica(B, seed=1, beta2=0.999, precision='bf16s')
+    other.load_state_dict(net.state_dict())
+    for n, c in other.wcopy.items():
+        assert torch.equal(c, net.wcopy[n]), n
+    assert torch.equal(other.w4, net.w4)
+    img, dep, keep = synth(B, 77, 96, 128)
+    args = (torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
+    net.step(*args)
+    other.step(*args)
+    assert torch.equal(other.coarse, net.coarse) and torch.equal(other.fine, net.fine)

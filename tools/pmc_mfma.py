@@ -1,7 +1,7 @@
 """Builds profiles/<round>_pmc_mfma_busy.json from one rocprofv3 counter pass of the bench command:
 
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
-              --output-format csv -d gpurun_out/pmc_mfma -o m -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --also ""
+              --output-format csv -d gpurun_out/pmc_mfma -o m -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --no-dp-rank --also ""
     python tools/pmc_mfma.py gpurun_out/pmc_mfma/m_counter_collection.csv gpurun_out/pmc_mfma/m_kernel_trace.csv profiles/rNN_pmc_mfma_busy.json
 
 mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the share of the kernel during which a
