@@ -320,31 +320,38 @@ __device__ __forceinline__ float masked_log(float v) {
   return isnan(l) ? 0.f : l;     // tf.where(tf.is_nan(log), 0, log): -inf is kept
 }
 
-// one block per sample: ws[2b] = sum d^2, ws[2b+1] = sum d; the block that finishes last (ticket in ws[2*nb], which
-// wraps back to 0: nothing to re-initialise between calls) adds the batch up — one launch instead of two.  The per-sample
-// sums cross CUs as write-through stores, drained before the ticket, and are read back past the L1 (MI355X_MICROARCH.md,
-// inter-workgroup visibility).
+// kSilogParts blocks per sample (one sample is 4070 pixels at MSDN's size: with one block per sample 32 CUs each walked a
+// chain of load latencies and logarithms — 29 us on the step's critical path; now every CU holds one short piece).  Block
+// (b, part) leaves its partial sums in ws[2nb+1 + 2(b*parts+part) ..]; the block that finishes last (ticket in ws[2nb],
+// which wraps back to 0: nothing to re-initialise between calls) adds each sample's parts in part order — the same sum
+// whatever the timing — writes ws[2b] = sum d^2, ws[2b+1] = sum d for the backward kernel, and the batch mean.  The
+// partials cross CUs as write-through stores, drained before the ticket, and are read back past the L1
+// (MI355X_MICROARCH.md, inter-workgroup visibility).
+constexpr int kSilogParts = A3D_SILOG_PARTS;
 __global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
-                                                        float* __restrict__ ws, float* __restrict__ loss, int npix, float c) {
+                                                        float* __restrict__ ws, float* __restrict__ loss, int npix, int nb,
+                                                        float c) {
   __shared__ float red[2][4];
   __shared__ unsigned last;
-  const int b = blockIdx.x, nb = gridDim.x;
+  const int b = blockIdx.x / kSilogParts, part = blockIdx.x % kSilogParts;
+  const int chunk = (npix + kSilogParts - 1) / kSilogParts;
+  const int lo = part * chunk, hi = min(npix, lo + chunk);
   const float* o = out + (size_t)b * npix;
   const float* t = tgt + (size_t)b * npix;
+  float* partials = ws + 2 * nb + 1;
   float s2 = 0.f, s1 = 0.f;
-  // eight elements per thread and round, all sixteen loads issued before the first logarithm: a block is alone on its
-  // CU with one sample (4070 pixels at MSDN's size), so what this loop costs is its chain of load latencies
-  for (int i0 = threadIdx.x; i0 < npix; i0 += 8 * 256) {
-    float ov[8], tv[8];
+  // four elements per thread and round, all eight loads issued before the first logarithm
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {
+    float ov[4], tv[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * 256;
-      ov[u] = i < npix ? o[i] : 0.f;
-      tv[u] = i < npix ? t[i] : 0.f;
+      ov[u] = i < hi ? o[i] : 0.f;
+      tv[u] = i < hi ? t[i] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (i0 + u * 256 >= npix) break;
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * 256 >= hi) break;
       const float d = __fsub_rn(masked_log(ov[u]), masked_log(tv[u]));
       s2 += d * d;
       s1 += d;
@@ -358,17 +365,26 @@ __global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict_
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&ws[2 * b], red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ws[2 * b + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned total = (unsigned)(nb * kSilogParts);
+    __hip_atomic_store(&partials[2 * blockIdx.x], red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[2 * blockIdx.x + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = atomicInc(reinterpret_cast<unsigned*>(ws + 2 * nb), (unsigned)nb - 1u) == (unsigned)nb - 1u;
+    last = atomicInc(reinterpret_cast<unsigned*>(ws + 2 * nb), total - 1u) == total - 1u;
   }
   __syncthreads();
   if (!last || threadIdx.x >= 64) return;
   float s = 0.f;
   for (int i = threadIdx.x; i < nb; i += 64) {
-    const float a2 = __hip_atomic_load(&ws[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float a1 = __hip_atomic_load(&ws[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float a2 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < kSilogParts; ++q) {
+      a2 += __hip_atomic_load(&partials[2 * (i * kSilogParts + q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a1 += __hip_atomic_load(&partials[2 * (i * kSilogParts + q) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ws[2 * i] = a2;
+    ws[2 * i + 1] = a1;
     s += a2 - c * (a1 * a1);
   }
   s = wave_sum(s);
@@ -697,7 +713,7 @@ int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, floa
   A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && loss && ws, "silog_fwd: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   clear_stale_error();
-  hipLaunchKernelGGL(silog_fwd_kernel, dim3(b), dim3(256), 0, st, out, tgt, ws, loss, npix, kSilogC);
+  hipLaunchKernelGGL(silog_fwd_kernel, dim3(b * kSilogParts), dim3(256), 0, st, out, tgt, ws, loss, npix, b, kSilogC);
   return check_launch("silog_fwd");
 }
 

