@@ -69,4 +69,10 @@ int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const f
 int stencil1_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
                         hipStream_t st);
 
+// ---- few-channel forward convolution straight from L2 (conv3.hip) ----
+bool conv3_applicable(const a3d_conv_desc* d, const void* x);
+size_t conv3_ws_bytes(const a3d_conv_desc* d);
+int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
+              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace a3d

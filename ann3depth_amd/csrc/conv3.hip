@@ -1,0 +1,257 @@
+// conv3.hip — forward convolution of the few-channel layers (Cin <= 4, unpadded: coarse/conv/conv2d_0 11x11 s4,
+// fine/first 9x9 s2, src/models.py:211,241; DCNF's first conv 11x11 s1, src/models.py:64) on the fp32 matrix cores,
+// with operands taken straight from L1/L2: no LDS, no barriers, no im2col tile.
+//
+// With few channels a filter row (s, c) of one output pixel is ONE contiguous run of S*Cin floats of the image.  The K
+// axis is (r, q): filter row r, position q inside the run, the run padded to a multiple of 4 floats (the filter gets zero
+// rows for the pad, the image floats read there are the next pixels of the same row).  Then
+//   * the k -> (r, q) decode is the same for every pixel, so a lane's A address is `pixel base + offset(k)`: one add;
+//   * four consecutive k of one pixel are 16 contiguous bytes: lane (row li, half h) of a v_mfma_f32_32x32x2_f32 quad
+//     loads k = 8u+4h .. +3 of its row with ONE buffer_load_dwordx4 and feeds MFMA j with element j;
+//   * the filter is repacked per call as [K/4][N][4] (150 KB, one tiny kernel), so the B fragment of a lane (column li)
+//     is one coalesced 16-byte load as well.  (Reading the stored HWIO filter with four 4-byte loads per fragment
+//     instead — no repack, no workspace — was measured: 14 instead of 5 load instructions per 24 MFMAs cost 20 %,
+//     conv2d_0 96 -> 118 us, fine/first 163 -> 187 us.)
+// A wave owns TM x TN accumulator tiles of 32x32 (64 or 128 output pixels x 64 or 96 filters) and walks all of K; its
+// loads for chunk u+1 are in flight while chunk u's 4*TM*TN MFMAs issue.  Waves never meet: the input (26 MB at B = 32)
+// and the packed filter (<= 160 KB) live in L2, the XCD-aware block order keeps an XCD on one eighth of the images.
+// The generic implicit-GEMM kernel staged these layers through LDS with 4- and 8-byte loads and a per-lane tap decode:
+// matrix pipe 0.50-0.55 busy; this form has nothing but loads and MFMAs in its loop.
+//
+// Fused 2x2 / stride-2 max pool (the train step never writes the pre-pool activation): GEMM rows are enumerated pool
+// window by pool window (row = 4 * window + position), so the four conv outputs of a window are four accumulator
+// registers of one lane; only their maximum and (optionally) its position are stored — the contract of
+// a3d_conv2d_pool_fwd, same as the generic kernel's.
+#include <algorithm>
+
+#include "a3d_internal.h"
+#include "igemm.h"
+
+namespace a3d {
+
+struct Conv3Params {
+  const float* x; const float* wp; const float* bias; float* y; uint8_t* argmax;
+  unsigned long long x_bytes, wp_bytes;
+  int M;                 // GEMM rows: n*ho*wo, or 4 * n*(ho/2)*(wo/2) with the fused pool
+  int N, Np;             // filters, and the packed filter's column count (a multiple of 32*TN)
+  int Kp;                // padded K = multiple of 8 >= R * RLP
+  int Kreal;             // R * RLP: chunks beyond it (the K tail) load nothing
+  int RL, RLP;           // run length S*Cin and its padded length (multiple of 4)
+  int rowpitch;          // floats per image row = W * Cin
+  int imgpitch;          // floats per image = H * W * Cin
+  int step;              // floats between the runs of neighbouring output pixels = stride * Cin
+  int stride;
+  int ldc, act, pool, c16;
+  int m_tiles;           // wave tasks along M
+  FastDiv div_img, div_row;      // (pooled) pixels per image, per row
+  FastDiv div_rlp;
+};
+
+// filter [R][RL][N] (HWIO with s, c fused) -> [Kp/4][Np][4], zero where q >= RL, r >= R or n >= N
+__global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int R, int RL,
+                                                         int RLP, int N, int Np, int Kp) {
+  const int total = Kp * Np;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int j = i & 3, col = (i >> 2) % Np, k4 = (i >> 2) / Np;
+    const int k = 4 * k4 + j, r = k / RLP, q = k - r * RLP;
+    wp[i] = (r < R && q < RL && col < N) ? w[(size_t)(r * RL + q) * N + col] : 0.f;
+  }
+}
+
+template <int TM, int TN, bool POOL>
+__global__ __launch_bounds__(256, (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(const Conv3Params p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  // XCD-aware order: the blocks an XCD receives (ids congruent mod 8) work on one contiguous eighth of the tiles
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile = (int)bid * 4 + wave;               // wave task: tile_n fastest
+  const int tiles_n = p.Np / (32 * TN);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  if (tile_m >= p.m_tiles) return;
+  const int m0 = tile_m * (32 * TM), n0 = tile_n * (32 * TN);
+
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.x, p.x_bytes), rsB = make_rsrc(p.wp, p.wp_bytes);
+  // byte offset of each of this lane's rows' reference pixel
+  uint32_t a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int row = m0 + a * 32 + li;
+    uint32_t off = kOOB;
+    if (row < p.M) {
+      uint32_t pix, sub = 0;
+      if (POOL) { pix = (uint32_t)row >> 2; sub = (uint32_t)row & 3u; } else pix = (uint32_t)row;
+      const uint32_t img = fdiv(pix, p.div_img), rem = pix - img * p.div_img.d;
+      uint32_t oy = fdiv(rem, p.div_row), ox = rem - oy * p.div_row.d;
+      if (POOL) { oy = 2 * oy + (sub >> 1); ox = 2 * ox + (sub & 1u); }
+      off = (img * (uint32_t)p.imgpitch + oy * (uint32_t)(p.stride * p.rowpitch) + ox * (uint32_t)p.step) * 4u;
+    }
+    a_base[a] = off;
+  }
+  const uint32_t b_base = (uint32_t)((n0 + li) * 16);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+
+  const int nchunks = p.Kp / 8;
+  f32x4 af[2][TM], bf[2][TN];
+  auto fetch = [&](int u, int buf) {
+    const int k = 8 * u + 4 * lh;                     // this half's four k: one filter row (RLP % 4 == 0)
+    const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
+    const uint32_t koff = k < p.Kreal ? (r * (uint32_t)p.rowpitch + q) * 4u : kOOB;      // K tail: nothing to read
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const uint32_t off = (a_base[a] | koff) & kOOB ? kOOB : a_base[a] + koff;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0);
+      af[buf][a] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+    const uint32_t boff = (uint32_t)((2 * u + lh) * p.Np) * 16u + b_base;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(boff + (uint32_t)b * 512u), 0, 0);
+      bf[buf][b] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    }
+  };
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][a][j], bf[buf][b][j], acc[a][b], 0, 0, 0);
+  };
+  fetch(0, 0);
+  int u = 0;
+  for (; u + 2 <= nchunks; u += 2) {                  // two chunks per trip: the register double buffer is static
+    fetch(u + 1, 1);
+    multiply(0);
+    if (u + 2 < nchunks) fetch(u + 2, 0);
+    multiply(1);
+  }
+  if (u < nchunks) multiply(0);
+
+  // ---- epilogue: bias, activation, (max pool + argmax), store ----
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + b * 32 + li;
+      if (col >= p.N) continue;
+      const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = m0 + a * 32 + 8 * g + 4 * lh;       // the lane holds rows row .. row+3 of this column
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[a][b][4 * g + i] + bias;
+          if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
+          else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
+        }
+        if (POOL) {
+          if (row >= p.M) continue;
+          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+          float val = v[0];
+          int arg = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i)
+            if (v[i] > val) { val = v[i]; arg = i; }
+          const size_t o = (size_t)(row >> 2) * p.ldc + col;
+          if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)val;
+          else p.y[o] = val;
+          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (row + i >= p.M) continue;
+            const size_t o = (size_t)(row + i) * p.ldc + col;
+            if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)v[i];
+            else p.y[o] = v[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ----
+struct Conv3Shape {
+  int RL, RLP, Kreal, Kp, TN, Np;
+};
+static Conv3Shape conv3_shape(const a3d_conv_desc* d) {
+  Conv3Shape s;
+  s.RL = d->s * d->c;
+  s.RLP = (s.RL + 3) / 4 * 4;
+  s.Kreal = d->r * s.RLP;
+  s.Kp = (s.Kreal + 7) / 8 * 8;
+  s.TN = (d->k + 31) / 32 >= 3 ? 3 : 2;               // 96 filters: one 3-tile wave column; 63 / 64: two tiles
+  s.Np = (d->k + 32 * s.TN - 1) / (32 * s.TN) * (32 * s.TN);
+  return s;
+}
+
+bool conv3_applicable(const a3d_conv_desc* d, const void* x) {
+  static const bool off = getenv("A3D_NO_CONV3") && atoi(getenv("A3D_NO_CONV3")) != 0;
+  if (off) return false;
+  if (d->precision != A3D_PREC_F32 || d->c > 4 || d->pad_t || d->pad_l || d->ldx != d->c) return false;
+  if (d->storage & ~A3D_STORE_Y_BF16) return false;
+  if (d->k < 33) return false;                          // (one-output-channel layers have their own stencil kernel)
+  if (x && (reinterpret_cast<uintptr_t>(x) & 3)) return false;
+  if ((d->ho - 1) * d->stride + d->r > d->h || (d->wo - 1) * d->stride + d->s > d->w) return false;   // VALID geometry
+  if ((double)d->n * d->h * d->w * d->c * 4.0 >= 2147483647.0) return false;     // 31-bit byte offsets into the image
+  return true;
+}
+
+size_t conv3_ws_bytes(const a3d_conv_desc* d) {
+  const Conv3Shape s = conv3_shape(d);
+  return ((size_t)s.Kp * s.Np * 4 + 255) / 256 * 256;
+}
+
+template <int TM, int TN>
+static void conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, hipStream_t st) {
+  if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), 0, st, p);
+}
+
+int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
+              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st) {
+  const Conv3Shape s = conv3_shape(d);
+  if (!ws || ws_bytes < conv3_ws_bytes(d)) return set_error(A3D_EWORKSPACE, "conv3_fwd: need %zu workspace bytes", conv3_ws_bytes(d));
+  float* wp = static_cast<float*>(ws);
+  clear_stale_error();
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3(std::min((s.Kp * s.Np + 255) / 256, 1024)), dim3(256), 0, st, w, wp, d->r, s.RL,
+                     s.RLP, d->k, s.Np, s.Kp);
+  int rc = check_launch("conv3_pack");
+  if (rc != A3D_OK) return rc;
+  Conv3Params p{};
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.argmax = argmax;
+  p.x_bytes = (unsigned long long)d->n * d->h * d->w * d->c * 4ull;
+  p.wp_bytes = (unsigned long long)s.Kp * s.Np * 4ull;
+  const int ph = d->ho / 2, pw = d->wo / 2;
+  p.M = pool ? d->n * ph * pw * 4 : d->n * d->ho * d->wo;
+  p.N = d->k; p.Np = s.Np; p.Kp = s.Kp; p.Kreal = s.Kreal; p.RL = s.RL; p.RLP = s.RLP;
+  p.rowpitch = d->w * d->c; p.imgpitch = d->h * d->w * d->c; p.step = d->stride * d->c; p.stride = d->stride;
+  p.ldc = pool ? ld_out : d->ldy; p.act = act; p.pool = pool; p.c16 = (d->storage & A3D_STORE_Y_BF16) ? 1 : 0;
+  p.div_img = make_fastdiv(pool ? ph * pw : d->ho * d->wo);
+  p.div_row = make_fastdiv(pool ? pw : d->wo);
+  p.div_rlp = make_fastdiv(s.RLP);
+  const int tiles_n = s.Np / (32 * s.TN);
+  const int TM = 2;                                    // 64 output pixels (16 pool windows) per wave
+  p.m_tiles = (p.M + 32 * TM - 1) / (32 * TM);
+  const unsigned blocks = (unsigned)(((long)p.m_tiles * tiles_n + 3) / 4);
+  clear_stale_error();
+  if (s.TN == 3) conv3_launch<2, 3>(p, pool != 0, blocks, st);
+  else conv3_launch<2, 2>(p, pool != 0, blocks, st);
+  return check_launch("conv3_fwd");
+}
+
+
+}  // namespace a3d

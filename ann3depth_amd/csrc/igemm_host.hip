@@ -647,6 +647,7 @@ static size_t bf16_image_filter_bytes(const a3d_conv_desc* d);
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
+  if (conv3_applicable(d, nullptr)) return conv3_ws_bytes(d);
   size_t need = plan_gemm(fwd_problem(d), d->precision).ws_bytes;
   RunForm rf;
   if (run_form_ok(d, nullptr, &rf)) {
@@ -736,6 +737,8 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!pool && bf16_image_form_ok(d, x))
     return conv_fwd_bf16_image(d, x, w, bias, y, act, ws, ws_bytes, st);
+  if (conv3_applicable(d, x))                    // few-channel layers: operands straight from L2 (conv3.hip)
+    return conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
   GemmProblem g = fwd_problem(d);
   const int ph = d->ho / 2, pw = d->wo / 2;
   if (pool) {

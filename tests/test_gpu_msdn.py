@@ -235,32 +235,42 @@ def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, glob
 
 
 def test_msdn_learning_mode_tracks_the_oracles_adam_slots(models):
-    """beta2 = 0.999 (flagged non-reference mode), three steps on well-conditioned outputs (shifted_params): Adam's m and v
-    of every trained variable against the oracle's ApplyAdam — at 1e-5 after the first step (a pure function of the
-    gradient: a wrong beta, epsilon or bias-correction constant cannot hide), and the weight update itself; later steps
-    compound through alpha * m / sqrt(v), whose sign for a near-zero gradient element is decided by fp32 summation order,
-    so they are held to 1e-3 on the slots."""
+    """beta2 = 0.999 (flagged non-reference mode), three steps on well-conditioned outputs (shifted_params).
+    (1) The optimizer arithmetic, isolated from the forward: the oracle's ApplyAdam (oracle.tf13_ops.AdamTF1) is fed the
+        GPU's OWN gradient of each step; m, v and the weights must follow it at 1e-6 over all three steps — a wrong beta,
+        epsilon, learning rate or bias-correction power cannot hide (the old test accepted corr > 0.75 on the weights).
+    (2) The gradients themselves against the oracle's end-to-end step: 1e-5 for the dense layers at the first step; the
+        conv layers sit behind ReLU / max-pool decisions that a last-bit difference of the forward takes the other way
+        (3.9e-3 on conv2d_0's kernel at this size), and from the second step on alpha * m / sqrt(v) turns the sign of a
+        near-zero gradient element into a +-lr move of its weight, so those are held to 2e-2."""
+    from oracle.tf13_ops import AdamTF1
     B = 2
     params = shifted_params()
     net = models.MSDNReplica(B, params=params, beta2=0.999)
     tr = O.Trainer({k: v.copy() for k, v in params.items()}, B, beta2=0.999)
+    lrs = {'CoarseConv': 0.001, 'CoarseDense': 0.1}
+    twin = {g: AdamTF1(lr, 0.9, 0.999) for g, lr in lrs.items()}          # fed with the GPU's gradients
+    twin_p = {n: v.copy() for n, v in params.items()}
     for step in range(3):
         img, dep, keep = synth(B, 1000 + step, 96, 128)
         net.step(torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
         tr.step(img, dep, keep)
-        tol = 1e-5 if step == 0 else 1e-3
+        for gname, opt in twin.items():
+            names = [n for n in params if net.group_of[n] == gname]
+            opt.apply(twin_p, {n: net.grad(n).cpu().numpy() for n in names})
+            for n in names:
+                assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < 1e-6, (step, n, 'm')
+                assert rel(net.slot(n, 'v').cpu().numpy(), opt.v[n]) < 1e-6, (step, n, 'v')
+                upd, ref = net.var(n).cpu().numpy() - params[n], twin_p[n] - params[n]
+                assert rel(upd, ref) < 1e-5, (step, n, 'var')
+                assert np.abs(ref).max() > 0
         for n in params:
             if not n.startswith('coarse'):
+                np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])          # fine/* frozen in the coarse phase
                 continue
             opt = tr.opt[net.group_of[n]]
-            assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < tol, (step, n, 'm')
-            assert rel(net.slot(n, 'v').cpu().numpy(), opt.v[n]) < 2 * tol, (step, n, 'v')
-            if step == 0:
-                # var -= alpha * m / (sqrt(v) + eps): compare the UPDATE where the gradient is clear of the epsilon
-                upd, ref = net.var(n).cpu().numpy() - params[n], tr.p[n] - params[n]
-                big = np.abs(opt.m[n]) > 1e-6
-                assert big.mean() > 0.05, n         # (dense_0: dropout and ReLU leave most rows of dW at zero)
-                assert rel(upd[big], ref[big]) < 1e-4, n
+            tol = 1e-5 if (step == 0 and '/dense/' in n) else 2e-2
+            assert rel(net.slot(n, 'm').cpu().numpy(), opt.m[n]) < tol, (step, n, 'oracle m')
 
 
 @pytest.mark.parametrize('prec,tol', [('bf16x3', 1e-4), ('bf16', 5e-2)])

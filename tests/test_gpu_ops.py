@@ -52,6 +52,11 @@ CONV_CASES = [
     (32, 13, 18, 384, 256, 3, 2, 'VALID'),   # conv2d_4 at batch 32: the four bwd-data parity classes as ONE launch
     (20, 31, 33, 64, 48, 3, 2, 'SAME'),      # the same single-launch path with odd sizes, SAME padding, unequal classes
     (24, 26, 30, 5, 7, 5, 2, 'SAME'),        # ... and with scalar operands (Cin, Cout not multiples of 4), 5x5 taps
+    # few-channel forward straight from L2 (conv3.hip): run starts 12 / 4 / 32 bytes apart, K tails, Cout off the tile width
+    (2, 30, 35, 3, 64, 11, 1, 'VALID'),      # DCNF's first conv kind (stride 1: runs start 12 bytes apart)
+    (3, 23, 29, 1, 40, 5, 1, 'VALID'),       # one channel: runs start 4 bytes apart, run of 5 -> 8 floats
+    (2, 20, 27, 4, 70, 3, 2, 'VALID'),       # four channels, 70 filters (three column tiles, 26 of 96 columns idle)
+    (65, 15, 15, 2, 33, 7, 4, 'VALID'),      # 65 images of 3 x 3 outputs: row tiles crossing images, M tail
 ]
 
 
@@ -529,6 +534,8 @@ def test_tensorflow_published_vectors_through_the_c_abi(ops):
     (4, 27, 37, 96, 256, 5, 1, 'SAME'),       # conv2d_1: 27x37 -> 13x18, odd row and column dropped
     (1, 9, 8, 5, 7, 3, 1, 'SAME'),            # scalar operands, tiny
     (2, 2, 2, 4, 4, 1, 1, 'VALID'),           # exactly one window per image
+    (3, 33, 31, 3, 64, 11, 1, 'VALID'),       # DCNF's first conv kind (conv3.hip, stride 1): 23x21 -> 11x10, odd row and column
+    (2, 21, 18, 1, 40, 4, 1, 'VALID'),        # one channel, 40 filters
 ])
 def test_conv2d_pool_fwd_equals_conv_then_pool(ops, n, h, w, c, k, ks, st, pad):
     """The fused conv + ReLU + 2x2 max pool writes what conv2d_fwd followed by maxpool2x2_fwd writes (to fp32 summation
@@ -562,7 +569,8 @@ def test_conv2d_pool_fwd_equals_conv_then_pool(ops, n, h, w, c, k, ks, st, pad):
 
 
 @pytest.mark.parametrize('n,h,w,c,k,ks,st,pad,ld', [(3, 40, 52, 3, 63, 9, 2, 'VALID', 64), (2, 27, 37, 96, 256, 5, 1, 'SAME', 256),
-                                                   (1, 9, 8, 5, 7, 3, 1, 'SAME', 7), (2, 35, 48, 3, 96, 11, 4, 'VALID', 96)])
+                                                   (1, 9, 8, 5, 7, 3, 1, 'SAME', 7), (2, 35, 48, 3, 96, 11, 4, 'VALID', 96),
+                                                   (3, 33, 31, 3, 64, 11, 1, 'VALID', 64)])
 def test_maxpool_bwd_from_recorded_argmax(ops, n, h, w, c, k, ks, st, pad, ld):
     """conv2d_pool_fwd's argmax bytes + pooled values give maxpool2x2_bwd_idx everything MaxPoolGrad + ReluGrad need:
     same dx as the unfused conv -> pool -> maxpool2x2_bwd path (odd last row / column zero), and as the oracle."""
