@@ -130,8 +130,28 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   return plan;
 }
 
+// Measured winners for shapes where the cost model below loses more than 3 % to a configuration of the sweep
+// (tools/sweep_hot.py --assert-auto-within 0.03; profiles/r03_sweep_hot.txt).  The model's block-slot count is that of
+// the 8-wave tiles (two per CU); 4-wave 64x64 blocks sit four to a CU and want several thousand blocks when a handful
+// of tiles carry a K of 10^5 — fine/second's bwd-filter: 64x64 x 128 splits 290 us, the model's pick 315-363 us.
+struct TunedPlan { int mode, M, N, K, cfg, splitk; };
+static const TunedPlan kTuned[] = {
+    {MODE_BWD_F, 1600, 64, 130240, 4, 128},        // fine/second/conv2d bwd-filter at batch 32
+};
+
 static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
   if (precision != A3D_PREC_F32 && g.avec == 4 && g.bvec == 4) return plan_gemm_bf16(g, precision);
+  if (tune_int("A3D_FORCE_CFG", -1) < 0 && !g.plain) {
+    for (const TunedPlan& t : kTuned) {
+      if (t.mode != g.mode || t.M != g.M || t.N != g.N || t.K != g.K) continue;
+      GemmPlan pl{};
+      const int nk = std::max(1, (g.K + 31) / 32), kps = (nk + t.splitk - 1) / t.splitk;
+      pl.cfg = t.cfg; pl.ktiles_per_split = kps; pl.splitk = (nk + kps - 1) / kps;
+      pl.tiles_m = (g.M + kCfgs[t.cfg].bm - 1) / kCfgs[t.cfg].bm; pl.tiles_n = (g.N + kCfgs[t.cfg].bn - 1) / kCfgs[t.cfg].bn;
+      pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * g.M * g.N * 4 : 0;
+      if (pl.ws_bytes <= kMaxSlabBytes) return pl;
+    }
+  }
   GemmPlan best{};
   double best_t = 1e300;
   const int nk = std::max(1, (g.K + 31) / 32);
@@ -220,7 +240,9 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
         double t = (double)bm * bn * per * 32.0 / (96.5e3 * kCfgs[c].eff) * (grid <= 256 ? 0.62 : 1.0);
         // ~1.5 slabs per block are written and read back, then the split tiles are written once more
         const double slabs = std::min<double>(1.5 * grid, 2.0 * tiles) * bm * bn * 4.0;
-        t += 3.0 + 0.4 * meet + (2.0 * slabs + (double)std::min<long>(tiles, grid) * bm * bn * 4.0) / 3.0e6;
+        // (round 3 refit: 4.5 TB/s for the slab traffic — the fixup reads eight slabs deep; at 3 TB/s the model preferred
+        // split-K 2 for conv2d_1's bwd-data, measured 349 us against 334 for stream-K: profiles/r03_sweep_hot.txt)
+        t += 3.0 + 0.4 * meet + (2.0 * slabs + (double)std::min<long>(tiles, grid) * bm * bn * 4.0) / 4.5e6;
         if (force_streamk > 0) t = 0;
         if (t < best_t) {
           best_t = t;

@@ -1,4 +1,7 @@
-"""Compact re-fit sweep: hot MSDN layers x direction x {tile config} x a few split / stream-K choices."""
+"""Compact re-fit sweep: hot MSDN layers x direction x {tile config} x a few split / stream-K choices.
+    python tools/sweep_hot.py [layers ...] [--assert-auto-within 0.03]
+With --assert-auto-within X the exit code is 1 when the planner's own choice is more than X slower than the best forced
+configuration of any (layer, direction) listed: the regression check of plan_gemm's cost model."""
 import os, sys, json
 os.environ['A3D_TUNING'] = '1'   # the library reads its A3D_FORCE_* switches per launch only then
 import torch
@@ -6,7 +9,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ann3depth_amd import ops
 from tools.sweep_igemm import LAYERS, CFGS, timeit
 B = 32
-only = sys.argv[1:] or ['conv2d_1', 'conv2d_2', 'conv2d_3', 'conv2d_4', 'fine2', 'conv2d_0', 'fine1']
+args = sys.argv[1:]
+within = None
+if '--assert-auto-within' in args:
+    i = args.index('--assert-auto-within')
+    within = float(args[i + 1])
+    del args[i:i + 2]
+only = args or ['conv2d_1', 'conv2d_2', 'conv2d_3', 'conv2d_4', 'fine2', 'conv2d_0', 'fine1']
+losers = []
+# the clocks ramp during the first launches of a process: warm the chip before the first `auto` is timed
+_w = torch.randn((4096, 4096), device='cuda')
+for _ in range(50):
+    _w @ _w
+torch.cuda.synchronize()
 def clear():
     for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK'):
         os.environ.pop(v, None)
@@ -34,5 +49,12 @@ for name, h, w, c, k, ks, st, pad in LAYERS:
                     except Exception: continue
                     res.append((t, CFGS[ci], kind + str(v)))
         res.sort()
+        clear(); t_auto = min(t_auto, timeit(fn))       # auto again, after the forced runs: the better of the two
+        if within is not None and res and t_auto > res[0][0] * (1 + within):
+            losers.append((name, mode, t_auto, res[0]))
         print(f'{name:9s} {mode:6s} auto {t_auto:7.1f}us {flops / t_auto / 1e6:5.0f}TF || ' + ' | '.join(f'{cn} {kv} {t:.0f}' for t, cn, kv in res[:7]), flush=True)
 clear()
+if within is not None:
+    for name, mode, t, best in losers:
+        print(f'PLANNER LOSES {name} {mode}: auto {t:.0f} us vs {best[1]} {best[2]} {best[0]:.0f} us')
+    sys.exit(1 if losers else 0)
