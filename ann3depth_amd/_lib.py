@@ -54,6 +54,8 @@ SIGNATURES = {
     'a3d_maxpool2x2_bwd': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P]),
     'a3d_resize_bilinear_tf1': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     'a3d_resize_bilinear_tf1_pair': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, _P, _P]),
+    'a3d_resize_bilinear_tf1_ex': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int,
+                                           _P, _P]),
     'a3d_extract_patches': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, _P]),
     'a3d_silog_loss_fwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),
     'a3d_silog_loss_bwd': (c_int, [c_int, c_int, _P, _P, _P, _P, _P]),
@@ -90,6 +92,11 @@ SIGNATURES = {
     'a3d_example_parse': (c_int, [_P, c_size_t, POINTER(ExampleView)]),
     'a3d_decode_raw_plus_half': (c_int, [_P, c_size_t, _P]),
     'a3d_record_decode': (c_int, [_P, c_size_t, c_int, _P, c_size_t, _P, c_size_t, POINTER(ExampleView)]),
+    'a3d_record_decode_u8': (c_int, [_P, c_size_t, c_int, _P, _P, c_size_t, _P, _P, c_size_t, POINTER(ExampleView),
+                                     POINTER(c_int)]),
+    'a3d_records_decode': (c_int, [POINTER(c_void_p), POINTER(c_size_t), c_int, c_int, POINTER(c_int64), _P, _P, _P, _P,
+                                   POINTER(c_int32), POINTER(c_int32)]),
+    'a3d_h2d_gather': (c_int, [_P, _P, POINTER(c_int32), c_int, c_size_t, _P]),
     'a3d_example_write': (c_int64, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_size_t]),
 }
 

@@ -759,8 +759,31 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!pool && bf16_image_form_ok(d, x))
     return conv_fwd_bf16_image(d, x, w, bias, y, act, ws, ws_bytes, st);
-  if (conv3_applicable(d, x))                    // few-channel layers: operands straight from L2 (conv3.hip)
-    return conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+  if (conv3_applicable(d, x)) {                  // few-channel layers: operands straight from L2 (conv3.hip)
+    TimingSlot slot{};
+    bool timed = false;
+    {
+      std::lock_guard<std::mutex> lk(g_timing_mu);
+      timed = g_timing_on;
+    }
+    if (timed) {
+      if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
+        return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
+      (void)hipEventRecord(slot.start, st);
+    }
+    rc = conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+    if (timed) {
+      (void)hipEventRecord(slot.stop, st);
+      a3d_timing_record& r = slot.rec;
+      r.mode = MODE_FWD; r.prec = A3D_PREC_F32; r.bm = 64; r.bn = d->k > 64 ? 96 : 64; r.waves_m = 1; r.nwaves = 1; r.bk = 8;
+      r.avec = 4; r.bvec = 4; r.splitk = 1; r.lds_dma = 2;          // 2: conv3_fwd_kernel (filter repack included in ms)
+      r.m = pool ? d->n * (d->ho / 2) * (d->wo / 2) * 4 : d->n * d->ho * d->wo; r.n = d->k; r.k = d->r * d->s * d->c; r.ms = 0.f;
+      r.flops = 2.0 * r.m * r.n * r.k;
+      std::lock_guard<std::mutex> lk(g_timing_mu);
+      g_timing.push_back(slot);
+    }
+    return rc;
+  }
   GemmProblem g = fwd_problem(d);
   const int ph = d->ho / 2, pw = d->wo / 2;
   if (pool) {

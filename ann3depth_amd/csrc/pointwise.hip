@@ -257,31 +257,49 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const __bf16* __r
 // One block per output row of one tensor (blockIdx.y selects the tensor of a pair: the step resizes the image and its
 // depth map, src/models.py:282-283, in ONE launch): the row's source lines and vertical weight are scalars, a thread walks
 // the row's (pixel, channel) elements with 32-bit arithmetic.  Same separate fp32 operations as before: bit-exact.
-struct ResizeOne { const float* x; float* y; int h, w, c, oh, ow; float sy, sx; };
+struct ResizeOne { const float* x; float* y; int h, w, c, oh, ow; float sy, sx; int u8; };
 struct ResizePair { ResizeOne t[2]; int n; };
-__global__ __launch_bounds__(256) void resize_kernel(const ResizePair p) {
-  const ResizeOne& r = p.t[blockIdx.y];
-  const int rows = p.n * r.oh;
+template <typename SRC>
+__device__ __forceinline__ void resize_rows(const ResizeOne& r, int n, const float* lut) {
+  const int rows = n * r.oh;
+  const SRC* src = reinterpret_cast<const SRC*>(r.x);
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const int b = row / r.oh, oy = row - b * r.oh;
     const float fy = __fmul_rn((float)oy, r.sy);
     const int y0 = (int)fy, y1 = min(y0 + 1, r.h - 1);
     const float ly = __fsub_rn(fy, (float)y0);
-    const float* l0 = r.x + ((size_t)b * r.h + y0) * r.w * r.c;
-    const float* l1 = r.x + ((size_t)b * r.h + y1) * r.w * r.c;
+    const SRC* l0 = src + ((size_t)b * r.h + y0) * r.w * r.c;
+    const SRC* l1 = src + ((size_t)b * r.h + y1) * r.w * r.c;
     float* out = r.y + (size_t)row * r.ow * r.c;
     const int ne = r.ow * r.c;
+    auto tap = [&](const SRC* line, int i) -> float {
+      if constexpr (sizeof(SRC) == 1) return lut[line[i]];
+      else return line[i];
+    };
     for (int e = threadIdx.x; e < ne; e += 256) {
       const int ox = e / r.c, ch = e - ox * r.c;
       const float fx = __fmul_rn((float)ox, r.sx);
       const int x0 = (int)fx, x1 = min(x0 + 1, r.w - 1);
       const float lx = __fsub_rn(fx, (float)x0);
-      const float tl = l0[x0 * r.c + ch], tr = l0[x1 * r.c + ch];
-      const float bl = l1[x0 * r.c + ch], br = l1[x1 * r.c + ch];
+      const float tl = tap(l0, x0 * r.c + ch), tr = tap(l0, x1 * r.c + ch);
+      const float bl = tap(l1, x0 * r.c + ch), br = tap(l1, x1 * r.c + ch);
       const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), lx));
       const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), lx));
       out[e] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ly));
     }
+  }
+}
+__global__ __launch_bounds__(256) void resize_kernel(const ResizePair p) {
+  const ResizeOne& r = p.t[blockIdx.y];
+  if (r.u8) {
+    // pixel value k -> the float the converter stored, plus the loader's 0.5: fl(fl(fl(k / 255) - 0.5) + 0.5), in the
+    // separate correctly-rounded fp32 operations numpy performed (tools/data_tf_converter.py:36-37, src/data.py:84-85)
+    __shared__ float lut[256];
+    lut[threadIdx.x] = __fadd_rn(__fsub_rn(__fdiv_rn((float)threadIdx.x, 255.f), 0.5f), 0.5f);
+    __syncthreads();
+    resize_rows<uint8_t>(r, p.n, lut);
+  } else {
+    resize_rows<float>(r, p.n, nullptr);
   }
 }
 
@@ -665,8 +683,9 @@ int a3d_maxpool2x2_bwd_bf16(int n, int h, int w, int c, const void* x, int ldx, 
   return check_launch("maxpool_bwd_bf16");
 }
 
-static ResizeOne resize_one(int h, int w, int c, const float* x, int oh, int ow, float* y) {
+static ResizeOne resize_one(int h, int w, int c, const float* x, int oh, int ow, float* y, int u8 = 0) {
   ResizeOne r;
+  r.u8 = u8;
   r.x = x; r.y = y; r.h = h; r.w = w; r.c = c; r.oh = oh; r.ow = ow;
   r.sy = (float)h / (float)oh; r.sx = (float)w / (float)ow;
   return r;
@@ -694,6 +713,20 @@ int a3d_resize_bilinear_tf1_pair(int n, int h, int w, int c0, const float* x0, i
   hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min(n * std::max(oh0, oh1), 16384), 2), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return check_launch("resize_pair");
+}
+
+int a3d_resize_bilinear_tf1_ex(int n, int h, int w, int c0, const void* x0, int u8_0, int oh0, int ow0, float* y0, int c1,
+                               const void* x1, int u8_1, int oh1, int ow1, float* y1, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h > 0 && w > 0 && c0 > 0 && oh0 > 0 && ow0 > 0 && x0 && y0, "resize_ex: bad arguments");
+  A3D_CHECK_ARG(!x1 || (c1 > 0 && oh1 > 0 && ow1 > 0 && y1), "resize_ex: bad second tensor");
+  ResizePair p;
+  p.n = n;
+  p.t[0] = resize_one(h, w, c0, static_cast<const float*>(x0), oh0, ow0, y0, u8_0 ? 1 : 0);
+  p.t[1] = x1 ? resize_one(h, w, c1, static_cast<const float*>(x1), oh1, ow1, y1, u8_1 ? 1 : 0) : p.t[0];
+  clear_stale_error();
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)std::min(n * std::max(oh0, x1 ? oh1 : oh0), 16384), x1 ? 2 : 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch("resize_ex");
 }
 
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream) {

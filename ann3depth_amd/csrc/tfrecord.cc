@@ -4,6 +4,9 @@
 #include <algorithm>
 #include <cstring>
 #include <initializer_list>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "a3d_internal.h"
 
@@ -342,6 +345,162 @@ int a3d_record_decode(const uint8_t* frame, size_t len, int verify_crc, float* i
     uint32_t want;
     memcpy(&want, payload + plen, 4);
     if (mask_crc(crc) != want) return a3d::set_error(A3D_EFORMAT, "tfrecord: corrupt payload");
+  }
+  return A3D_OK;
+}
+
+// The converter writes png_u8 / 255 - 0.5 in float32 (tools/data_tf_converter.py:36-37 of the reference), so a record's
+// floats are normally 256 distinct values.  quantise() recovers k and checks, bit for bit, that the float IS
+// fl(fl(k / 255) - 0.5): returns false at the first float that is not (the caller then decodes the feature as float32).
+#if defined(__x86_64__)
+// eight floats per round on AVX2 (the scalar loop below costs a reader thread more than the record's CRC)
+__attribute__((target("avx2"))) static size_t quantise_avx2(const uint8_t* src, size_t n, uint8_t* dst, bool* ok) {
+  const __m256 half = _mm256_set1_ps(0.5f), scale = _mm256_set1_ps(255.0f), zero = _mm256_setzero_ps(),
+               top = _mm256_set1_ps(256.0f);
+  __m256 bad = _mm256_setzero_ps();
+  size_t i = 0;
+  for (; i + 16 <= n; i += 16) {
+    __m256i k[2];
+    for (int h = 0; h < 2; ++h) {
+      const __m256 v = _mm256_loadu_ps(reinterpret_cast<const float*>(src + 4 * (i + 8 * h)));
+      const __m256 kf = _mm256_add_ps(_mm256_mul_ps(_mm256_add_ps(v, half), scale), half);
+      const __m256 in = _mm256_and_ps(_mm256_cmp_ps(kf, zero, _CMP_GE_OQ), _mm256_cmp_ps(kf, top, _CMP_LT_OQ));
+      k[h] = _mm256_cvttps_epi32(_mm256_and_ps(kf, in));
+      const __m256 back = _mm256_sub_ps(_mm256_div_ps(_mm256_cvtepi32_ps(k[h]), scale), half);
+      bad = _mm256_or_ps(bad, _mm256_or_ps(_mm256_cmp_ps(back, v, _CMP_NEQ_UQ), _mm256_cmp_ps(in, zero, _CMP_EQ_OQ)));
+    }
+    // 16 x int32 -> 16 x uint8 in order
+    const __m256i p16 = _mm256_permute4x64_epi64(_mm256_packus_epi32(k[0], k[1]), 0xD8);
+    const __m128i p8 = _mm_packus_epi16(_mm256_castsi256_si128(p16), _mm256_extracti128_si256(p16, 1));
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), p8);
+  }
+  *ok = _mm256_movemask_ps(bad) == 0;
+  return i;
+}
+#endif
+
+static bool quantise(const uint8_t* src, size_t n, uint8_t* dst) {
+  uint32_t bad = 0;
+  size_t i = 0;
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) {
+    bool ok = true;
+    i = quantise_avx2(src, n, dst, &ok);
+    if (!ok) return false;
+  }
+#endif
+  for (; i < n; ++i) {
+    float v;
+    memcpy(&v, src + 4 * i, 4);
+    const float kf = (v + 0.5f) * 255.0f + 0.5f;               // in [0.5, 255.5] when representable; NaN fails `in`
+    const bool in = kf >= 0.f && kf < 256.f;
+    const int k = (int)(in ? kf : 0.f);
+    const float back = (float)k / 255.0f - 0.5f;
+    bad |= (uint32_t)(!(back == v)) | (uint32_t)(!in);
+    dst[i] = (uint8_t)k;
+  }
+  return bad == 0;
+}
+
+// a3d_record_decode that ships a feature as uint8 when every one of its floats has the converter's form k/255 - 0.5
+// (4x fewer bytes to pin, to DMA and to read back on the device, where a3d_resize_bilinear_tf1_ex rebuilds
+// fl(fl(fl(k/255) - 0.5) + 0.5) — the value a3d_record_decode would have stored — bit for bit).  A feature that holds
+// any other float is decoded as float32 + 0.5 exactly like a3d_record_decode.  *kinds: bit 0 = image went to image_u8,
+// bit 1 = depth went to depth_u8; the other destination of a feature is left untouched.
+int a3d_record_decode_u8(const uint8_t* frame, size_t len, int verify_crc, uint8_t* image_u8, float* image_f32,
+                         size_t image_count, uint8_t* depth_u8, float* depth_f32, size_t depth_count,
+                         a3d_example_view* view, int* kinds) {
+  if (!kinds || !image_u8 || !image_f32 || !depth_u8 || !depth_f32)
+    return a3d::set_error(A3D_EINVAL, "record_decode_u8: null argument");
+  size_t off, plen, used;
+  int rc = a3d_tfrecord_next(frame, len, 0, &off, &plen, &used);
+  if (rc != A3D_OK) return rc;
+  const uint8_t* payload = frame + off;
+  a3d_example_view ev;
+  rc = a3d_example_parse(payload, plen, &ev);
+  if (rc != A3D_OK) return rc;
+  if (ev.image_bytes != image_count * 4 || ev.depth_bytes != depth_count * 4)
+    return a3d::set_error(A3D_EINVAL, "record_decode_u8: record holds %zu / %zu feature bytes, destination %zu / %zu floats",
+                          ev.image_bytes, ev.depth_bytes, image_count, depth_count);
+  if (view) *view = ev;
+  static const bool hw = have_sse42();
+  struct Seg { const uint8_t* p; size_t n; uint8_t* q; float* f; int bit; };
+  const bool image_first = ev.image < ev.depth;
+  const Seg img{ev.image, ev.image_bytes, image_u8, image_f32, 1}, dep{ev.depth, ev.depth_bytes, depth_u8, depth_f32, 2};
+  const Seg first = image_first ? img : dep, second = image_first ? dep : img;
+  const uint8_t* cursor = payload;
+  uint32_t crc = 0;
+  auto crc_range = [&](const uint8_t* p, size_t n) {
+    if (verify_crc && n) crc = hw ? crc32c_hw(p, n, crc) : crc32c_sw(p, n, crc);
+  };
+  *kinds = 0;
+  for (const Seg& s : {first, second}) {
+    crc_range(cursor, (size_t)(s.p - cursor));
+    bool as_u8 = true;
+    for (size_t done = 0; done < s.n;) {                     // 72 KB blocks: CRC a block, then convert it while it is in cache
+      const size_t blk = std::min<size_t>(s.n - done, 73728);
+      crc_range(s.p + done, blk);
+      if (as_u8 && !quantise(s.p + done, blk / 4, s.q + done / 4)) {
+        as_u8 = false;                                        // not the converter's floats: this feature goes out as float32
+        for (size_t i = 0; i < done / 4; ++i) {               // (what was already quantised is decoded again)
+          float v;
+          memcpy(&v, s.p + 4 * i, 4);
+          s.f[i] = v + 0.5f;
+        }
+      }
+      if (!as_u8) {
+        float* d = s.f + done / 4;
+        for (size_t i = 0; i < blk / 4; ++i) {
+          float v;
+          memcpy(&v, s.p + done + 4 * i, 4);
+          d[i] = v + 0.5f;
+        }
+      }
+      done += blk;
+    }
+    if (as_u8) *kinds |= s.bit;
+    cursor = s.p + s.n;
+  }
+  crc_range(cursor, (size_t)(payload + plen - cursor));
+  if (verify_crc) {
+    uint32_t want;
+    memcpy(&want, payload + plen, 4);
+    if (mask_crc(crc) != want) return a3d::set_error(A3D_EFORMAT, "tfrecord: corrupt payload");
+  }
+  return A3D_OK;
+}
+
+// A reader thread's unit of work: n framed records into n slots of the staging pool in ONE call (the thread holds the
+// host language's interpreter lock only between calls: with one record per call sixteen readers took it from the thread
+// that launches the training step often enough to cost 10 % of the loop, tools/bench_input.py).  u8 pools NULL: plain
+// float32 decode (a3d_record_decode); otherwise a3d_record_decode_u8, kinds[i] as there.  Every record must have the
+// sizes dims = {image h, w, c, depth h, w, c}: records of different sizes cannot share a batch.
+int a3d_records_decode(const void* const* frames, const size_t* lens, int n, int verify_crc, const int64_t* dims,
+                       uint8_t* image_u8_pool, float* image_f32_pool, uint8_t* depth_u8_pool, float* depth_f32_pool,
+                       const int32_t* slots, int32_t* kinds) {
+  if (!frames || !lens || !dims || !image_f32_pool || !depth_f32_pool || !slots || !kinds || n <= 0)
+    return a3d::set_error(A3D_EINVAL, "records_decode: bad arguments");
+  const size_t ic = (size_t)(dims[0] * dims[1] * dims[2]), dc = (size_t)(dims[3] * dims[4] * dims[5]);
+  for (int i = 0; i < n; ++i) {
+    const size_t s = (size_t)slots[i];
+    a3d_example_view ev;
+    int k = 0, rc;
+    if (image_u8_pool && depth_u8_pool)
+      rc = a3d_record_decode_u8(static_cast<const uint8_t*>(frames[i]), lens[i], verify_crc, image_u8_pool + s * ic,
+                                image_f32_pool + s * ic, ic, depth_u8_pool + s * dc, depth_f32_pool + s * dc, dc, &ev, &k);
+    else
+      rc = a3d_record_decode(static_cast<const uint8_t*>(frames[i]), lens[i], verify_crc, image_f32_pool + s * ic, ic,
+                             depth_f32_pool + s * dc, dc, &ev);
+    if (rc != A3D_OK) return rc;
+    if (ev.image_height != dims[0] || ev.image_width != dims[1] || ev.image_channels != dims[2] || ev.depth_height != dims[3] ||
+        ev.depth_width != dims[4] || ev.depth_channels != dims[5])
+      return a3d::set_error(A3D_EINVAL, "records_decode: record is %lldx%lldx%lld / %lldx%lldx%lld, the pool holds %lldx%lldx%lld / "
+                            "%lldx%lldx%lld: records of different sizes cannot be batched", (long long)ev.image_height,
+                            (long long)ev.image_width, (long long)ev.image_channels, (long long)ev.depth_height,
+                            (long long)ev.depth_width, (long long)ev.depth_channels, (long long)dims[0], (long long)dims[1],
+                            (long long)dims[2], (long long)dims[3], (long long)dims[4], (long long)dims[5]);
+    kinds[i] = k;
   }
   return A3D_OK;
 }

@@ -9,14 +9,20 @@ file: CRC check, protobuf parse and ``decode_raw + 0.5`` happen in liba3d.so (GI
 into a slot of a staging pool; the shuffle queue holds slot numbers, so a record is copied exactly once on the host
 (into pinned memory when a GPU consumer asks for it) and then DMA'd to HBM.  With world_size > 1 each rank reads the
 records whose index is congruent to its rank.
+
+Records written by the converter hold png_u8 / 255 - 0.5 (tools/data_tf_converter.py:36-37): a feature whose floats all
+have that form — checked bit for bit while the record is decoded — is staged as the uint8 pixel values instead (a quarter
+of the bytes through pinned memory and the host link), and the consumer rebuilds exactly the float32 the loader's `+ 0.5`
+(src/data.py:84-85) would have produced: `expand_u8` on the host, the resize kernel's table on the device.
 """
 import collections
+import ctypes
 import os
 import threading
 
 import numpy as np
 
-from . import tfrecord
+from . import _lib, tfrecord
 
 Pipeline = collections.namedtuple('Pipeline', ('files', 'labels', 'reader', 'convert'))
 
@@ -61,9 +67,19 @@ def _get_pipeline(dataset):
 
 
 def default_reader_threads():
-    """The reference uses num_threads=2 (src/data.py:55), enough for a 2017 GPU; an MI355X eats ~8k records/s."""
+    """The reference uses num_threads=2 (src/data.py:55), enough for a 2017 GPU; an MI355X eats ~10.6 k records/s.
+    Twelve threads decode 16-18 k records/s on the GPU box (tools/bench_input.py, profiles/r03_input_pipeline.json), each
+    taking RECORDS_PER_CALL records per call into liba3d.so so that the interpreter lock stays with the thread that
+    launches the step (one record per call and sixteen threads: 9.1 k images/s through the loop instead of 10.3 k)."""
     env = os.environ.get('A3D_READER_THREADS')
-    return int(env) if env else max(2, min(16, (os.cpu_count() or 2) // 2))
+    return int(env) if env else max(2, min(12, (os.cpu_count() or 2) // 2))
+
+
+def expand_u8(k):
+    """uint8 pixel values -> the float32 the reference's loader hands to the model: fl(fl(fl(k / 255) - 0.5) + 0.5), in
+    numpy's float32 operations (converter: `.astype(np.float32) / 255. - .5`; loader: `+ 0.5`)."""
+    lut = (np.arange(256, dtype=np.float32) / np.float32(255.) - np.float32(.5)) + np.float32(.5)
+    return lut[np.asarray(k)]
 
 
 class ShuffleBatch:
@@ -81,6 +97,8 @@ class ShuffleBatch:
         self.queue = []                       # filled slot numbers
         self.free = None                      # free slot numbers (after allocate())
         self.images = self.depths = None
+        self.images_u8 = self.depths_u8 = None    # uint8 twins of the pool (allocate(..., alloc_u8)): converter-written records
+        self.kind = None                          # per slot: bit 0 image is in images_u8, bit 1 depth is in depths_u8
         self.cv = threading.Condition()
         self.src_lock = threading.Lock()
         self.live = num_threads
@@ -103,41 +121,89 @@ class ShuffleBatch:
         _, ishape, dshape = rf.header(off, ln)
         return ishape, dshape
 
-    def allocate(self, alloc=None):
+    def allocate(self, alloc=None, alloc_u8=None):
         """Create the slot pool.  alloc(shape) -> float32 ndarray; default plain numpy, a GPU consumer passes an
-        allocator of pinned memory."""
+        allocator of pinned memory.  alloc_u8(shape) -> uint8 ndarray turns on the uint8 staging of converter-written
+        records (module docstring); a slot then holds each feature in ONE of its two arrays, see `kind`."""
         if self.images is not None:
             return
         ishape, dshape = self.shapes()
         alloc = alloc or (lambda shape: np.empty(shape, np.float32))
         self.images = alloc((self.nslots,) + tuple(ishape))
         self.depths = alloc((self.nslots,) + tuple(dshape))
+        if alloc_u8 is not None and self.convert is _convert_img_depth and os.environ.get('A3D_NO_U8_RECORDS', '0') != '1':
+            self.images_u8 = alloc_u8((self.nslots,) + tuple(ishape))
+            self.depths_u8 = alloc_u8((self.nslots,) + tuple(dshape))
+        self.kind = np.zeros(self.nslots, np.uint8)
         self.free = collections.deque(range(self.nslots))
 
-    def _next_record(self):
-        with self.src_lock:                    # the reader op is shared: each record goes to exactly one thread
+    def materialise(self, slot, which):
+        """Make sure feature `which` (0 image, 1 depth) of a slot exists as float32 (a batch that mixes uint8-staged and
+        float32 records goes to the device as float32); returns the float32 array of the slot."""
+        f32, u8 = (self.images, self.images_u8) if which == 0 else (self.depths, self.depths_u8)
+        if self.kind[slot] & (1 << which):
+            f32[slot] = expand_u8(u8[slot])
+            self.kind[slot] &= ~(1 << which) & 0xff
+        return f32[slot]
+
+    RECORDS_PER_CALL = 4      # a reader thread decodes this many records per call into liba3d.so (one lock round trip each)
+
+    def _next_records(self, want):
+        """Up to `want` records (at least one, or StopIteration): each record goes to exactly one thread."""
+        with self.src_lock:                    # the reader op is shared
+            recs = []
             if self.first is not None:
-                rec, self.first = self.first, None
-                return rec
-            return next(self.records)
+                recs.append(self.first)
+                self.first = None
+            while len(recs) < want:
+                try:
+                    recs.append(next(self.records))
+                except StopIteration:
+                    if not recs:
+                        raise
+                    break
+            return recs
+
+    def _decode(self, recs, slots):
+        """Records -> slots, in one call into the library when the pipeline's converter is the default one."""
+        if self.convert is not _convert_img_depth:
+            for (rf, off, ln), slot in zip(recs, slots):
+                self.convert(rf, off, ln, self.images[slot], self.depths[slot])
+            return
+        n = len(recs)
+        frames = (ctypes.c_void_p * n)(*[rf.base + off - 12 for rf, off, _ in recs])
+        lens = (ctypes.c_size_t * n)(*[ln + 16 for _, _, ln in recs])
+        ids = (ctypes.c_int32 * n)(*slots)
+        kinds = (ctypes.c_int32 * n)()
+        dims = (ctypes.c_int64 * 6)(*(tuple(self.images.shape[1:]) + tuple(self.depths.shape[1:])))
+        u8 = self.images_u8 is not None
+        _lib.check(_lib.load().a3d_records_decode(frames, lens, n, 1, dims, self.images_u8.ctypes.data if u8 else None,
+                                                  self.images.ctypes.data, self.depths_u8.ctypes.data if u8 else None,
+                                                  self.depths.ctypes.data, ids, kinds),
+                   f'a3d_records_decode({recs[0][0].path}@{recs[0][1]})')
+        for slot, k in zip(slots, kinds):
+            self.kind[slot] = k
 
     def _produce(self):
         try:
             while True:
                 try:
-                    rec = self._next_record()
+                    recs = self._next_records(self.RECORDS_PER_CALL)
                 except StopIteration:
                     break
-                with self.cv:
-                    while (len(self.queue) >= self.capacity or not self.free) and not self.closed:
-                        self.cv.wait()
-                    if self.closed:
-                        return
-                    slot = self.free.popleft()
-                self.convert(*rec, self.images[slot], self.depths[slot])      # C code, outside the GIL
-                with self.cv:
-                    self.queue.append(slot)
-                    self.cv.notify_all()
+                while recs:
+                    with self.cv:
+                        while (len(self.queue) >= self.capacity or not self.free) and not self.closed:
+                            self.cv.wait()
+                        if self.closed:
+                            return
+                        room = max(1, min(len(recs), len(self.free), self.capacity - len(self.queue)))
+                        slots = [self.free.popleft() for _ in range(room)]
+                    self._decode(recs[:room], slots)                         # C code, outside the GIL
+                    recs = recs[room:]
+                    with self.cv:
+                        self.queue.extend(slots)
+                        self.cv.notify_all()
         except BaseException as e:                  # surfaced by dequeue(): never swallow a corrupt record
             with self.cv:
                 self.error = e
@@ -172,11 +238,13 @@ class ShuffleBatch:
                         break
                     raise OutOfRangeError('input queue is closed and has insufficient elements')
                 self.cv.wait()
-            picks = []
-            for _ in range(self.B):
-                i = int(self.rng.integers(len(self.queue)))
-                self.queue[i], self.queue[-1] = self.queue[-1], self.queue[i]
-                picks.append(self.queue.pop())
+            # batch_size uniformly chosen distinct elements (RandomShuffleQueue.dequeue_many), drawn in one call: removing
+            # the chosen positions from the back keeps the positions still to be removed valid
+            chosen = self.rng.choice(len(self.queue), self.B, replace=False)
+            picks = [self.queue[i] for i in chosen]
+            for i in sorted(chosen.tolist(), reverse=True):
+                self.queue[i] = self.queue[-1]
+                self.queue.pop()
             self.cv.notify_all()
         return picks
 
@@ -192,8 +260,8 @@ class ShuffleBatch:
             out_images = np.empty((self.B,) + self.images.shape[1:], np.float32)
             out_depths = np.empty((self.B,) + self.depths.shape[1:], np.float32)
         for b, s in enumerate(slots):
-            out_images[b] = self.images[s]
-            out_depths[b] = self.depths[s]
+            out_images[b] = self.materialise(s, 0)
+            out_depths[b] = self.materialise(s, 1)
         self.release(slots)
         return out_images, out_depths
 

@@ -1126,10 +1126,19 @@ class TrainOp:
         self.replica, self.pipeline, self.seed = replica, pipeline, seed
         dev = replica.device
         self.keep = torch.empty((replica.B, 4096), dtype=torch.uint8, device=dev) if replica.uses_dropout else None
-        pipeline.allocate(lambda shape: torch.empty(shape, dtype=torch.float32).pin_memory().numpy())
+        pipeline.allocate(lambda shape: torch.empty(shape, dtype=torch.float32).pin_memory().numpy(),
+                          lambda shape: torch.empty(shape, dtype=torch.uint8).pin_memory().numpy())
         self.pool = (torch.from_numpy(pipeline.images), torch.from_numpy(pipeline.depths))      # pinned views
+        # converter-written records are staged as uint8 pixel values (data.py): their own pinned pool and device buffers;
+        # the resize kernel rebuilds the loader's float32 from them bit for bit
+        self.pool_u8 = None
+        if pipeline.images_u8 is not None:
+            self.pool_u8 = (torch.from_numpy(pipeline.images_u8), torch.from_numpy(pipeline.depths_u8))
         self.dev = [tuple(torch.empty((replica.B,) + tuple(p.shape[1:]), device=dev) for p in self.pool)
                     for _ in range(2)]
+        self.dev_u8 = [tuple(torch.empty((replica.B,) + tuple(p.shape[1:]), device=dev, dtype=torch.uint8) for p in self.pool)
+                       for _ in range(2)] if self.pool_u8 is not None else None
+        self.cur = [None, None]             # the (images, depths) tensors batch i was copied into: uint8 or float32 each
         self.copy_stream = torch.cuda.Stream(device=dev)
         self.copied = [None, None]          # event: the DMA into buffer i finished
         self.consumed = [None, None]        # event: the step that read buffer i finished
@@ -1152,12 +1161,25 @@ class TrainOp:
             return
         if self.consumed[i] is not None:
             self.copy_stream.wait_event(self.consumed[i])
+        pl = self.pipeline
+        cur = []
+        kinds = int(np.bitwise_and.reduce(pl.kind[slots])) if self.pool_u8 is not None else 0
+        for which in (0, 1):                # images, depths: uint8 when EVERY record of the batch staged that feature so
+            as_u8 = bool(kinds & (1 << which))
+            if not as_u8 and self.pool_u8 is not None:
+                for s in slots:
+                    pl.materialise(s, which)                    # (a mixed batch: the uint8 records are expanded on the host)
+            cur.append((self.dev_u8 if as_u8 else self.dev)[i][which])
+        ids = (ctypes.c_int32 * len(slots))(*slots)
         with torch.cuda.stream(self.copy_stream):
-            for b, s in enumerate(slots):
-                self.dev[i][0][b].copy_(self.pool[0][s], non_blocking=True)
-                self.dev[i][1][b].copy_(self.pool[1][s], non_blocking=True)
+            for which in (0, 1):
+                src = (self.pool_u8 if cur[which].dtype == torch.uint8 else self.pool)[which]
+                ops.check(_lib.load().a3d_h2d_gather(cur[which].data_ptr(), src.data_ptr(), ids, len(slots),
+                                                     src[0].numel() * src.element_size(), self.copy_stream.cuda_stream),
+                          'a3d_h2d_gather')                     # B copies from ONE call (no per-record host-language work)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        self.cur[i] = tuple(cur)
         self.copied[i] = ev
         self.held[i] = slots
 
@@ -1170,7 +1192,7 @@ class TrainOp:
         cur.wait_event(self.copied[i])
         if self.keep is not None:
             ops.dropout_keep_mask(self.keep, self.seed, r.global_step)
-        self.last = r.step(self.dev[i][0], self.dev[i][1], self.keep)
+        self.last = r.step(self.cur[i][0], self.cur[i][1], self.keep)
         ev = torch.cuda.Event()
         ev.record(cur)
         self.consumed[i] = ev

@@ -193,16 +193,28 @@ def maxpool2x2_bwd(x, dy, dx, relu_mask=True):
 
 
 def resize_bilinear_tf1(x, y):
+    """x float32, or uint8 pixel values k of a converter-written record (the kernel reads fl(fl(fl(k/255) - .5) + .5))."""
     n, h, w, c = x.shape
+    if x.dtype == torch.uint8:
+        check(_lib.load().a3d_resize_bilinear_tf1_ex(n, h, w, c, _ptr(x), 1, y.shape[1], y.shape[2], _ptr(y), 0, None, 0, 0, 0,
+                                                     None, _stream()), 'a3d_resize_bilinear_tf1_ex')
+        return y
     check(_lib.load().a3d_resize_bilinear_tf1(n, h, w, c, _ptr(x), y.shape[1], y.shape[2], _ptr(y), _stream()),
           'a3d_resize_bilinear_tf1')
     return y
 
 
 def resize_bilinear_tf1_pair(x0, y0, x1, y1):
-    """Both resizes of a step in one launch: x0 -> y0 and x1 -> y1, stored tensors of the same batch and size."""
+    """Both resizes of a step in one launch: x0 -> y0 and x1 -> y1, stored tensors of the same batch and size; each
+    float32 or uint8 (see resize_bilinear_tf1)."""
     n, h, w, c0 = x0.shape
     assert x1.shape[:3] == (n, h, w)
+    if x0.dtype == torch.uint8 or x1.dtype == torch.uint8:
+        check(_lib.load().a3d_resize_bilinear_tf1_ex(n, h, w, c0, _ptr(x0), int(x0.dtype == torch.uint8), y0.shape[1],
+                                                     y0.shape[2], _ptr(y0), x1.shape[3], _ptr(x1),
+                                                     int(x1.dtype == torch.uint8), y1.shape[1], y1.shape[2], _ptr(y1),
+                                                     _stream()), 'a3d_resize_bilinear_tf1_ex')
+        return
     check(_lib.load().a3d_resize_bilinear_tf1_pair(n, h, w, c0, _ptr(x0), y0.shape[1], y0.shape[2], _ptr(y0), x1.shape[3],
                                                    _ptr(x1), y1.shape[1], y1.shape[2], _ptr(y1), _stream()),
           'a3d_resize_bilinear_tf1_pair')

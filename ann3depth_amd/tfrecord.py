@@ -128,6 +128,23 @@ class RecordFile:
             raise ValueError(f'{self.path}: record is {ishape}/{dshape}, destination is '
                              f'{tuple(image.shape)}/{tuple(depth.shape)}: records of different sizes cannot be batched')
 
+    def decode_into_u8(self, offset, length, image_u8, image_f32, depth_u8, depth_f32, verify_crc=True):
+        """decode_into for converter-written records (a3d_record_decode_u8): a feature whose floats all are
+        png_u8 / 255 - 0.5 lands in its uint8 array as the pixel values, any other in its float32 array (+ 0.5).
+        Returns (image_is_u8, depth_is_u8)."""
+        ev = ExampleView()
+        kinds = ctypes.c_int(0)
+        check(_lib.load().a3d_record_decode_u8(self.base + offset - 12, length + 16, int(verify_crc), image_u8.ctypes.data,
+                                               image_f32.ctypes.data, image_f32.size, depth_u8.ctypes.data,
+                                               depth_f32.ctypes.data, depth_f32.size, ctypes.byref(ev), ctypes.byref(kinds)),
+              f'a3d_record_decode_u8({self.path}@{offset})')
+        ishape = (ev.image_height, ev.image_width, ev.image_channels)
+        dshape = (ev.depth_height, ev.depth_width, ev.depth_channels)
+        if tuple(image_f32.shape) != ishape or tuple(depth_f32.shape) != dshape:
+            raise ValueError(f'{self.path}: record is {ishape}/{dshape}, destination is '
+                             f'{tuple(image_f32.shape)}/{tuple(depth_f32.shape)}: records of different sizes cannot be batched')
+        return bool(kinds.value & 1), bool(kinds.value & 2)
+
     def parse(self, offset, length):
         """-> (image [H,W,C], depth [H,W,C']) float32 with '+ 0.5'.  Sizes come from the record's own size features
         (the reference hard-codes 480x640, src/data.py:84-85)."""

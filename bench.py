@@ -57,6 +57,8 @@ def collect_timing(lib):
 def kernel_name(r):
     if r.prec:
         return f'igemm_bf16_kernel<{r.mode}, {r.bm}, {r.bn}, {"true" if r.prec == 1 else "false"}>'
+    if r.lds_dma == 2:
+        return f'conv3_fwd_kernel<{r.bm // 32}, {r.bn // 32}>'
     if r.lds_dma:
         return f'igemm_glds_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.nwaves}>'
     return f'igemm_kernel<{r.mode}, {r.bm}, {r.bn}, {r.waves_m}, {r.nwaves}, {r.bk}, {r.avec}, {r.bvec}>'

@@ -148,6 +148,12 @@ int a3d_resize_bilinear_tf1(int n, int h, int w, int c, const float* x, int oh, 
 /* The two resizes of a training step (image and depth map of the same stored size, src/models.py:282-283) in one launch. */
 int a3d_resize_bilinear_tf1_pair(int n, int h, int w, int c0, const float* x0, int oh0, int ow0, float* y0, int c1,
                                  const float* x1, int oh1, int ow1, float* y1, void* stream);
+/* The same one or two resizes (x1 == NULL: one) with each source either float32 or the uint8 pixel values k of
+ * a3d_record_decode_u8 (u8_0 / u8_1 != 0): a tap then reads fl(fl(fl(k / 255) - 0.5) + 0.5), the float the converter and
+ * the loader's `+ 0.5` (src/data.py:84-85) produce from that pixel, from a 256-entry table built in LDS — the output is
+ * bit-identical to resizing the float32 record. */
+int a3d_resize_bilinear_tf1_ex(int n, int h, int w, int c0, const void* x0, int u8_0, int oh0, int ow0, float* y0, int c1,
+                               const void* x1, int u8_1, int oh1, int ow1, float* y1, void* stream);
 
 /* tf.extract_image_patches(k x k, stride, SAME) + reshape (src/models.py:53-59): y [n*ph*pw, k, k, c]. */
 int a3d_extract_patches(int n, int h, int w, int c, const float* x, int k, int stride, float* y, void* stream);
@@ -263,7 +269,8 @@ typedef struct a3d_timing_record {
   int32_t mode;        /* 0 fwd, 1 bwd-data, 2 bwd-filter */
   int32_t bm, bn, waves_m, nwaves, bk, avec, bvec;   /* igemm_kernel<mode,bm,bn,waves_m,nwaves,bk,avec,bvec> */
   int32_t prec;        /* A3D_PREC_*; for bf16 modes the kernel is igemm_bf16_kernel<mode,bm,bn,x3> */
-  int32_t lds_dma;     /* 1: igemm_glds_kernel<mode,bm,bn,waves_m,nwaves> (tiles staged by global_load_lds) */
+  int32_t lds_dma;     /* 1: igemm_glds_kernel<mode,bm,bn,waves_m,nwaves> (tiles staged by global_load_lds);
+                        * 2: conv3_fwd_kernel<bm/32,bn/32,pool> (few-channel layers, one wave per bm x bn tile, no LDS) */
   int32_t splitk;
   int32_t m, n, k;     /* GEMM extents of the launch */
   float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */
@@ -297,6 +304,25 @@ int a3d_decode_raw_plus_half(const uint8_t* src, size_t bytes, float* dst);
  * over the bytes.  *view (optional) receives the size features. */
 int a3d_record_decode(const uint8_t* frame, size_t len, int verify_crc, float* image_dst, size_t image_floats,
                       float* depth_dst, size_t depth_floats, a3d_example_view* view);
+/* a3d_record_decode for records written by the converter (tools/data_tf_converter.py:36-37: png_u8 / 255 - 0.5): a feature
+ * whose floats ALL have that form, checked bit for bit, is delivered as the uint8 values k instead (*kinds bit 0: image in
+ * image_u8, bit 1: depth in depth_u8) — a quarter of the bytes for the pinned staging pool, the host link and the
+ * device-side read; a3d_resize_bilinear_tf1_ex rebuilds exactly the float32 value `stored + 0.5` of src/data.py:84-85 from
+ * k.  Any other feature is decoded to its float32 destination as a3d_record_decode does. */
+int a3d_record_decode_u8(const uint8_t* frame, size_t len, int verify_crc, uint8_t* image_u8, float* image_f32,
+                         size_t image_count, uint8_t* depth_u8, float* depth_f32, size_t depth_count,
+                         a3d_example_view* view, int* kinds);
+/* n framed records into slots slots[i] of the staging pool (dense arrays of image / depth features: float32, and uint8
+ * twins or NULL) in one call: a3d_record_decode_u8 per record when the twins exist, a3d_record_decode otherwise; kinds[i]
+ * as a3d_record_decode_u8's.  dims = {image h, w, c, depth h, w, c}: a record of any other size is an error. */
+int a3d_records_decode(const void* const* frames, const size_t* lens, int n, int verify_crc, const int64_t* dims,
+                       uint8_t* image_u8_pool, float* image_f32_pool, uint8_t* depth_u8_pool, float* depth_f32_pool,
+                       const int32_t* slots, int32_t* kinds);
+/* One dequeued batch from the pinned staging pool to its device buffer: record b of the batch is slot slots[b] of the pool
+ * (`bytes_each` bytes per slot, both sides dense), n asynchronous host-to-device copies on `stream` issued from ONE call —
+ * the shuffle queue hands out slot numbers (src/data.py:51-55: tf.train.shuffle_batch), and 2 x 32 copies per step issued
+ * one by one from the host language cost more of the step's launch budget than the copies themselves. */
+int a3d_h2d_gather(void* dst, const void* src_pool, const int32_t* slots, int n, size_t bytes_each, void* stream);
 /* Serialise one framed record (writer side).  Returns bytes written, or the needed size if cap is too small
  * (nothing written then), or a negative error. */
 int64_t a3d_example_write(const float* image, int ih, int iw, int ic, const float* depth, int dh, int dw, int dc,

@@ -36,25 +36,101 @@ def write_shard(root, n=40, seed=0):
             w.write_example(img, dep)
 
 
-def test_train_op_matches_oracle_on_a_dequeued_batch(tmp_path):
+@pytest.mark.parametrize('u8_records', [True, False])
+def test_train_op_matches_oracle_on_a_dequeued_batch(tmp_path, monkeypatch, u8_records):
+    """One dequeued batch through the model plugin against the oracle — on BOTH transfer paths: converter-written records
+    staged and DMA'd as uint8 pixel values and rebuilt by the resize kernel (data.py), and the plain float32 path
+    (A3D_NO_U8_RECORDS=1).  The oracle always sees the float32 the reference's loader would have produced."""
     from ann3depth_amd import data, models
+    if not u8_records:
+        monkeypatch.setenv('A3D_NO_U8_RECORDS', '1')
     write_shard(str(tmp_path))
     inputs, targets = data.inputs(str(tmp_path), 'nyu', 4, seed=3)
     op = models.msdn(inputs, targets)
     op.copied[0].synchronize()                       # batch 0 has landed in device buffer 0 (prefetched)
-    img, dep = op.dev[0][0].cpu().numpy(), op.dev[0][1].cpu().numpy()
+    assert (op.cur[0][0].dtype == torch.uint8) == u8_records and (op.cur[0][1].dtype == torch.uint8) == u8_records
+    img, dep = (t.cpu().numpy() for t in op.cur[0])
+    if u8_records:
+        img, dep = data.expand_u8(img), data.expand_u8(dep)          # the loader's float32, from the pixel values
     out = op.run()                                   # consumes it; the buffer is refilled with batch 2 afterwards
     torch.cuda.synchronize()
-    assert img.shape == (4, 48, 64, 3) and dep.shape == (4, 6, 8, 1)
+    assert img.shape == (4, 48, 64, 3) and dep.shape == (4, 6, 8, 1) and img.dtype == np.float32
     assert img.min() >= 0 and img.max() <= 1                               # '+0.5' applied: k/255
     keep = op.keep.cpu().numpy().astype(bool)
     assert 0.45 < keep.mean() < 0.55
     a = O.forward(O.init_params(3000), img, dep, keep)
+    np.testing.assert_array_equal(op.replica.x.cpu().numpy(), a['images'])   # the resized inputs: bit for bit on both paths
+    np.testing.assert_array_equal(op.replica.t.cpu().numpy(), a['depths'])
     assert rel(op.replica.coarse.cpu().numpy(), a['coarse']) < 1e-3
     assert rel(op.replica.fine.cpu().numpy(), a['fine']) < 1e-3
     assert abs(float(out['coarse_loss']) - a['loss_coarse']) < 2e-3 * abs(a['loss_coarse'])
     assert op.global_step == 1
     op.pipeline.close()
+
+
+def test_mixed_batches_fall_back_to_float32_per_feature(tmp_path):
+    """A shard whose depth maps are NOT of the converter's form (arbitrary floats) while its images are: images travel as
+    uint8, depths as float32; and a shard with ONE odd image among converter-written ones: the batches that hold it go
+    as float32 (the uint8-staged records of such a batch are expanded on the host), all values exact."""
+    from ann3depth_amd import data, models, tfrecord
+    rng = np.random.default_rng(5)
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, 'nyu'))
+    stored = []
+    with tfrecord.TFRecordWriter(os.path.join(root, 'nyu', 'train.tfrecords')) as w:
+        for i in range(24):
+            img = rng.integers(0, 256, (48, 64, 3)).astype(np.float32) / np.float32(255) - np.float32(.5)
+            if i == 7:
+                img[3, 4, 1] = np.nextafter(img[3, 4, 1], np.float32(1))      # one float that is no pixel value
+            img[0, 0, 0] = np.float32(i) / np.float32(255) - np.float32(.5)    # tag
+            dep = (rng.random((6, 8, 1)) - 0.5).astype(np.float32)
+            w.write_example(img, dep)
+            stored.append((img, dep))
+    inputs, targets = data.inputs(root, 'nyu', 4, epochs=1, seed=1, num_threads=2)
+    op = models.msdn(inputs, targets)
+    kinds = set()
+    for _ in range(6):                               # all 24 records
+        i = op.k & 1
+        op.copied[i].synchronize()
+        img_t, dep_t = op.cur[i]
+        assert dep_t.dtype == torch.float32
+        img = img_t.cpu().numpy()
+        tags = [int(t) for t in (img[:, 0, 0, 0] if img.dtype == np.uint8 else np.rint(img[:, 0, 0, 0] * 255))]
+        kinds.add((img.dtype == np.uint8, 7 in tags))
+        want = np.stack([stored[t][0] for t in tags]) + np.float32(.5)
+        np.testing.assert_array_equal(data.expand_u8(img) if img.dtype == np.uint8 else img, want)
+        np.testing.assert_array_equal(dep_t.cpu().numpy(), np.stack([stored[t][1] for t in tags]) + np.float32(.5))
+        op.run()
+    assert (False, True) in kinds and not any(u8 and odd for u8, odd in kinds)    # the odd record's batch went as float32
+    assert any(u8 for u8, _ in kinds)                                              # ... the others as uint8
+    op.pipeline.close()
+
+
+def test_resize_from_uint8_equals_resize_from_the_loaders_float32():
+    """a3d_resize_bilinear_tf1_ex: every one of the 256 pixel values, image and depth map of a pair and the single-tensor
+    form, against the float32 path bit for bit (BASELINE config 2's sizes)."""
+    from ann3depth_amd import data, ops
+    rng = np.random.default_rng(9)
+    k_img = rng.integers(0, 256, (3, 480, 640, 3), dtype=np.uint8)
+    k_img.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)
+    k_dep = rng.integers(0, 256, (3, 480, 640, 1), dtype=np.uint8)
+    f_img, f_dep = data.expand_u8(k_img), data.expand_u8(k_dep)
+    assert f_img.dtype == np.float32
+    np.testing.assert_array_equal(f_img, (k_img.astype(np.float32) / np.float32(255.) - np.float32(.5)) + np.float32(.5))
+    dev = lambda a: torch.from_numpy(a).cuda()
+    outs = []
+    for xi, xd in ((dev(f_img), dev(f_dep)), (dev(k_img), dev(k_dep)), (dev(k_img), dev(f_dep)), (dev(f_img), dev(k_dep))):
+        y0, y1 = torch.empty((3, 228, 304, 3), device='cuda'), torch.empty((3, 55, 74, 1), device='cuda')
+        ops.resize_bilinear_tf1_pair(xi, y0, xd, y1)
+        outs.append((y0, y1))
+    for y0, y1 in outs[1:]:
+        assert torch.equal(y0, outs[0][0]) and torch.equal(y1, outs[0][1])
+    np.testing.assert_array_equal(outs[0][0].cpu().numpy(), T.resize_bilinear_tf1(f_img, 228, 304))
+    single = torch.empty((3, 240, 320, 3), device='cuda')
+    ref = torch.empty_like(single)
+    ops.resize_bilinear_tf1(dev(k_img), single)
+    ops.resize_bilinear_tf1(dev(f_img), ref)
+    assert torch.equal(single, ref)
 
 
 def test_make_train_drop_in(tmp_path):

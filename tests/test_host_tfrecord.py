@@ -232,3 +232,93 @@ def test_pipeline_surfaces_corrupt_and_mismatched_records(tmp_path):
     with pytest.raises((_lib.A3dError, ValueError)):
         while True:
             inp.pipeline.next_batch()
+
+
+def test_record_decode_u8_is_exact_or_declines(tmp_path):
+    """a3d_record_decode_u8 (data.py: converter-written records travel as uint8 pixel values): a feature is delivered as
+    uint8 only when EVERY float is bit for bit fl(fl(k/255) - 0.5); expand_u8 then gives exactly what decode_into's
+    `+ 0.5` gives.  One float off by an ulp, a NaN, a value outside [-.5, .5]: the feature comes as float32 instead."""
+    rng = np.random.default_rng(42)
+    k_img = rng.integers(0, 256, (37, 41, 3), dtype=np.uint8)
+    k_img.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)                        # every pixel value once
+    k_dep = rng.integers(0, 256, (9, 11, 1), dtype=np.uint8)
+    conv = lambda k: k.astype(np.float32) / np.float32(255.) - np.float32(.5)         # tools/data_tf_converter.py:36-37
+    good_img, good_dep = conv(k_img), conv(k_dep)
+    off = good_img.copy()
+    off[5, 6, 2] = np.nextafter(off[5, 6, 2], np.float32(-1))
+    nan = good_dep.copy()
+    nan[1, 1, 0] = np.nan
+    big = good_dep.copy()
+    big[8, 10, 0] = np.float32(0.75)
+    cases = [(good_img, good_dep, True, True), (off, good_dep, False, True), (good_img, nan, True, False),
+             (good_img, big, True, False), (off, (rng.random((9, 11, 1)) - .5).astype(np.float32), False, False)]
+    path = str(tmp_path / 'u8.tfrecords')
+    with tfrecord.TFRecordWriter(path) as w:
+        for img, dep, _, _ in cases:
+            w.write_example(img, dep)
+    rf = tfrecord.RecordFile(path)
+    frames = list(rf.frames())
+    for (o, ln), (img, dep, img_u8, dep_u8) in zip(frames, cases):
+        ref_i, ref_d = np.empty(img.shape, np.float32), np.empty(dep.shape, np.float32)
+        rf.decode_into(o, ln, ref_i, ref_d)
+        iu, iff = np.full(img.shape, 77, np.uint8), np.full(img.shape, -9, np.float32)
+        du, dff = np.full(dep.shape, 77, np.uint8), np.full(dep.shape, -9, np.float32)
+        assert rf.decode_into_u8(o, ln, iu, iff, du, dff) == (img_u8, dep_u8)
+        got_i = data.expand_u8(iu) if img_u8 else iff
+        got_d = data.expand_u8(du) if dep_u8 else dff
+        np.testing.assert_array_equal(got_i.view(np.uint32), ref_i.view(np.uint32))   # bits, so that a NaN compares too
+        np.testing.assert_array_equal(got_d.view(np.uint32), ref_d.view(np.uint32))
+        if img_u8:
+            np.testing.assert_array_equal(iu, k_img)
+            assert (iff == -9).all()                              # the float32 destination of a uint8 feature is untouched
+    # a flipped payload bit is still caught on this path
+    raw = bytearray(open(path, 'rb').read())
+    raw[frames[0][0] + 40] ^= 0x10
+    bad = str(tmp_path / 'bad.tfrecords')
+    open(bad, 'wb').write(bytes(raw))
+    rfb = tfrecord.RecordFile(bad)
+    o, ln = frames[0]
+    with pytest.raises(_lib.A3dError, match='corrupt'):
+        rfb.decode_into_u8(o, ln, np.empty(good_img.shape, np.uint8), np.empty(good_img.shape, np.float32),
+                           np.empty(good_dep.shape, np.uint8), np.empty(good_dep.shape, np.float32))
+
+
+def test_shuffle_batch_with_uint8_staging_hands_out_the_same_batches(tmp_path):
+    """The staging pool with uint8 twins (what a GPU consumer allocates) against the plain float32 pool: every record comes
+    out with the same float32 values, bit for bit — on a shard that mixes converter-written and arbitrary records."""
+    rng = np.random.default_rng(3)
+    os.makedirs(tmp_path / 'nyu')
+    with tfrecord.TFRecordWriter(str(tmp_path / 'nyu' / 'train.tfrecords')) as w:
+        for i in range(40):
+            img = rng.integers(0, 256, (6, 8, 3)).astype(np.float32) / np.float32(255) - np.float32(.5)
+            dep = rng.integers(0, 256, (3, 4, 1)).astype(np.float32) / np.float32(255) - np.float32(.5)
+            if i % 5 == 0:
+                img = (rng.random((6, 8, 3)) - .5).astype(np.float32)
+            dep[0, 0, 0] = np.float32(i) / np.float32(255) - np.float32(.5)             # tag
+            w.write_example(img, dep)
+    batches = []
+    for u8 in (False, True):
+        inp, _ = data.inputs(str(tmp_path), 'nyu', 4, epochs=1, seed=11, num_threads=1)
+        sb = inp.pipeline
+        sb.allocate(None, (lambda shape: np.empty(shape, np.uint8)) if u8 else None)
+        assert (sb.images_u8 is not None) == u8
+        got = []
+        try:
+            while True:
+                got.append(tuple(a.copy() for a in sb.next_batch()))
+        except data.OutOfRangeError:
+            pass
+        batches.append(got)
+    assert len(batches[0]) == len(batches[1]) == 10
+    # (which records meet in a batch depends on how far the reader thread had got when the batch was drawn: compare by tag)
+    by_tag = []
+    for got in batches:
+        recs = {}
+        for imgs, deps in got:
+            for b in range(4):
+                recs[int(np.rint(deps[b, 0, 0, 0] * 255))] = (imgs[b], deps[b])
+        assert sorted(recs) == list(range(40))
+        by_tag.append(recs)
+    for t in range(40):
+        np.testing.assert_array_equal(by_tag[0][t][0], by_tag[1][t][0])
+        np.testing.assert_array_equal(by_tag[0][t][1], by_tag[1][t][1])

@@ -35,16 +35,49 @@ for _ in range(steps):
     sb.next_batch()
 out['reader_images_per_s'] = round(B * steps / (time.perf_counter() - t0), 1)
 sb.close()
-inp, tgt = data.inputs(root, 'nyu', B, seed=0)
-op = models.msdn(inp, tgt)
-op.run(); op.run()
+# the reader threads alone (CRC + parse + decode into the staging pool; the consumer only returns the slots)
+for label, u8 in (('uint8', True), ('float32', False)):
+    inp, tgt = data.inputs(root, 'nyu', B, seed=0)
+    sb = inp.pipeline
+    sb.allocate(None, (lambda shape: np.empty(shape, np.uint8)) if u8 else None)
+    sb.release(sb.dequeue())
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sb.release(sb.dequeue())
+    out[f'decode_only_images_per_s_{label}'] = round(B * steps / (time.perf_counter() - t0), 1)
+    out['reader_threads'] = len(sb.threads)
+    sb.close()
+# `make train`'s loop on both transfer paths: converter-written records staged and DMA'd as uint8 pixel values (the default
+# for such records, data.py), and everything as float32 (A3D_NO_U8_RECORDS=1: what round 2 measured)
+for label, env in (('uint8_records', '0'), ('float32_records', '1')):
+    os.environ['A3D_NO_U8_RECORDS'] = env
+    inp, tgt = data.inputs(root, 'nyu', B, seed=0)
+    op = models.msdn(inp, tgt)
+    op.run(); op.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        op.run()
+    torch.cuda.synchronize()
+    out[f'train_loop_images_per_s_{label}'] = round(B * steps / (time.perf_counter() - t0), 1)
+    out[f'staged_as_{label}'] = str(op.cur[0][0].dtype)
+    op.pipeline.close()
+    del op
+os.environ.pop('A3D_NO_U8_RECORDS')
+# the same step with its batch resident in HBM (what bench.py times): the ceiling of the loop above
+net = models.MSDNReplica(B, keep_dense_grads=False)
+ti = torch.from_numpy(np.broadcast_to(img + np.float32(.5), (B,) + img.shape).copy()).cuda()
+td = torch.from_numpy(np.broadcast_to(dep + np.float32(.5), (B,) + dep.shape).copy()).cuda()
+keep = (torch.rand((B, 4096), device='cuda') >= 0.5).to(torch.uint8)
+for _ in range(3):
+    net.step(ti, td, keep)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    op.run()
+    net.step(ti, td, keep)
 torch.cuda.synchronize()
-out['train_loop_images_per_s'] = round(B * steps / (time.perf_counter() - t0), 1)
-op.pipeline.close()
+out['resident_images_per_s'] = round(B * steps / (time.perf_counter() - t0), 1)
+out['loop_over_resident'] = round(out['train_loop_images_per_s_uint8_records'] / out['resident_images_per_s'], 3)
 print(json.dumps(out))
 import shutil
 shutil.rmtree(root, ignore_errors=True)
