@@ -105,7 +105,7 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline_from(recs):
+def roofline_from(recs, with_traffic=True):
     groups = {}
     for r in recs:
         g = groups.setdefault(kernel_name(r), {'ms': 0.0, 'flops': 0.0, 'calls': 0})
@@ -119,9 +119,18 @@ def roofline_from(recs):
     table = {k: {'calls': v['calls'], 'avg_us': round(1e3 * v['ms'] / v['calls'], 2),
                  'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
     roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(name),
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            'traffic': pmc_traffic(name) if with_traffic else None,
             'calls': g['calls'], 'avg_launch_us': round(1e3 * g['ms'] / g['calls'], 2),
             'flops_per_launch': g['flops'] / g['calls']}
+    if roof['traffic'] is not None:
+        # what the counters can and cannot say (profiles/r03_ic_evidence.txt): FETCH_SIZE / WRITE_SIZE count the L2s' fabric
+        # requests, Infinity-Cache hits included, and gfx950 has no counter that separates those from HBM reads
+        # (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on every launch)
+        roof['traffic_fabric'] = roof['traffic']
+        roof['traffic_hbm'] = None
+        roof['traffic_note'] = ('fabric-side bytes per launch from the committed PMC passes of this command (profiles/*_pmc_traffic.json), '
+                                'Infinity-Cache hits included; no gfx950 counter isolates HBM: see profiles/r03_ic_evidence.txt')
     return roof, table
 
 
@@ -217,7 +226,7 @@ def bench_dcnf(args, lib, device, rank, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lib.a3d_timing_enable(0)
-    roof, table = roofline_from(collect_timing(lib))
+    roof, table = roofline_from(collect_timing(lib), with_traffic=False)      # (the committed PMC passes are MSDN's)
     gflop = net.P * (2.672 + 2 * 2.672 - 0.377)
     if rank == 0:
         print(json.dumps({
