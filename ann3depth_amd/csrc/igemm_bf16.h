@@ -278,8 +278,16 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   }
 
   // loads of k-tile kt into ra / rb (slot: row-table buffer of that tile, BWD_F); live = false: a tile that does not exist
-  auto stage = [&](auto uni_c, int kt, int slot, bool live) {
+  auto stage = [&](auto uni_c, int kt_real, int slot, bool live) {
     constexpr bool UNI = decltype(uni_c)::value;
+#ifdef A3D_HACK_FIXED_KT
+    // timing-only diagnostic build (never shipped, results are wrong): every iteration stages the FIRST k-tile, so all of
+    // the per-tile address generation is loop-invariant and leaves the loop — what the kernel would cost without it
+    const int kt = kt_begin;
+    (void)kt_real;
+#else
+    const int kt = kt_real;
+#endif
     __amdgpu_buffer_rsrc_t rsA, rsB;
     // ---------- A ----------
     if constexpr (MODE == MODE_BWD_F) {

@@ -10,6 +10,9 @@ unless data is given.  Round 2 adds
   tensorflow/python/kernel_tests/pooling_ops_test.py       (_testMaxPoolGradDirect1: ties go to the first maximum)
   tensorflow/python/kernel_tests/histogram_ops_test.py / histogram_fixed_width's docstring example
   tensorflow/python/ops/nn_test.py                         (DropoutTest: kept elements are x / keep_prob)
+Round 3 adds
+  tensorflow/python/training/gradient_descent_test.py      (GradientDescentOptimizerTest.testBasic)
+  tf.scatter_nd_update's documented example (python/ops/state_ops.py docstring): rank-1 update of 4 of 8 elements
 These are DATA (inputs by rule + expected outputs), not source; they pin the oracle's conv2d
 (VALID / SAME incl. the odd SAME split, stride > kernel), both conv gradients, max-pool and the legacy bilinear resize
 to what TensorFlow 1.3 computes.
@@ -92,3 +95,13 @@ HISTOGRAM_FIXED_WIDTH = {
 
 # nn.dropout: binary = floor(keep_prob + U); y = x / keep_prob * binary -> an all-ones input comes out as {0, 1/keep_prob}
 DROPOUT_KEEP_PROBS = [0.1, 0.5, 0.8]
+
+# GradientDescentOptimizerTest.testBasic: var -= learning_rate * grad  (dcnf's tf.train.GradientDescentOptimizer(0.1),
+# src/models.py:198)
+SGD_TEST_BASIC = {'learning_rate': 3.0, 'var0': [1.0, 2.0], 'var1': [3.0, 4.0], 'grads0': [0.1, 0.1], 'grads1': [0.01, 0.01],
+                  'expected0': [1.0 - 3.0 * 0.1, 2.0 - 3.0 * 0.1], 'expected1': [3.0 - 3.0 * 0.01, 4.0 - 3.0 * 0.01]}
+
+# tf.scatter_nd_update docstring: ref = [1..8]; indices [[4], [3], [1], [7]]; updates [9, 10, 11, 12]
+# (get_A builds the CRF's R with two such updates along (left, right) and (right, left), src/models.py:138-141)
+SCATTER_ND_UPDATE_DOC = {'ref': [1, 2, 3, 4, 5, 6, 7, 8], 'indices': [[4], [3], [1], [7]], 'updates': [9, 10, 11, 12],
+                         'expected': [1, 11, 3, 10, 9, 6, 7, 12]}

@@ -90,6 +90,19 @@ def test_crf_loss_and_gradient_match_oracle(regime):
     assert rel(dz.cpu().numpy(), dz32[..., 0]) < 5e-3
 
 
+def test_sgd_apply_on_tensorflows_published_vector():
+    """GradientDescentOptimizerTest.testBasic (tests/golden/tf13_published_vectors.py) through a3d_sgd_apply."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import tf13_published_vectors as V
+    from ann3depth_amd import ops
+    c = V.SGD_TEST_BASIC
+    for k in ('0', '1'):
+        var = torch.tensor(c['var' + k], device='cuda')
+        ops.sgd_apply(var, torch.tensor(c['grads' + k], device='cuda'), c['learning_rate'])
+        np.testing.assert_allclose(var.cpu().numpy(), c['expected' + k], rtol=1e-6)
+
+
 def test_sgd_apply_is_exact():
     from ann3depth_amd import ops
     rng = np.random.default_rng(0)

@@ -112,3 +112,33 @@ def test_dropout_values(keep_prob):
     vals = np.unique(y)
     assert len(vals) == 2 and vals[0] == 0
     np.testing.assert_allclose(vals[1], 1 / keep_prob, rtol=1e-6)
+
+
+def test_gradient_descent_basic():
+    """GradientDescentOptimizerTest.testBasic against the update rule the DCNF oracle and sgd_kernel apply
+    (var -= lr * g in the variable's dtype); the HIP kernel runs the same vector in tests/test_gpu_dcnf.py."""
+    c = V.SGD_TEST_BASIC
+    for k in ('0', '1'):
+        var = np.array(c['var' + k], np.float32)
+        var -= np.float32(c['learning_rate']) * np.array(c['grads' + k], np.float32)
+        np.testing.assert_allclose(var, c['expected' + k], rtol=1e-6)
+
+
+def test_scatter_nd_update_documented_example_and_the_crf_matrix():
+    """The documented rank-1 example through numpy's index assignment (what oracle.dcnf.crf_matrix uses for get_A's two
+    scatter_nd_update calls), then the matrix itself: R symmetric with r on the pair positions, A = I + D - R."""
+    from oracle import dcnf as OD
+    c = V.SCATTER_ND_UPDATE_DOC
+    ref = np.array(c['ref'])
+    ref[np.array(c['indices'])[:, 0]] = c['updates']
+    np.testing.assert_array_equal(ref, c['expected'])
+    left, right = OD.pair_indices()
+    r = np.arange(1, len(left) + 1, dtype=np.float64)
+    A = OD.crf_matrix(r)
+    R = np.zeros_like(A)
+    for (i, j), v in zip(zip(left, right), r):          # scatter_nd_update: one element per index pair, later wins
+        R[i, j] = v
+    for (i, j), v in zip(zip(right, left), r):
+        R[i, j] = v
+    np.testing.assert_array_equal(A, np.eye(A.shape[0]) + np.diag(R.sum(axis=1)) - R)
+    np.testing.assert_array_equal(R, R.T)

@@ -1,35 +1,37 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/prof_<tag>/ and writes the summaries to be judged into
-# profiles/<tag>_* (tracked).      bash tools/profile_round.sh r03
+# gpurun_out/prof_<tag>/profiles/ (only gpurun_out/ travels back from the box: copy them into profiles/ afterwards).
+#     bash tools/profile_round.sh r03
 # Counter passes are separate runs (one --pmc group each, kernel trace only), as MI355X_MICROARCH.md prescribes.
 set -e -o pipefail
 tag=${1:-rXX}
 out=gpurun_out/prof_$tag
-mkdir -p $out profiles
+P=$out/profiles
+mkdir -p $P
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="--steps 20 --warmup 5 --no-cpu-baseline --no-fine --no-dp-rank --also \"\""
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-cp $out/bench_default.json profiles/${tag}_bench_default.json
+cp $out/bench_default.json $P/${tag}_bench_default.json
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/bench_under_rocprof.log 2>&1
-cp $out/kt/kt_kernel_stats.csv profiles/${tag}_bench_coarse_kernel_stats.csv
-grep '^{' $out/bench_under_rocprof.log | tail -1 > profiles/${tag}_bench_coarse_under_rocprof.json
-python3 tools/timeline.py "$out/kt/kt_kernel_trace.csv" adam_frozen -v > profiles/${tag}_step_timeline.txt
+cp $out/kt/kt_kernel_stats.csv $P/${tag}_bench_coarse_kernel_stats.csv
+grep '^{' $out/bench_under_rocprof.log | tail -1 > $P/${tag}_bench_coarse_under_rocprof.json
+python3 tools/timeline.py "$out/kt/kt_kernel_trace.csv" adam_frozen -v > $P/${tag}_step_timeline.txt
 echo "kernel trace + timeline done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o f -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o w -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv profiles/${tag}_pmc_traffic.json > $out/pmc_traffic.txt
+python3 tools/pmc_traffic.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv $P/${tag}_pmc_traffic.json > $out/pmc_traffic.txt
 echo "traffic done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $out/pmc_mfma -o m -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/pmc_mfma.log 2>&1
-python3 tools/pmc_mfma.py $out/pmc_mfma/m_counter_collection.csv $out/pmc_mfma/m_kernel_trace.csv profiles/${tag}_pmc_mfma_busy.json > $out/pmc_mfma.txt
+python3 tools/pmc_mfma.py $out/pmc_mfma/m_counter_collection.csv $out/pmc_mfma/m_kernel_trace.csv $P/${tag}_pmc_mfma_busy.json > $out/pmc_mfma.txt
 echo "mfma done"
-python3 bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --no-dp-rank --precision bf16s --also bf16,bf16x3,fp32 > profiles/${tag}_bench_batch64_bf16_storage.json 2> $out/bench_b64.err
+python3 bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --no-dp-rank --precision bf16s --also bf16,bf16x3,fp32 > $P/${tag}_bench_batch64_bf16_storage.json 2> $out/bench_b64.err
 echo "b64 done"
-python3 bench.py --model dcnf --no-cpu-baseline > profiles/${tag}_bench_dcnf.json 2> $out/bench_dcnf.err
+python3 bench.py --model dcnf --no-cpu-baseline > $P/${tag}_bench_dcnf.json 2> $out/bench_dcnf.err
 echo "dcnf done"
-python3 tools/bench_input.py 256 32 100 2> $out/input.err | tail -1 > profiles/${tag}_input_pipeline.json
+python3 tools/bench_input.py 256 32 100 2> $out/input.err | tail -1 > $P/${tag}_input_pipeline.json
 echo "input done"
-python3 tools/bench_layers.py > profiles/${tag}_bench_layers.txt 2> $out/layers.err
+python3 tools/bench_layers.py > $P/${tag}_bench_layers.txt 2> $out/layers.err
 echo "layers done"
 rm -rf $out/kt $out/pmc_fetch $out/pmc_write $out/pmc_mfma
-ls profiles | grep $tag
+ls $P
