@@ -25,10 +25,15 @@ struct Bf16Cfg {
   // k-tile: 64 for the plain bf16 kernel (half as many barriers and LDS round trips per MAC as 32; 78 KB of LDS, two
   // blocks per CU), 32 for the two-plane x3 variant (its planes would not fit otherwise)
   static constexpr int BK = X3 ? 32 : 64;
-  static constexpr int NWAVES = 8, NT = 512, WAVES_M = 4, WAVES_N = 2;
+#ifndef A3D_BF16_WAVES
+#define A3D_BF16_WAVES 8
+#endif
+  // 8 waves of 32 x (BN/2), or (diagnostic / tuning build: -DA3D_BF16_WAVES=4) 4 waves of 64 x (BN/2): twice the MFMAs
+  // per wave, barrier and fragment read, half the wavefronts per CU
+  static constexpr int NWAVES = A3D_BF16_WAVES, NT = 64 * NWAVES, WAVES_M = NWAVES / 2, WAVES_N = 2;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(TM == 1 && TN >= 1 && TN * 32 * WAVES_N == BN, "tile");
+  static_assert(TM >= 1 && TN >= 1 && TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile");
   static constexpr bool A_KC = (MODE != MODE_BWD_F);     // A tile k-contiguous?
   static constexpr bool B_KC = (MODE == MODE_BWD_D);
   static constexpr int A_ROWS = A_KC ? BM : BK, A_COLS = A_KC ? BK : BM;     // same tile shapes as the fp32 kernel
@@ -46,14 +51,14 @@ struct Bf16Cfg {
 };
 
 // fp32 registers of a loader tile -> bf16 plane(s), same [row][col] orientation as the global tile
-template <class Tile, bool X3, bool PLAIN>
+template <class Tile, bool X3, bool PLAIN, int NT>
 __device__ __forceinline__ void store_bf16(const float (&regs)[Tile::NL][4], __bf16* hi, __bf16* lo, int ld, int tid) {
 #pragma unroll
   for (int j = 0; j < Tile::NL; ++j) {
     int row, cq;
     if constexpr (PLAIN) {
-      const int idx = tid + j * 512;
-      if (Tile::TOTAL % 512 != 0 && idx >= Tile::TOTAL) continue;
+      const int idx = tid + j * NT;
+      if (Tile::TOTAL % NT != 0 && idx >= Tile::TOTAL) continue;
       row = idx / Tile::CPR;
       cq = idx % Tile::CPR;
     } else {
@@ -74,14 +79,14 @@ __device__ __forceinline__ void store_bf16(const float (&regs)[Tile::NL][4], __b
 
 // registers of a loader tile that was gathered from a bf16 tensor through its "float view" (a float = two adjacent
 // bf16 channels; 4 floats = 8 bf16 = one 16-byte chunk) -> bf16 plane, bit for bit
-template <class Tile, bool PLAIN>
+template <class Tile, bool PLAIN, int NT>
 __device__ __forceinline__ void store_raw16(const float (&regs)[Tile::NL][4], __bf16* hi, int ld, int tid) {
 #pragma unroll
   for (int j = 0; j < Tile::NL; ++j) {
     int row, cq;
     if constexpr (PLAIN) {
-      const int idx = tid + j * 512;
-      if (Tile::TOTAL % 512 != 0 && idx >= Tile::TOTAL) continue;
+      const int idx = tid + j * NT;
+      if (Tile::TOTAL % NT != 0 && idx >= Tile::TOTAL) continue;
       row = idx / Tile::CPR;
       cq = idx % Tile::CPR;
     } else {
@@ -125,9 +130,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane, int ld, int col0,
 // unconverted.  C16: the output tensor (and, in BWD_D, the ReluGrad mask, which is the same activation) is bf16; split-K
 // slabs and filter gradients stay fp32.
 template <int MODE, int BM, int BN, bool X3, bool A16 = false, bool B16 = false, bool C16 = false>
-__global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm_bf16_kernel(const IgemmParams p) {
   using Cfg = Bf16Cfg<MODE, BM, BN, X3>;
-  constexpr int BK = Cfg::BK, NT = Cfg::NT, TN = Cfg::TN;
+  constexpr int BK = Cfg::BK, NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
   constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
   static_assert(!(X3 && (A16 || B16)), "the split-operand mode needs fp32 sources");
   using ATile = Im2colTile<NT, Cfg::A_ROWS, A16 ? Cfg::A_COLS / 2 : Cfg::A_COLS, 4, TRANSPOSED>;
@@ -174,11 +179,13 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
   if (kt_end > nk_total) kt_end = nk_total;
   const int nkt = kt_end - kt_begin;
 
-  f32x16 acc[TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int b = 0; b < TN; ++b)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
   float ra[ATile::NL][4];
   float rb[BTile::NL][4];
@@ -379,10 +386,10 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     }
   };
   auto store_tiles = [&](int buf) {
-    if constexpr (A16) store_raw16<ATile, false>(ra, A_hi(buf), Cfg::A_LD, tid);
-    else store_bf16<ATile, X3, false>(ra, A_hi(buf), A_lo(buf), Cfg::A_LD, tid);
-    if constexpr (B16) store_raw16<BTile, B_PLAIN>(rb, B_hi(buf), Cfg::B_LD, tid);
-    else store_bf16<BTile, X3, B_PLAIN>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
+    if constexpr (A16) store_raw16<ATile, false, NT>(ra, A_hi(buf), Cfg::A_LD, tid);
+    else store_bf16<ATile, X3, false, NT>(ra, A_hi(buf), A_lo(buf), Cfg::A_LD, tid);
+    if constexpr (B16) store_raw16<BTile, B_PLAIN, NT>(rb, B_hi(buf), Cfg::B_LD, tid);
+    else store_bf16<BTile, X3, B_PLAIN, NT>(rb, B_hi(buf), B_lo(buf), Cfg::B_LD, tid);
   };
 
   auto k_loop = [&](auto uni_c) {
@@ -408,14 +415,17 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     const __bf16* bl = B_lo(cur);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 a_hi, a_lo, b_hi[TN], b_lo[TN];
-      const int arow = wm * Cfg::WM + li;
-      if (Cfg::A_KC) {
-        a_hi = frag_kc(ah, Cfg::A_LD, arow, 16 * s + 8 * lh);
-        if (X3) a_lo = frag_kc(al, Cfg::A_LD, arow, 16 * s + 8 * lh);
-      } else {
-        a_hi = frag_tr(ah, Cfg::A_LD, wm * Cfg::WM, 16 * s, lane);
-        if (X3) a_lo = frag_tr(al, Cfg::A_LD, wm * Cfg::WM, 16 * s, lane);
+      bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int arow0 = wm * Cfg::WM + a * 32;
+        if (Cfg::A_KC) {
+          a_hi[a] = frag_kc(ah, Cfg::A_LD, arow0 + li, 16 * s + 8 * lh);
+          if (X3) a_lo[a] = frag_kc(al, Cfg::A_LD, arow0 + li, 16 * s + 8 * lh);
+        } else {
+          a_hi[a] = frag_tr(ah, Cfg::A_LD, arow0, 16 * s, lane);
+          if (X3) a_lo[a] = frag_tr(al, Cfg::A_LD, arow0, 16 * s, lane);
+        }
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
@@ -433,13 +443,15 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
         store_tiles(cur ^ 1);
       }
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        if (X3) {
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[b], acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[b], acc[b], 0, 0, 0);
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          if (X3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[a], b_hi[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[a], b_lo[b], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[a], b_hi[b], acc[a][b], 0, 0, 0);
         }
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[b], acc[b], 0, 0, 0);
-      }
     }
     __syncthreads();
     cur ^= 1;
@@ -475,6 +487,8 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     }
   }
 #pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int col = n0 + wn * Cfg::WN + b * 32 + li;
     if (col >= p.N) continue;
@@ -482,9 +496,9 @@ __global__ __launch_bounds__(512, 4) void igemm_bf16_kernel(const IgemmParams p)
     if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      const int row = m0 + wm * Cfg::WM + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
       if (row >= p.M) continue;
-      float val = acc[b][v];
+      float val = acc[a][b][v];
       const size_t o = (partial || MODE != MODE_BWD_D
                             ? (size_t)row
                             : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
