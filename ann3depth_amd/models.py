@@ -358,7 +358,12 @@ class MSDNReplica:
         red = self.reducer
         work = red.any(self._poison)
         red.wait(work)
-        host = torch.empty(1, dtype=torch.int32).pin_memory() if self.device.type == 'cuda' else torch.empty(1, dtype=torch.int32)
+        if not hasattr(self, '_poison_ring'):       # four pinned words, reused (at most two reads are ever outstanding)
+            ring = torch.empty(4, dtype=torch.int32)
+            self._poison_ring = (ring.pin_memory() if self.device.type == 'cuda' else ring, 0)
+        ring, nxt = self._poison_ring
+        self._poison_ring = (ring, (nxt + 1) % 4)
+        host = ring[nxt:nxt + 1]
         host.copy_(self._poison, non_blocking=True)
         ev = None
         if self.device.type == 'cuda':

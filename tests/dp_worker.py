@@ -90,6 +90,31 @@ def main(out_path):
     assert np.array_equal(gathered.numpy(), one.m['w']), 'sharded m differs from one rank on the summed gradient'
     assert float(np.abs(one.m['w']).max()) > 0
     assert red.agree_all([rank, 5 - rank, 0]) == [1, 5, 0]
+    # ---- the driver's per-step decision (ann3depth.Session._decide): an exhausted input on ONE rank stops both cleanly, a
+    # reader FAILURE on one rank is raised on both (it used to look like a clean end of input), the chief's
+    # checkpoint request reaches everybody
+    import types
+    from ann3depth_amd import ann3depth, data
+    def session(end):
+        rep = types.SimpleNamespace(reducer=red, global_step=0)
+        op = types.SimpleNamespace(replica=rep, end=end, k=0)
+        sess = ann3depth.Session(op, None, last_step=10, stop_at_signal=types.SimpleNamespace(signal_received=0),
+                                 save_checkpoint_secs=0, save_summaries_steps=0, trace_every=0, logger=None, world=world)
+        return sess, op
+    sess, op = session((0, data.OutOfRangeError('dry')) if rank == 1 else None)
+    assert sess._decide(op) is False and sess.stop and sess.sig.signal_received == 0           # both ranks stop, exit code 0
+    sess, op = session((0, ValueError('tfrecord: corrupt payload')) if rank == 1 else None)
+    try:
+        sess._decide(op)
+        raise AssertionError('a reader failure must not pass for a clean end of input')
+    except ValueError as e:
+        assert rank == 1 and 'corrupt' in str(e)
+    except RuntimeError as e:
+        assert rank == 0 and 'another replica' in str(e)
+    sess, op = session(None)
+    assert sess._decide(op, want_save=(rank == 0)) is True and not sess.stop                   # the chief's timer fired
+    sess, op = session((5, data.OutOfRangeError('later')))                                    # not due yet: batch 5, k = 0
+    assert sess._decide(op) is False and not sess.stop
     # collective stop decision (dp.GradReducer.agree): SIGUSR1 reaches rank 1 only, during its third "step"; both ranks
     # must leave the loop after the same step with the signal number as the agreed value
     import signal
