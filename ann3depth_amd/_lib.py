@@ -15,7 +15,7 @@ class A3dError(RuntimeError):
 class ConvDesc(ctypes.Structure):
     """struct a3d_conv_desc"""
     _fields_ = [(n, c_int32) for n in ('n', 'h', 'w', 'c', 'k', 'r', 's', 'stride', 'pad_t', 'pad_l', 'ho', 'wo',
-                                       'ldx', 'ldy', 'precision', 'storage')]
+                                       'ldx', 'ldy', 'precision', 'storage', 'hints')]
 
 
 class ExampleView(ctypes.Structure):

@@ -215,10 +215,24 @@ size_t conv3_ws_bytes(const a3d_conv_desc* d) {
   return ((size_t)s.Kp * s.Np * 4 + 255) / 256 * 256;
 }
 
+// share: A3D_HINT_SHARE_CU — the kernel uses no LDS, so a dynamic request of 80 KiB + 1 KiB caps it at one 4-wave block
+// per CU... two blocks (8 waves, two per SIMD) need 160 / 3 KiB + 1 KiB each
 template <int TM, int TN>
-static void conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, hipStream_t st) {
-  if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), 0, st, p);
+static int conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, bool share, hipStream_t st) {
+  constexpr size_t kShare = (size_t)163840 / 3 + 1024;
+  const size_t lds = share ? kShare : 0;
+  static bool attr_done = false;
+  if (share && !attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShare) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShare) != hipSuccess)
+      return set_error(A3D_ELAUNCH, "conv3: hipFuncSetAttribute failed");
+    attr_done = true;
+  }
+  if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), lds, st, p);
+  return A3D_OK;
 }
 
 int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
@@ -248,8 +262,9 @@ int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const floa
   p.m_tiles = (p.M + 32 * TM - 1) / (32 * TM);
   const unsigned blocks = (unsigned)(((long)p.m_tiles * tiles_n + 3) / 4);
   clear_stale_error();
-  if (s.TN == 3) conv3_launch<2, 3>(p, pool != 0, blocks, st);
-  else conv3_launch<2, 2>(p, pool != 0, blocks, st);
+  const bool share = (d->hints & A3D_HINT_SHARE_CU) != 0;
+  rc = s.TN == 3 ? conv3_launch<2, 3>(p, pool != 0, blocks, share, st) : conv3_launch<2, 2>(p, pool != 0, blocks, share, st);
+  if (rc != A3D_OK) return rc;
   return check_launch("conv3_fwd");
 }
 

@@ -181,6 +181,7 @@ struct IgemmParams {
   float* sk_ws;                 // [2 * grid][BM * BN] accumulator slabs
   float* sk_bias;               // [2 * grid][BN] BiasAddGrad partial sums (bwd-filter)
   FastDiv div_nk;               // k-tiles per tile
+  int share;                    // host only: A3D_HINT_SHARE_CU — launch with enough dynamic LDS that <= 8 waves fit a CU
   int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
   unsigned long long* stamps;   // diagnostic builds (-DA3D_STAMPS) only: per-wave phase cycle sums; null otherwise
 };

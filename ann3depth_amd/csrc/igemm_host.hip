@@ -792,6 +792,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   }
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
+  if (d->hints & A3D_HINT_SHARE_CU) g.no_glds = 1;      // the register-staged kernels take the hint (launch_one)
   RunForm rf{};
   const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
   size_t ws_used = 0;
@@ -829,6 +830,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   A3D_CHECK_ARG(!(p.a16 || p.b16) || plan.prec == A3D_PREC_BF16, "conv2d_fwd: bf16 operands need vectorisable tensors");
   A3D_CHECK_ARG(!p.c16 || plan.prec == A3D_PREC_BF16 || plan.cfg < kFirstGldsCfg, "conv2d_fwd: no bf16 output from the LDS-DMA kernel");
   p.A = x; p.B = filter; p.C = y; p.bias = bias; p.act = act;
+  p.share = (d->hints & A3D_HINT_SHARE_CU) ? 1 : 0;
   p.npix = g.M; p.nrsc = g.K;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;
   p.stride = d->stride; p.lstride = ilog2_exact(d->stride); p.pad_t = d->pad_t; p.pad_l = d->pad_l;

@@ -11,19 +11,29 @@ namespace a3d {
                     X(4, 64, 64, 2, 4, 32) X(5, 32, 128, 1, 4, 32) X(6, 64, 128, 1, 4, 32) X(7, 128, 128, 4, 8, 32) \
                     X(8, 128, 64, 4, 8, 32)
 
+// A3D_HINT_SHARE_CU: the dynamic LDS request is raised until only 8 / NWAVES blocks (two wavefronts per SIMD) fit the
+// CU's 160 KiB, so the other stream's bandwidth-bound kernels find free registers and wave slots on every CU.
+template <int NWAVES>
+constexpr size_t share_lds_bytes(size_t need) {
+  constexpr size_t blocks = NWAVES >= 8 ? 1 : 8 / NWAVES;
+  const size_t pad = (size_t)163840 / (blocks + 1) + 1024;
+  return need > pad ? need : pad;
+}
+
 template <int BM, int BN, int WAVES_M, int NWAVES, int BK, int AVEC, int BVEC>
 static int launch_one(IgemmParams& p, unsigned grid, hipStream_t st) {
   using Cfg = IgemmCfg<A3D_MODE, BM, BN, WAVES_M, NWAVES, BK, AVEC, BVEC>;
   auto kern = igemm_kernel<A3D_MODE, BM, BN, WAVES_M, NWAVES, BK, AVEC, BVEC>;
+  constexpr size_t kShared = share_lds_bytes<NWAVES>(Cfg::LDS_BYTES);
   static bool attr_done = false;   // idempotent attribute, benign if set twice
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShared);
     if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
   clear_stale_error();
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), p.share ? kShared : Cfg::LDS_BYTES, st, p);
   return check_launch("igemm");
 }
 

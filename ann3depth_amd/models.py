@@ -156,6 +156,15 @@ class MSDNReplica:
         # CUs only as far as the register file allows (two 8-wave GEMM blocks fill a SIMD's 512 registers), so the gain
         # is a quarter of the stretch, not all of it.  The dominant bwd-filter GEMMs run after the join, alone.
         self.overlap = os.environ.get('A3D_OVERLAP', '1') == '1'
+        # A3D_SHARE_CU: which fine-network GEMMs are launched with A3D_HINT_SHARE_CU (at most two wavefronts per SIMD, so
+        # that the dense layers' weight-streaming kernels find room on every CU): 3 = fine/second only (default; measured
+        # 3.06 against 3.10 ms per step without any hint), 1 = fine/first too (3.07), 2 = fine/first only (3.11), 0 = none.
+        # Starting fine/first earlier (beside the coarse conv stack: 3.18 ms) or later (after the dense forward: 3.11 ms)
+        # both lose: an MFMA-bound grid beside another MFMA-bound grid only takes CU slots from it.
+        share = int(os.environ.get('A3D_SHARE_CU', '3')) if (self.overlap and dev.type == 'cuda') else 0
+        self._share_names = {0: (), 1: ('fine/first/conv2d', 'fine/second/conv2d'), 2: ('fine/first/conv2d',),
+                             3: ('fine/second/conv2d',)}[share]
+        self._shared_desc = {}
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         # data-parallel replicas under the reference's frozen optimizer: the dense bucket is reduce-scattered and each
         # rank keeps the Adam `m` slot of its own slices only (dp.py); gather_state() reassembles it
@@ -294,6 +303,14 @@ class MSDNReplica:
         """The layer's conv descriptor for 'fwd' | 'bwd_d' | 'bwd_f', with that call's storage bits."""
         d = self.d[name]
         bits = self.store.get(name, {}).get(which, 0)
+        if which == 'fwd' and name in self._share_names:
+            # a fine-network GEMM on the side stream beside the dense layers' weight streams: leave those room on every CU
+            key = (name, bits)
+            if key not in self._shared_desc:
+                e = ops.with_storage(d, bits)
+                e.hints = ops.HINT_SHARE_CU
+                self._shared_desc[key] = e
+            return self._shared_desc[key]
         return ops.with_storage(d, bits) if bits else d
 
     def _w(self, name, which='fwd'):

@@ -68,7 +68,10 @@ def same_pad(in_size, k, stride):
 STORE_X, STORE_W, STORE_Y = 1, 2, 4      # a3d_conv_desc.storage bits: which tensors are bf16 in memory
 
 
-def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32', storage=0):
+HINT_SHARE_CU = 1                    # a3d_conv_desc.hints
+
+
+def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32', storage=0, hints=0):
     """Descriptor of tf.layers.conv2d(x[n,h,w,c], k, (r,s), (stride,stride), padding).  precision selects the
     arithmetic of the contraction: 'fp32' (exact, default), 'bf16x3' (split operands) or 'bf16'."""
     padding = padding.upper()
@@ -81,7 +84,7 @@ def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precisio
     else:
         raise ValueError(padding)
     return ConvDesc(n=n, h=h, w=w, c=c, k=k, r=r, s=s, stride=stride, pad_t=pt, pad_l=pl, ho=ho, wo=wo,
-                    ldx=ldx or c, ldy=ldy or k, precision=PREC[precision], storage=storage)
+                    ldx=ldx or c, ldy=ldy or k, precision=PREC[precision], storage=storage, hints=hints)
 
 
 def conv2d_fwd(d, x, w, bias, y, act=None):

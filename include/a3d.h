@@ -52,7 +52,14 @@ typedef struct a3d_conv_desc {
   int32_t ldy;               /* elements between consecutive output pixels (>= k) */
   int32_t precision;         /* A3D_PREC_*: arithmetic of the contraction */
   int32_t storage;           /* A3D_STORE_* bits: which tensors are bf16 in memory (0: all float32); needs A3D_PREC_BF16 */
+  int32_t hints;             /* A3D_HINT_* bits: scheduling advice, never changes a result */
 } a3d_conv_desc;
+
+/* The forward launch will run beside bandwidth-bound kernels of ANOTHER stream (the fine network's forward beside the
+ * coarse network's dense layers: src/models.py:289-290 builds both in one graph): keep at most two wavefronts per SIMD
+ * resident, so that the other stream's kernels find free registers and wave slots on every CU instead of waiting for
+ * GEMM blocks to retire. */
+#define A3D_HINT_SHARE_CU 1
 
 /* BASELINE config 5 ("bf16 activations + bf16 weight copies, fp32 master and accumulate"): tensors marked here are bf16 in
  * HBM (pass their pointers through the float* parameters); channel counts and pixel strides of a bf16 tensor must be
