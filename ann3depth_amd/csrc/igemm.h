@@ -180,6 +180,10 @@ struct IgemmParams {
   int streamk;
   float* sk_ws;                 // [2 * grid][BM * BN] accumulator slabs
   float* sk_bias;               // [2 * grid][BN] BiasAddGrad partial sums (bwd-filter)
+  // host only (launch_igemm): a window-run filter gradient whose split-K reduction stores straight into the unpadded
+  // filter (run rows of unpad_rl floats out of padded rows of unpad_rlp); unpad_done reports that it did
+  float* unpad_dst;
+  int unpad_rl, unpad_rlp, unpad_done;
   FastDiv div_nk;               // k-tiles per tile
   int share;                    // host only: A3D_HINT_SHARE_CU — launch with enough dynamic LDS that <= 8 waves fit a CU
   int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
@@ -1093,6 +1097,8 @@ struct ReduceParams {
   int vec4;              // plain 16-byte sum (bwd-filter slabs)
   int c16;               // output (and BWD_D mask) tensors are bf16
   const float* dbias_ws; float* dbias_out;     // bwd-filter: the [splitk][N] BiasAddGrad slabs ride along, or null
+  int row_rl, row_rlp;   // vec4 sums of a window-run filter gradient: row rr*row_rlp + q of the slabs is row rr*row_rl + q of
+                         // C for q < row_rl and a pad row otherwise (not stored); row_rlp == 0: rows as they are
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p);
 

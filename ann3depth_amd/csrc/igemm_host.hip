@@ -284,6 +284,14 @@ __device__ __forceinline__ V slab_sum(const V* ws, size_t slab, int splitk, size
   return s;
 }
 
+// C position (in units of V) of slab position i when the slabs' rows are padded window runs (ReduceParams::row_rlp), or
+// SIZE_MAX for a pad row; nv = V's per row
+__device__ __forceinline__ size_t unpadded_pos(size_t i, int nv, int rl, int rlp) {
+  if (rlp == 0) return i;
+  const size_t row = i / (size_t)nv, c = i - row * (size_t)nv;
+  const size_t rr = row / (size_t)rlp, q = row - rr * (size_t)rlp;
+  return q < (size_t)rl ? (rr * (size_t)rl + q) * (size_t)nv + c : SIZE_MAX;
+}
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   const size_t total = (size_t)p.M * p.N;
   if (p.dbias_out) {       // N sums of `splitk` values: the grid's first threads do them on the side
@@ -296,7 +304,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
     const f4* ws4 = reinterpret_cast<const f4*>(p.ws);
     const size_t slab4 = p.slab / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-      reinterpret_cast<f4*>(p.C)[i] = slab_sum<f4>(ws4, slab4, p.splitk, i);
+      const size_t o = unpadded_pos(i, p.N / 4, p.row_rl, p.row_rlp);
+      if (o != SIZE_MAX) reinterpret_cast<f4*>(p.C)[o] = slab_sum<f4>(ws4, slab4, p.splitk, i);
     }
     return;
   }
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
 // one-thread sum above: a launch uses one or the other by shape alone, never by timing).
 template <typename V>
 __device__ __forceinline__ void reduce_wide(const V* src, V* dst, size_t slab, size_t count, int splitk, size_t first,
-                                            V* lds) {
+                                            V* lds, int nv = 0, int rl = 0, int rlp = 0) {
   const int tid = threadIdx.x, out = tid & 15, part = tid >> 4;
   const size_t i = first + out;
   const int per = (splitk + 15) / 16, z0 = part * per, z1 = min(splitk, z0 + per);
@@ -348,7 +357,8 @@ __device__ __forceinline__ void reduce_wide(const V* src, V* dst, size_t slab, s
     V t = lds[out];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += lds[q * 16 + out];
-    dst[i] = t;
+    const size_t o = unpadded_pos(i, nv, rl, rlp);
+    if (o != SIZE_MAX) dst[o] = t;
   }
 }
 __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const ReduceParams p, unsigned blocks_c) {
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const ReducePar
   __shared__ f4 lds[256];
   if (blockIdx.x < blocks_c)
     reduce_wide<f4>(reinterpret_cast<const f4*>(p.ws), reinterpret_cast<f4*>(p.C), p.slab / 4, (size_t)p.M * p.N / 4,
-                    p.splitk, (size_t)blockIdx.x * 16, lds);
+                    p.splitk, (size_t)blockIdx.x * 16, lds, p.N / 4, p.row_rl, p.row_rlp);
   else
     reduce_wide<float>(p.dbias_ws, p.dbias_out, (size_t)p.N, (size_t)p.N, p.splitk, (size_t)(blockIdx.x - blocks_c) * 16,
                        reinterpret_cast<float*>(lds));
@@ -461,6 +471,10 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     r.dbias_ws = final_dbias ? p.dbias : nullptr;
     r.dbias_out = final_dbias;
+    if (r.vec4 && p.unpad_dst && p.unpad_rlp > 0 && p.N % 4 == 0 && aligned16(p.unpad_dst)) {
+      r.C = p.unpad_dst; r.row_rl = p.unpad_rl; r.row_rlp = p.unpad_rlp;
+      p.unpad_done = 1;
+    }
     rc = launch_splitk_reduce(r, st);
   }
   return rc;
@@ -1066,8 +1080,9 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
                  (unsigned long long)d->n * d->ho * d->wo * d->ldy, d->r, run ? 1 : d->s, inside ? d->r : 0,
                  inside ? d->s : 0);
   }
+  if (run) { p.unpad_dst = dw; p.unpad_rl = rf.rl; p.unpad_rlp = rf.rlp; }
   rc = launch_igemm(MODE_BWD_F, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
-  if (rc != A3D_OK || !run) return rc;
+  if (rc != A3D_OK || !run || p.unpad_done) return rc;       // the split-K reduction stored the unpadded filter itself
   clear_stale_error();
   hipLaunchKernelGGL(unpad_filter_kernel, dim3((d->r * rf.rl * d->k + 255) / 256), dim3(256), 0, st, out, dw, d->r,
                      rf.rl, rf.rlp, d->k);
