@@ -243,25 +243,43 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
     a_base = Abase + boff;
     a_bytes = (a_total - boff) * 4ull;
   }
+  // ---- k-tile table (FWD / BWD_D, wave-uniform taps): what changes from k-tile to k-tile — the tap's (dy, dx), the A
+  // gather's byte offset, the B tile's byte offset — is decoded ONCE per block, one thread per k-tile, into the unused
+  // half of the row table; the loop reads one 16-byte entry (broadcast) instead of redoing ~70 scalar instructions per
+  // wave and tile on the CU's one scalar unit (16 waves: more scalar cycles per tile than its 8 MFMAs take).  The entry
+  // past the last tile makes every offset out of range: the loads of a tile that does not exist return zeros.
+  int4* kttab = pixtab + Cfg::PIX;
+  const bool use_tab = (MODE != MODE_BWD_F) && t_uni && nkt + 1 <= Cfg::PIX && b_total * 4ull < 0x80000000ull;
+  if (use_tab && tid <= nkt) {
+    int4 e = {0, 0, (int)kOOB, (int)kOOB};
+    if (tid < nkt) {
+      const uint32_t c1 = fdiv((uint32_t)(kt_begin + tid), p.div_taps), r1 = (uint32_t)(kt_begin + tid) - c1 * (uint32_t)p.ntaps;
+      const uint32_t r2 = fdiv((uint32_t)(kt_begin + tid), t_div_cpt), c2 = (uint32_t)(kt_begin + tid) - r2 * (uint32_t)t_cpt;
+      const uint32_t trs = t_kperm ? r1 : r2, chunk = t_kperm ? c1 : c2;
+      const uint32_t r = fdiv(trs, p.div_s), sx = trs - r * p.div_s.d;
+      e.x = SGN * (int)r;
+      e.y = SGN * (int)sx;
+      e.z = ((e.x * pW + e.y) * pldA + (int)chunk * AKS) * 4;
+      if constexpr (MODE == MODE_BWD_D) {
+        const uint32_t rs = (p.tap_r0 + p.sub_step * r) * p.S_full + p.tap_s0 + p.sub_step * sx;
+        e.w = (int)((rs * (uint32_t)(p.Cn * pB.Cg) + (uint32_t)n0 * (uint32_t)pB.Cg + chunk * (uint32_t)BKS) * 4u);
+      } else {
+        const int ldb_vv = B16 ? p.ldb / 2 : p.ldb;
+        e.w = (int)((trs * (uint32_t)p.Cg + chunk * (uint32_t)BK) * (uint32_t)ldb_vv * 4u);
+      }
+    }
+    kttab[tid] = e;
+  }
   __syncthreads();
   if constexpr (MODE != MODE_BWD_F) {
 #pragma unroll
     for (int j = 0; j < A_NL; ++j) {
       const int4 pt = pixtab[a_r0 + j * A_RPP];
-      a_rowoff[j] = pt.x + (t_uni ? a_cq * 16 : 0);
+      a_rowoff[j] = pt.x + (use_tab ? a_cq * 16 : 0);
       a_y0[j] = pt.w ? pt.y : -(1 << 30);
       a_x0[j] = pt.z;
     }
   }
-  struct TapPos { uint32_t rs, chunk; };
-  auto tap_of = [&](int kt) -> TapPos {
-    const uint32_t c1 = fdiv((uint32_t)kt, p.div_taps), r1 = (uint32_t)kt - c1 * (uint32_t)p.ntaps;
-    const uint32_t r2 = fdiv((uint32_t)kt, t_div_cpt), c2 = (uint32_t)kt - r2 * (uint32_t)t_cpt;
-    TapPos t;
-    t.rs = t_kperm ? r1 : r2;
-    t.chunk = t_kperm ? c1 : c2;
-    return t;
-  };
   // a bf16 B tile is read in 16-byte chunks up to its row stride: pad columns (fine/first's 64th channel) are zeros
   const int ldb_v = B16 ? p.ldb / 2 : p.ldb, n0_v = B16 ? n0 / 2 : n0, nn_v = B16 ? p.ldb / 2 : p.N;
   constexpr int B_CPR = BTile::CPR;
@@ -296,6 +314,7 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
     const int kt = kt_real;
 #endif
     __amdgpu_buffer_rsrc_t rsA, rsB;
+    uint32_t tab_boff = 0;        // UNI: byte offset of the B tile (k-tile table)
     // ---------- A ----------
     if constexpr (MODE == MODE_BWD_F) {
       const int pix0 = kt * BK;
@@ -314,17 +333,16 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
       int dy, dx, coloff;
       bool cv = true;
       if constexpr (UNI) {
-        const TapPos t = tap_of(kt);
-        const uint32_t r = fdiv(t.rs, p.div_s), sx = t.rs - r * p.div_s.d;
-        dy = SGN * (int)r; dx = SGN * (int)sx;
-        coloff = ((dy * pW + dx) * pldA + (int)t.chunk * AKS) * 4;
+        const int4 e = kttab[live ? kt - kt_begin : nkt];      // one address for the whole wave: a broadcast read
+        dy = e.x; dx = e.y; coloff = e.z;
+        tab_boff = (uint32_t)e.w;
       } else {
         const ColDec d = decode_col(pA, kt * AKS + a_cq * 4);
         dy = SGN * d.r; dx = SGN * d.s;
         coloff = ((dy * pW + dx) * pldA + d.c) * 4;
         cv = d.valid;
       }
-      rsA = make_rsrc(a_base, live ? a_bytes : 0ull);
+      rsA = make_rsrc(a_base, (UNI || live) ? a_bytes : 0ull);     // table entries past the end point out of range
 #pragma unroll
       for (int j = 0; j < A_NL; ++j) {
         const int y = a_y0[j] + dy, x = a_x0[j] + dx;
@@ -336,14 +354,10 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
     if constexpr (MODE == MODE_BWD_D) {
       // filter W[rs][cin][cout] read as rows = cin, columns = k = (rs, cout), in view floats
       if constexpr (UNI) {
-        const TapPos t = tap_of(kt);
-        const uint32_t rp = fdiv(t.rs, p.div_s), sp = t.rs - rp * p.div_s.d;
-        const uint32_t rs = (p.tap_r0 + p.sub_step * rp) * p.S_full + p.tap_s0 + p.sub_step * sp;
-        const unsigned long long boff = (unsigned long long)rs * (unsigned long long)(p.Cn * pB.Cg) +
-                                        (unsigned long long)n0 * pB.Cg + t.chunk * BKS;
-        rsB = make_rsrc(p.B + boff, live ? (b_total - boff) * 4ull : 0ull);
+        rsB = make_rsrc(p.B, b_total * 4ull);                     // the tile's offset comes from the table
 #pragma unroll
-        for (int j = 0; j < BTile::NL; ++j) load_vec_buf<4>(rsB, b_voff[j], rb[j]);
+        for (int j = 0; j < BTile::NL; ++j)
+          load_vec_buf<4>(rsB, ((b_voff[j] | tab_boff) >> 31) ? kOOB : b_voff[j] + tab_boff, rb[j]);
       } else {
         const int kcol = kt * BKS + b_cq * 4;
         const bool kvalid = kcol < pB.K;
@@ -359,12 +373,18 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
           load_vec_buf<4>(rsB, (kvalid && b_voff[j] != kOOB) ? base + (b_voff[j] - (uint32_t)(b_cq * 16)) : kOOB, rb[j]);
       }
     } else {
-      // plain [K][ldb] tile at rows row0.., columns n0..: the descriptor is re-based and ends with row K-1
-      int row0 = kt * BK;
       if constexpr (MODE == MODE_FWD && UNI) {
-        const TapPos t = tap_of(kt);
-        row0 = (int)(t.rs * (uint32_t)p.Cg + t.chunk * BK);
+        // columns n0.. of the whole [K][ldb] filter; the tile's first row comes from the table (rows past K - 1 lie
+        // past the descriptor's end)
+        const long long rec = ((long long)p.K * ldb_v - n0_v) * 4ll;
+        rsB = make_rsrc(p.B + n0_v, (unsigned long long)(rec > 0 ? rec : 0ll));
+#pragma unroll
+        for (int j = 0; j < BTile::NL; ++j)
+          load_vec_buf<4>(rsB, ((b_voff[j] | tab_boff) >> 31) ? kOOB : b_voff[j] + tab_boff, rb[j]);
+        return;
       }
+      // plain [K][ldb] tile at rows row0.., columns n0..: the descriptor is re-based and ends with row K-1
+      const int row0 = kt * BK;
       const int rows = p.K - row0;
       const long long rec = ((long long)(rows > 0 ? rows : 0) * ldb_v - n0_v) * 4ll;
       rsB = make_rsrc(p.B + ((unsigned long long)row0 * (unsigned long long)ldb_v + (unsigned long long)n0_v),
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
   if constexpr (MODE == MODE_BWD_F) {
     k_loop(std::false_type{});
   } else {
-    if (t_uni) k_loop(std::true_type{});
+    if (use_tab) k_loop(std::true_type{});       // wave-uniform taps through the k-tile table
     else k_loop(std::false_type{});
   }
 
