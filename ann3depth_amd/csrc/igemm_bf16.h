@@ -413,18 +413,28 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
   };
 
   auto k_loop = [&](auto uni_c) {
+  // FWD / BWD_D: a tile's loads are in flight for a whole iteration — requested at the top of iteration it - 1 (right
+  // after the registers they land in were parked in LDS), parked at the top of iteration it, read from LDS in iteration
+  // it + 1.  (BWD_F keeps the shorter schedule below: its row table is double-buffered on the same cadence.)
+  constexpr bool EARLY = MODE != MODE_BWD_F;
   if (nkt > 0) {
     stage(uni_c, kt_begin, 0, true);
     add_bias();
     store_tiles(0);
   }
+  if constexpr (EARLY) stage(uni_c, kt_begin + 1, 1, nkt > 1);
   __syncthreads();
 
   int cur = 0;
   for (int it = 0; it < nkt; ++it) {
     const int kt = kt_begin + it;
     const bool more = it + 1 < nkt;
-    stage(uni_c, kt + 1, (it + 1) & 1, more);        // a tile that does not exist: descriptors of 0 records
+    if constexpr (EARLY) {
+      if (more) store_tiles(cur ^ 1);              // tile it + 1; buffer cur ^ 1 was last read before the barrier above
+      stage(uni_c, kt + 2, 0, it + 2 < nkt);       // a tile that does not exist: offsets out of range / 0 records
+    } else {
+      stage(uni_c, kt + 1, (it + 1) & 1, more);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == MODE_BWD_F) {
       if (tid < Cfg::PIX) pixtab[(it & 1) * Cfg::PIX + tid] = row_entry((kt + 2) * BK + tid, image_of((kt + 2) * BK));
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
           if (X3) b_lo[b] = frag_tr(bl, Cfg::B_LD, bcol0, 16 * s, lane);
         }
       }
-      if (s == BK / 16 - 1 && more) {
+      if (!EARLY && s == BK / 16 - 1 && more) {
         add_bias();
         store_tiles(cur ^ 1);
       }

@@ -91,8 +91,8 @@ static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
 static const int kFirstGldsCfg = 9;
 
 // bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
-// (even at one block per CU for the two-plane x3 variant), and ~600 blocks with >= 12 k-tiles each fill the chip
-// (sweep: profiles/r01_sweep_bf16.txt).
+// (even at one block per CU for the two-plane x3 variant); split-K factors: x3 by round 1's sweep
+// (profiles/r01_sweep_bf16.txt: ~600 blocks with >= 12 k-tiles each), plain bf16 by round 3's, below.
 static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   GemmPlan pl{};
   pl.prec = precision;
@@ -104,6 +104,15 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   const int nk = std::max(1, (g.K + bk - 1) / bk);
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int splitk = (int)std::min<long>(std::max<long>(768 / tiles, 1), std::max(1, nk * (bk / 32) / 12));
+  if (precision == A3D_PREC_BF16) {
+    // Plain bf16 kernel, measured (profiles/r03_bf16_splitk_sweep.txt): one 128 x 128 block keeps a CU's staging path
+    // nearly as busy as two do (0.87 us per k-tile alone, 1.47 us each when two share the CU), so splitting K pays only
+    // until every CU has ONE block (two of the lighter 128 x 64 ones); past that it just adds a slab of the whole
+    // output per factor (conv2d_2 / conv2d_3 forward and bwd-data at batch 64: 351 tiles, 53 / 71 us unsplit against
+    // 72 / 85 us split in two).
+    const long target = pl.bf16_bn == 128 ? 256 : 512;
+    splitk = (int)std::min<long>(std::max<long>(target / tiles, 1), std::max(1, nk / 4));
+  }
   if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
