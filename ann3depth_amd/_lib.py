@@ -86,6 +86,7 @@ SIGNATURES = {
     'a3d_copy_channel': (c_int, [c_size_t, _P, c_int, c_int, _P, c_int, c_int, _P]),
     'a3d_timing_enable': (c_int, [c_int]),
     'a3d_timing_collect': (c_int, [POINTER(TimingRecord), c_int]),
+    'a3d_timing_select': (c_int, [POINTER(TimingRecord)]),
     'a3d_crc32c': (c_uint32, [_P, c_size_t]),
     'a3d_masked_crc32c': (c_uint32, [_P, c_size_t]),
     'a3d_tfrecord_next': (c_int, [_P, c_size_t, c_int, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t)]),

@@ -85,7 +85,30 @@ struct TimingSlot {
 };
 static std::mutex g_timing_mu;
 static bool g_timing_on = false;
+static bool g_timing_only = false;          // a3d_timing_select: bracket only launches of one kernel
+static a3d_timing_record g_timing_like{};
 static std::vector<TimingSlot> g_timing;
+
+// Is this launch to be bracketed?  `r` names the kernel about to be launched.
+static bool timing_wanted(const a3d_timing_record& r) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  if (!g_timing_on) return false;
+  if (!g_timing_only) return true;
+  const a3d_timing_record& l = g_timing_like;
+  return r.mode == l.mode && r.prec == l.prec && r.bm == l.bm && r.bn == l.bn && r.waves_m == l.waves_m &&
+         r.nwaves == l.nwaves && r.bk == l.bk && r.avec == l.avec && r.bvec == l.bvec && r.lds_dma == l.lds_dma;
+}
+static int timing_begin(TimingSlot& slot, hipStream_t st) {
+  if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
+    return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
+  (void)hipEventRecord(slot.start, st);
+  return A3D_OK;
+}
+static void timing_end(TimingSlot& slot, hipStream_t st) {
+  (void)hipEventRecord(slot.stop, st);
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing.push_back(slot);
+}
 static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
 static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
 static const int kFirstGldsCfg = 9;
@@ -433,22 +456,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d%s grid %u\n", mode, p.M, p.N, p.K,
             plan.cfg, kCfgs[plan.cfg].bm, kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, plan.sk_sliced ? " (K-sliced)" : "", grid);
   TimingSlot slot{};
-  bool timed = false;
   {
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    timed = g_timing_on;
-  }
-  if (timed) {
-    if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
-      return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
-    (void)hipEventRecord(slot.start, st);
-  }
-  if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
-  else if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
-  else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
-  else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
-  if (timed) {
-    (void)hipEventRecord(slot.stop, st);
     a3d_timing_record& r = slot.rec;
     r.mode = mode; r.prec = plan.prec;
     if (plan.prec != A3D_PREC_F32) {
@@ -460,9 +468,14 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     }
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    g_timing.push_back(slot);
   }
+  const bool timed = timing_wanted(slot.rec);
+  if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+  if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
+  else if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
+  else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
+  else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
+  if (timed) timing_end(slot, st);
   if (rc != A3D_OK) return rc;
   if (plan.streamk > 0) {
     const unsigned tiles = (unsigned)(plan.tiles_m * plan.tiles_n);
@@ -668,6 +681,13 @@ int a3d_timing_enable(int on) {
   return A3D_OK;
 }
 
+int a3d_timing_select(const a3d_timing_record* like) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing_only = like != nullptr;
+  if (like) g_timing_like = *like;
+  return A3D_OK;
+}
+
 int a3d_timing_collect(a3d_timing_record* out, int cap) {
   std::vector<TimingSlot> slots;
   {
@@ -784,27 +804,17 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     return conv_fwd_bf16_image(d, x, w, bias, y, act, ws, ws_bytes, st);
   if (conv3_applicable(d, x)) {                  // few-channel layers: operands straight from L2 (conv3.hip)
     TimingSlot slot{};
-    bool timed = false;
     {
-      std::lock_guard<std::mutex> lk(g_timing_mu);
-      timed = g_timing_on;
-    }
-    if (timed) {
-      if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
-        return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
-      (void)hipEventRecord(slot.start, st);
-    }
-    rc = conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
-    if (timed) {
-      (void)hipEventRecord(slot.stop, st);
       a3d_timing_record& r = slot.rec;
       r.mode = MODE_FWD; r.prec = A3D_PREC_F32; r.bm = 64; r.bn = d->k > 64 ? 96 : 64; r.waves_m = 1; r.nwaves = 1; r.bk = 8;
       r.avec = 4; r.bvec = 4; r.splitk = 1; r.lds_dma = 2;          // 2: conv3_fwd_kernel (filter repack included in ms)
       r.m = pool ? d->n * (d->ho / 2) * (d->wo / 2) * 4 : d->n * d->ho * d->wo; r.n = d->k; r.k = d->r * d->s * d->c; r.ms = 0.f;
       r.flops = 2.0 * r.m * r.n * r.k;
-      std::lock_guard<std::mutex> lk(g_timing_mu);
-      g_timing.push_back(slot);
     }
+    const bool timed = timing_wanted(slot.rec);
+    if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+    rc = conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+    if (timed) timing_end(slot, st);
     return rc;
   }
   GemmProblem g = fwd_problem(d);
@@ -1001,27 +1011,17 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       return A3D_OK;
     }
     TimingSlot slot{};
-    bool timed = false;
     {
-      std::lock_guard<std::mutex> lk(g_timing_mu);
-      timed = g_timing_on;
-    }
-    if (timed) {
-      if (hipEventCreate(&slot.start) != hipSuccess || hipEventCreate(&slot.stop) != hipSuccess)
-        return set_error(A3D_ELAUNCH, "timing: hipEventCreate failed");
-      (void)hipEventRecord(slot.start, st);
-    }
-    rc = launch_igemm_multi_bwd_d(multi_avec, multi_bvec, multi, multi_grid, (unsigned)n_multi, st);
-    if (timed) {
-      (void)hipEventRecord(slot.stop, st);
       a3d_timing_record& r = slot.rec;
       r.mode = MODE_BWD_D; r.prec = A3D_PREC_F32; r.bm = 64; r.bn = 64; r.waves_m = 2; r.nwaves = 4; r.bk = 32;
       r.avec = multi_avec; r.bvec = multi_bvec; r.splitk = 1; r.lds_dma = 0;
       r.m = d->n * d->h * d->w; r.n = d->c; r.k = d->r * d->s * d->k; r.ms = 0.f;
       r.flops = multi_flops;
-      std::lock_guard<std::mutex> lk(g_timing_mu);
-      g_timing.push_back(slot);
     }
+    const bool timed = timing_wanted(slot.rec);
+    if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+    rc = launch_igemm_multi_bwd_d(multi_avec, multi_bvec, multi, multi_grid, (unsigned)n_multi, st);
+    if (timed) timing_end(slot, st);
     return rc;
   }
   return A3D_OK;

@@ -269,7 +269,8 @@ int a3d_crf_loss(int n, int nsp, const float* z, const float* y, const float* r,
 int a3d_sgd_apply(size_t count, float* var, const float* g, float lr, void* stream);
 
 /* ---- opt-in kernel timing for bench.py's roofline line (the only process-global state in the library) ----
- * While enabled, every implicit-GEMM launch (conv / dense, any direction) is bracketed by a hipEvent pair recorded
+ * While enabled, every implicit-GEMM launch (conv / dense, any direction; or one kernel's: a3d_timing_select) is
+ * bracketed by a hipEvent pair recorded
  * on the launch stream.  a3d_timing_collect() synchronises those events, returns up to `cap` records (oldest first),
  * and clears the list.  Not for use inside graph capture. */
 typedef struct a3d_timing_record {
@@ -285,6 +286,11 @@ typedef struct a3d_timing_record {
 } a3d_timing_record;
 int a3d_timing_enable(int on);
 int a3d_timing_collect(a3d_timing_record* out, int cap);
+/* Bracket only launches of ONE kernel: the one `like` names by its template fields (mode, prec, bm, bn, waves_m, nwaves,
+ * bk, avec, bvec, lds_dma; the other fields are ignored); NULL = every launch again.  An event pair per launch costs the
+ * stream a few microseconds (30 GEMM launches per step: 3.5 % of the fp32 step, 8 % of the bf16-storage one), so
+ * bench.py times every kernel during its warm-up steps and, inside the timed region, only the dominant one. */
+int a3d_timing_select(const a3d_timing_record* like);
 
 /* ---- host side of the dataset plugin: TFRecord container + tf.train.Example (src/data.py:62-86,
  *      tools/data_tf_converter.py:27-53) ---- */

@@ -614,3 +614,44 @@ def test_fuzz_of_forced_plans_in_a_tuning_process():
                        timeout=300, cwd=root)
     assert r.returncode == 0 and 'FAIL' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert int(r.stdout.strip().splitlines()[-1].split()[0]) > 200
+
+
+def test_timing_brackets_every_launch_or_one_kernel(ops):
+    """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
+    bracketed, then brackets only that kernel inside its timed region."""
+    from ann3depth_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    small = ops.conv_desc(2, 13, 18, 64, 64, 3, 3, 1, 'SAME')          # a 64 x 64 tile configuration
+    big = ops.conv_desc(16, 27, 37, 96, 256, 5, 5, 1, 'SAME')          # a 128 x 128 one
+    args = {}
+    for name, d in (('small', small), ('big', big)):
+        x = dev(rng.standard_normal((d.n, d.h, d.w, d.c)).astype(np.float32))
+        w = dev(rng.standard_normal((d.r, d.s, d.c, d.k)).astype(np.float32))
+        args[name] = (d, x, w, dev(np.zeros(d.k, np.float32)), torch.empty((d.n, d.ho, d.wo, d.k), device='cuda'))
+
+    def collect():
+        arr = (_lib.TimingRecord * 64)()
+        return [arr[i] for i in range(lib.a3d_timing_collect(arr, 64))]
+
+    def run():
+        lib.a3d_timing_enable(1)
+        for name in ('small', 'big', 'small'):
+            ops.conv2d_fwd(*args[name], None)
+        torch.cuda.synchronize()
+        lib.a3d_timing_enable(0)
+        return collect()
+
+    try:
+        every = run()
+        assert len(every) == 3 and every[0].bm * every[0].bn < every[1].bm * every[1].bn
+        assert all(r.ms > 0 for r in every)
+        lib.a3d_timing_select(every[1])
+        only = run()
+        assert len(only) == 1 and (only[0].bm, only[0].bn, only[0].m) == (every[1].bm, every[1].bn, every[1].m) and only[0].ms > 0
+        lib.a3d_timing_select(None)
+        assert len(run()) == 3
+    finally:
+        lib.a3d_timing_enable(0)
+        lib.a3d_timing_select(None)
+        collect()
