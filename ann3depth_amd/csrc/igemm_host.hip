@@ -514,13 +514,23 @@ struct RunForm {
   int rl, rlp;  // run length S*Cin and its padded length
   int kp;       // R * rlp
 };
-static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
+// bwd_filter: the filter-gradient GEMM may also take runs that start at any 4-byte address (DCNF's first conv: stride 1,
+// runs 12 bytes apart) as 8-byte buffer loads — the hardware only asks a multi-dword buffer load for dword alignment —
+// and runs whose padding reaches past the row's end: what a pad element multiplies ends up in a pad row of the padded
+// gradient, which is never stored (past the tensor's end the descriptor returns zeros).
+static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf, bool bwd_filter = false) {
   if (d->pad_t || d->pad_l || d->ldx != d->c || d->c % 4 == 0 || d->c > 4) return false;
   if (tune_int("A3D_NO_RUNFORM", 0)) return false;
   const int step = d->stride * d->c, row = d->w * d->c;
   int vec = 0;
+  bool anywhere = false;
   if (step % 4 == 0 && row % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) vec = 4;
   else if (step % 2 == 0 && row % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) vec = 2;
+  else if (bwd_filter && d->precision == A3D_PREC_F32 && !d->storage && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
+           !tune_int("A3D_NO_RUNFORM_ANYWHERE", 0)) {
+    vec = 2;
+    anywhere = true;
+  }
   if (vec == 4 && d->precision == A3D_PREC_F32) {      // (the bf16 kernels take 16-byte operands only)
     // 8-byte runs pad less (conv2d_0: 33 -> 34 instead of 36 floats per filter row).  Worth the narrower loads when it
     // saves a whole 128-row tile of the bwd-filter GEMM (374 vs 396 rows: 3 tiles instead of 4; 172 -> 148 us, and the
@@ -534,7 +544,10 @@ static bool run_form_ok(const a3d_conv_desc* d, const float* x, RunForm* rf) {
   rf->rl = d->s * d->c;
   rf->rlp = (rf->rl + vec - 1) / vec * vec;
   rf->kp = d->r * rf->rlp;
-  return (d->wo - 1) * step + rf->rlp <= row;      // the padded run of the last output column stays inside its row
+  // the padded run of the last output column stays inside its row; `anywhere`: the run itself does (no implicit padding
+  // on the right / below: a SAME convolution with an even kernel has pad_t = pad_l = 0 and still pads), its padding may not
+  if (anywhere) return (d->wo - 1) * step + rf->rl <= row && (d->ho - 1) * d->stride + d->r <= d->h;
+  return (d->wo - 1) * step + rf->rlp <= row;
 }
 
 // filter [R*RL][N] <-> padded [R*RLP][N] (pad rows zero)
@@ -1033,7 +1046,7 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   GemmPlan plan = plan_gemm(bwd_f_problem(d), d->precision);
   size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
   RunForm rf;
-  if (run_form_ok(d, nullptr, &rf)) {
+  if (run_form_ok(d, nullptr, &rf, true)) {
     GemmProblem g = bwd_f_problem(d);
     g.M = rf.kp; g.avec = rf.vec;
     GemmPlan pr = plan_gemm(g, d->precision);
@@ -1056,7 +1069,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(dz)) g.bvec = 1;
   RunForm rf{};
-  const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
+  const bool run = run_form_ok(d, x, &rf, true) && ws && ws_bytes >= run_filter_bytes(d, rf);
   size_t ws_used = 0;
   float* out = dw;
   if (run) {                                   // window-run form: gradient of the PADDED filter, unpadded afterwards
