@@ -129,8 +129,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane, int ld, int col0,
 // it is gathered through its float view (half as many "channels", 16-byte chunks of 8 bf16) and lands in the LDS plane
 // unconverted.  C16: the output tensor (and, in BWD_D, the ReluGrad mask, which is the same activation) is bf16; split-K
 // slabs and filter gradients stay fp32.
-template <int MODE, int BM, int BN, bool X3, bool A16 = false, bool B16 = false, bool C16 = false>
-__global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm_bf16_kernel(const IgemmParams p) {
+// The whole GEMM of one block: `nwg` blocks work on problem `p`, this one is number `bid_in`.
+template <int MODE, int BM, int BN, bool X3, bool A16, bool B16, bool C16>
+__device__ __forceinline__ void igemm_bf16_body(const IgemmParams& p, const uint32_t nwg, const uint32_t bid_in) {
   using Cfg = Bf16Cfg<MODE, BM, BN, X3>;
   constexpr int BK = Cfg::BK, NT = Cfg::NT, TM = Cfg::TM, TN = Cfg::TN;
   constexpr bool TRANSPOSED = (MODE == MODE_BWD_D);
@@ -161,8 +162,7 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
 
-  const uint32_t nwg = gridDim.x;
-  uint32_t bid = blockIdx.x;
+  uint32_t bid = bid_in;
   {
     uint32_t q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -550,6 +550,22 @@ __global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm
       else Cout[o] = val;
     }
   }
+}
+
+template <int MODE, int BM, int BN, bool X3, bool A16 = false, bool B16 = false, bool C16 = false>
+__global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm_bf16_kernel(const IgemmParams p) {
+  igemm_bf16_body<MODE, BM, BN, X3, A16, B16, C16>(p, gridDim.x, blockIdx.x);
+}
+
+// Up to four independent problems in ONE launch (blockIdx.y selects the problem), as igemm_multi_kernel: the parity
+// classes of a strided bwd-data (conv2d_4 at batch 64: four GEMMs of 96 tiles each, 14 - 40 us plus a split-K reduction
+// apiece as separate launches).
+template <int MODE, int BM, int BN, bool X3, bool A16, bool B16, bool C16>
+__global__ __launch_bounds__(64 * A3D_BF16_WAVES, A3D_BF16_WAVES / 2) void igemm_bf16_multi_kernel(const IgemmMulti ps) {
+  const IgemmParams& p = ps.p[blockIdx.y];
+  const uint32_t nwg = (uint32_t)(p.tiles_m * p.tiles_n * p.splitk);
+  if (blockIdx.x >= nwg) return;
+  igemm_bf16_body<MODE, BM, BN, X3, A16, B16, C16>(p, nwg, blockIdx.x);
 }
 
 }  // namespace a3d

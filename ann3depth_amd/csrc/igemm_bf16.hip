@@ -48,6 +48,27 @@ static int launch_bf16_mode(int bn, bool x3, IgemmParams& p, unsigned grid, hipS
   return launch_bf16_bn<MODE, 64>(x3, p, grid, st);
 }
 
+// the parity classes of a strided bwd-data on bf16-stored tensors (dz, filter copy and dx all bf16) as one launch
+template <int BN>
+static int launch_bf16_multi_one(IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st) {
+  using Cfg = Bf16Cfg<MODE_BWD_D, 128, BN, false>;
+  auto kern = igemm_bf16_multi_kernel<MODE_BWD_D, 128, BN, false, true, true, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  clear_stale_error();
+  hipLaunchKernelGGL(kern, dim3(grid_x, count), dim3(Cfg::NT), Cfg::LDS_BYTES, st, ps);
+  return check_launch("igemm_bf16_multi");
+}
+int launch_igemm_bf16_multi_bwd_d(int bn, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st) {
+  if (bn == 128) return launch_bf16_multi_one<128>(ps, grid_x, count, st);
+  return launch_bf16_multi_one<64>(ps, grid_x, count, st);
+}
+
 int launch_igemm_bf16(int mode, int bn, bool x3, IgemmParams& p, unsigned grid, hipStream_t st) {
   if (mode == MODE_FWD) return launch_bf16_mode<MODE_FWD>(bn, x3, p, grid, st);
   if (mode == MODE_BWD_D) return launch_bf16_mode<MODE_BWD_D>(bn, x3, p, grid, st);

@@ -22,6 +22,7 @@ int launch_fixup_mode0(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, h
 int launch_fixup_mode1(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_fixup_mode2(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
+int launch_igemm_bf16_multi_bwd_d(int bn, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
 
 struct TileCfg {
   int bm, bn;
@@ -959,6 +960,11 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   double multi_flops = 0;
   const bool try_multi = d->stride == 2 && d->precision == A3D_PREC_F32 && !d->storage && !tune_int("A3D_NO_MULTI", 0) &&
                          tune_int("A3D_FORCE_CFG", -1) < 0;
+  // ... and on bf16-stored tensors (BASELINE config 5's conv2d_4): one launch of the bf16 kernel's 128-row tiles
+  const int all16 = A3D_STORE_X_BF16 | A3D_STORE_W_BF16 | A3D_STORE_Y_BF16;
+  const bool try_multi16 = d->stride == 2 && d->precision == A3D_PREC_BF16 && (d->storage & all16) == all16 && vec_ok_a &&
+                           vec_ok_b && !tune_int("A3D_NO_MULTI", 0) && tune_int("A3D_FORCE_SPLITK", 0) <= 0;
+  int multi16_bn = 0;
   for (int ph = 0; ph < d->stride; ++ph) {
     for (int pw = 0; pw < d->stride; ++pw) {
       BwdDClass c;
@@ -979,6 +985,11 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
         plan.cfg = 4; plan.splitk = 1; plan.ktiles_per_split = std::max(1, (g.K + 31) / 32);
         plan.tiles_m = (g.M + 63) / 64; plan.tiles_n = (g.N + 63) / 64;
       }
+      const bool multi16 = try_multi16 && plan.prec == A3D_PREC_BF16;
+      if (multi16) {                                     // the bf16 kernel's tiles, no split-K
+        multi16_bn = plan.bf16_bn;
+        plan.splitk = 1; plan.ktiles_per_split = std::max(1, (g.K + 63) / 64); plan.ws_bytes = 0;
+      }
       if (plan.ws_bytes > ws_bytes)
         return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
       p.M = g.M; p.N = g.N; p.K = g.K;
@@ -995,7 +1006,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       p.outW = d->w; p.outHW = d->h * d->w;
       fill_staging(p, MODE_BWD_D, (unsigned long long)d->n * d->ho * d->wo * d->ldy,
                    (unsigned long long)d->r * d->s * d->c * d->k, c.rp, c.sp, 0, 0);
-      if (try_multi) {
+      if (try_multi || multi16) {
         p.splitk = 1; p.ktiles_per_split = plan.ktiles_per_split; p.tiles_m = plan.tiles_m; p.tiles_n = plan.tiles_n;
         p.slab = (size_t)p.M * p.N;
         multi.p[n_multi++] = p;
@@ -1008,6 +1019,21 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       rc = launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, st);
       if (rc != A3D_OK) return rc;
     }
+  }
+  if (try_multi16 && n_multi > 0) {
+    TimingSlot slot{};
+    {
+      a3d_timing_record& r = slot.rec;
+      r.mode = MODE_BWD_D; r.prec = A3D_PREC_BF16; r.bm = 128; r.bn = multi16_bn; r.waves_m = 4; r.nwaves = 8; r.bk = 64;
+      r.avec = 4; r.bvec = 4; r.splitk = 1; r.lds_dma = 0;
+      r.m = d->n * d->h * d->w; r.n = d->c; r.k = d->r * d->s * d->k; r.ms = 0.f;
+      r.flops = multi_flops;
+    }
+    const bool timed = timing_wanted(slot.rec);
+    if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+    rc = launch_igemm_bf16_multi_bwd_d(multi16_bn, multi, multi_grid, (unsigned)n_multi, st);
+    if (timed) timing_end(slot, st);
+    return rc;
   }
   if (try_multi && n_multi > 0) {
     if (multi_tiles < 256) {                 // too little work for 64x64 tiles without split-K: one launch per class

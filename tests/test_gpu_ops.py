@@ -620,6 +620,32 @@ def test_fuzz_of_forced_plans_in_a_tuning_process():
     assert int(r.stdout.strip().splitlines()[-1].split()[0]) > 200
 
 
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', [(32, 13, 18, 384, 256, 3, 2, 'VALID'), (20, 31, 33, 64, 48, 3, 2, 'SAME'),
+                                                  (3, 9, 10, 8, 8, 1, 2, 'VALID')])
+def test_strided_bwd_data_on_bf16_tensors_is_one_launch(ops, n, h, w, c, k, ks, st, pad):
+    """Stride-2 bwd-data with dz, the filter copy and dx all bf16 (BASELINE config 5's conv2d_4): the parity classes run as
+    ONE launch of the bf16 kernel (igemm_bf16_multi_kernel) — here unequal classes, SAME padding, a 1 x 1 filter whose odd
+    classes receive no tap at all (zeros) — against the float64 oracle on the bf16-rounded operands: what is left is the
+    rounding of the bf16 output (2^-9 per element)."""
+    rng = np.random.default_rng(11 + h + c)
+    bf = torch.bfloat16
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, precision='bf16')
+    xb = dev(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(bf)
+    wb = dev((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)).to(bf)
+    dzb = dev(rng.standard_normal((n, d.ho, d.wo, k)).astype(np.float32)).to(bf)
+    x64, w64, dz64 = (t.float().cpu().numpy().astype(np.float64) for t in (xb, wb, dzb))
+    dd = ops.with_storage(d, ops.STORE_X | ops.STORE_W | ops.STORE_Y)
+    dx_ref = T.conv2d_bwd_data(dz64, w64, xb.shape, st, pad)
+    for mask in (None, xb):
+        dx = torch.full(xb.shape, float('nan'), device='cuda', dtype=bf)
+        ops.conv2d_bwd_data(dd, dzb, wb, dx, relu_mask=mask)
+        want = dx_ref if mask is None else dx_ref * (x64 > 0)
+        got = dx.float().cpu().numpy()
+        assert np.isfinite(got).all()
+        assert rel_l2(got, want) < 4e-3
+        assert (got[want == 0] == 0).all()                 # pixels no tap reaches, masked pixels: exact zeros
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
