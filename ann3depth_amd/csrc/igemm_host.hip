@@ -138,6 +138,7 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
     splitk = (int)std::min<long>(std::max<long>(target / tiles, 1), std::max(1, nk / 4));
   }
   if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
+  if (g.plain) splitk = 1;                      // fused pool: whole K ranges only
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
   pl.splitk = (nk + kps - 1) / kps;
@@ -766,10 +767,15 @@ __global__ __launch_bounds__(256) void pad_filter_bf16_kernel(const float* w, __
   }
 }
 static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                               void* ws, size_t ws_bytes, hipStream_t st) {
+                               int pool, int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st) {
   const int rl = d->s * 4, rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
   GemmProblem g = fwd_problem(d);
   g.K = d->r * rlp; g.avec = 4; g.bvec = 4; g.no_glds = 1;
+  const int ph = d->ho / 2, pw = d->wo / 2;
+  if (pool) {
+    g.M = d->n * ph * pw * 4;
+    g.plain = 1;
+  }
   const size_t ws_used = bf16_image_filter_bytes(d);
   GemmPlan plan = plan_gemm(g, d->precision);
   if (!ws || ws_used + plan.ws_bytes > ws_bytes)
@@ -793,6 +799,12 @@ static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const flo
   p.div_c = make_fastdiv(p.Cg); p.div_s = make_fastdiv(1);
   p.div_c_half = make_fastdiv(p.Cg / 2);
   p.ldb = np; p.ldc = d->ldy;
+  if (pool) {
+    p.pool = 1;
+    p.argmax = argmax;
+    p.div_phw = make_fastdiv(ph * pw * 4); p.div_pw = make_fastdiv(pw);
+    p.ldc = ld_out;
+  }
   fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * 4, (unsigned long long)g.K * np, d->r, 1, d->r, 1);
   return launch_igemm(MODE_FWD, plan, 4, 4, p, static_cast<char*>(ws) + ws_used, st);
 }
@@ -806,7 +818,8 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
   if (pool) {
-    A3D_CHECK_ARG(d->precision == A3D_PREC_F32, "conv2d_pool_fwd: fp32 only");
+    A3D_CHECK_ARG(d->precision == A3D_PREC_F32 || bf16_image_form_ok(d, x),
+                  "conv2d_pool_fwd: fp32, or the bf16 image form (4-channel bf16 image, a3d_pad_channels_bf16)");
     A3D_CHECK_ARG(d->ho >= 2 && d->wo >= 2 && ld_out >= d->k, "conv2d_pool_fwd: output smaller than one pool window");
     A3D_CHECK_ARG(!stencil1_applicable(d), "conv2d_pool_fwd: single-output-channel convs are not supported");
   } else if (stencil1_applicable(d)) {
@@ -814,8 +827,8 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (!pool && bf16_image_form_ok(d, x))
-    return conv_fwd_bf16_image(d, x, w, bias, y, act, ws, ws_bytes, st);
+  if (bf16_image_form_ok(d, x))
+    return conv_fwd_bf16_image(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
   if (conv3_applicable(d, x)) {                  // few-channel layers: operands straight from L2 (conv3.hip)
     TimingSlot slot{};
     {

@@ -278,9 +278,8 @@ class MSDNReplica:
             self.store['fine/second/conv2d'] = {'fwd': X | W, 'bwd_d': W | X, 'bwd_f': X}     # f2 / df2 stay fp32
             # ... except where fine/first has no backward (coarse phase, and once nothing trains any more): there its forward
             # runs on the bf16 pipe from a 4-channel bf16 copy of the image (8-byte pixels: window runs 16 bytes apart),
-            # 0.41 -> 0.10 ms at B = 64; f1 is then written (bf16) and pooled by a separate kernel
+            # 0.41 -> 0.10 ms at B = 64, conv + ReLU + max pool in one launch (f1 is never written there either)
             self.x4 = torch.empty((B, NET_H, NET_W, 4), device=dev, dtype=torch.bfloat16)
-            self.f1b = torch.empty((B, 110, 148, 64), device=dev, dtype=torch.bfloat16)
             self.w4 = torch.zeros((9, 9, 4, 63), device=dev)
             self.d4 = ops.with_storage(ops.conv_desc(B, NET_H, NET_W, 4, 63, 9, 9, 2, 'VALID', ldy=64, precision='bf16'),
                                        X | Y)
@@ -621,6 +620,10 @@ class MSDNReplica:
             ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
         self.dropout_on = keep_mask is not None            # None: the plugin was called with train=False
+        if self.bf16s and phase in (1, 3) and not (self.fuse_pool and phase in (1, 2, 3)):
+            # the fine network's 4-channel bf16 image, on the main stream: the side stream's chain (fine/first .. loss) is
+            # the longer one at the join, the main stream idles there
+            ops.pad_channels_bf16(self.x, self.x4)
         fused = self.fuse_pool and phase in (1, 2, 3)
         self.pooled_fwd = phase if fused else None
         lean_fine = fused
@@ -644,10 +647,8 @@ class MSDNReplica:
         with self._beside():        # beside the two weight-streaming dense layers
             if lean_fine:
                 self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
-            elif self.bf16s and phase in (1, 3):
-                ops.pad_channels_bf16(self.x, self.x4)
-                ops.conv2d_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.f1b, 'relu')
-                ops.maxpool2x2_fwd_bf16(self.f1b, self.cat, c=63)
+            elif self.bf16s and phase in (1, 3):        # conv + ReLU + pool in one launch: f1 is never written
+                ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu')
             elif self.bf16s:
                 self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
             else:

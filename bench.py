@@ -210,7 +210,7 @@ def hbm_bytes_bf16_storage(B):
         px(480, 640, 3, f4) + px(480, 640, 1, f4)                  # stored record, read by the resize
         + 3 * px(228, 304, 3, f4) + 3 * px(55, 74, 1, f4)          # x: written, read by conv2d_0 fwd, fine/first fwd (+ conv2d_0 bwd-filter: below); t: written, read by both losses
         + px(228, 304, 3, f4)                                      # x again: conv2d_0 bwd-filter
-        + 2 * px(228, 304, 4, b2) + 2 * px(110, 148, 63, b2)       # fine/first on the bf16 pipe: x4 and f1 (bf16), written + read
+        + 2 * px(228, 304, 4, b2)                                  # fine/first on the bf16 pipe: x4 written + read (conv + pool fused: f1 never reaches HBM)
         # forward activations, written once and read once by the next layer (bf16): p0, c1, p1, c2, c3, c4, cat; f2 fp32
         + 2 * (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
                + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4)

@@ -175,6 +175,19 @@ def test_conv_fwd_bf16_image_form(ops, n, h, w, k, ks, st, y16):
     got = y[..., :k].float().cpu().numpy()
     assert rel_l2(got, y32.cpu().numpy()) < 2e-2
     assert (y[..., k:].float().cpu().numpy() == -3.0).all()                              # pad channels are not written
+    # conv + ReLU + 2x2 max pool in one launch equals the two launches bit for bit (values are rounded to the output type
+    # before they are compared, first maximum wins), odd output sizes drop their last row / column, and the recorded
+    # position is the first maximum's
+    ph, pw = d.ho // 2, d.wo // 2
+    pooled = torch.full((n, ph, pw, ldy), -3.0, device='cuda', dtype=y.dtype)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x4, dev(w4), dev(bias), pooled, 'relu', arg)
+    torch.cuda.synchronize()
+    win = y[:, :2 * ph, :2 * pw, :k].float().reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4)
+    want, want_arg = win.max(-1).values, (win == win.max(-1, keepdim=True).values).float().argmax(-1)
+    assert torch.equal(pooled[..., :k].float(), want)
+    assert torch.equal(arg.long(), want_arg)
+    assert (pooled[..., k:].float().cpu().numpy() == -3.0).all()
 
 
 DENSE_CASES = [(32, 12288, 4096), (4, 512, 4070), (32, 4096, 4070), (7, 130, 66), (48, 12544, 128), (48, 128, 16),
