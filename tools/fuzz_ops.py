@@ -17,6 +17,7 @@ from ann3depth_amd import ops  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 TOL = 3e-6
+TOL_BF16_OUT, TOL_BF16_DW = 4e-3, 1e-4      # bf16 storage: an output rounded to bf16 (2^-9 per element); fp32 accumulation
 
 
 def rel(a, b, scale=None):
@@ -77,6 +78,53 @@ def run_conv(n, h, w, c, k, ks, st, pad):
     return err
 
 
+def run_conv_bf16s(n, h, w, c, k, ks, st, pad):
+    """bf16 storage (BASELINE config 5): x, the filter copy, y, dz and dx bf16, the filter gradient fp32 — against torch
+    float64 on the bf16-ROUNDED operands.  -> (error of the bf16 outputs, error of the fp32 filter gradient)"""
+    bf = torch.bfloat16
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, precision='bf16')
+    if d.ho <= 0 or d.wo <= 0:
+        return 0.0, 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, h, w, c), device='cuda', generator=g).to(bf)
+    wt = (torch.randn((ks, ks, c, k), device='cuda', generator=g) / np.sqrt(ks * ks * c)).to(bf)
+    b = torch.randn((k,), device='cuda', generator=g)
+    X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+    y = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=bf)
+    ops.conv2d_fwd(ops.with_storage(d, X | W | Y), x, wt, b, y, None)
+    ph = max((d.ho - 1) * st + ks - h, 0) if pad == 'SAME' else 0
+    pw = max((d.wo - 1) * st + ks - w, 0) if pad == 'SAME' else 0
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = wt.double().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    ref = F.conv2d(F.pad(xd, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wd, b.double(), stride=st)
+    e16 = rel(y.permute(0, 3, 1, 2), ref.detach())
+    dz = torch.randn((n, d.ho, d.wo, k), device='cuda', generator=g).to(bf)
+    gx, gw = torch.autograd.grad(ref, [xd, wd], dz.double().permute(0, 3, 1, 2))
+    dw = torch.full(wt.shape, float('nan'), device='cuda')
+    db = torch.full_like(b, float('nan'))
+    ops.conv2d_bwd_filter(ops.with_storage(d, X | Y), x, dz, dw, db)
+    e32 = max(rel(dw, gw.permute(2, 3, 1, 0)) if float(gw.norm()) > 0 else float(dw.abs().max()),
+              rel(db, dz.double().sum((0, 1, 2))))
+    dx = torch.full(x.shape, float('nan'), device='cuda', dtype=bf)
+    ops.conv2d_bwd_data(ops.with_storage(d, X | W | Y), dz, wt, dx)
+    e16 = max(e16, rel(dx, gx.permute(0, 2, 3, 1)) if float(gx.norm()) > 0 else float(dx.float().abs().max()))
+    return e16, e32
+
+
+def conv_case_bf16s():
+    st = int(rng.choice([1, 1, 2, 2]))
+    ks = int(rng.choice([1, 2, 3, 3, 5]))
+    pad = str(rng.choice(['SAME', 'VALID']))
+    c = int(rng.choice([8, 16, 24, 64, 96, 128, 256]))
+    k = int(rng.choice([8, 16, 48, 64, 96, 128, 200, 256]))
+    n = int(rng.integers(1, 48))
+    h = int(rng.integers(ks, 40))
+    w = int(rng.integers(ks, 40))
+    if n * h * w * max(c, k) > 2e7:
+        n = max(1, int(2e7 / (h * w * max(c, k))))
+    return n, h, w, c, k, ks, st, pad
+
+
 def run_dense():
     m = int(rng.choice([1, 2, 5, 16, 32, 33, 64, 200]))
     k = int(rng.choice([1, 3, 16, 100, 128, 1000, 4096, 12288]))
@@ -124,9 +172,17 @@ t_end = time.time() + budget
 count, worst = 0, (0.0, None)
 while time.time() < t_end:
     forced = force_plan()
-    if rng.random() < 0.25:
+    u = rng.random()
+    if u < 0.25:
         case, err = run_dense()
         case = ('dense',) + case
+    elif u < 0.45:
+        # bf16 storage on the bf16 kernels (a pinned tile configuration does not apply to them; split-K factors do)
+        os.environ.pop('A3D_FORCE_STREAMK', None)
+        case = conv_case_bf16s()
+        e16, e32 = run_conv_bf16s(*case)
+        err = max(e16 * TOL / TOL_BF16_OUT, e32 * TOL / TOL_BF16_DW)      # each judged against its own tolerance
+        case = ('conv bf16s',) + case
     else:
         case = conv_case()
         err = run_conv(*case)
