@@ -10,19 +10,23 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_share_one_gpu(tmp_path, world):
+    """tests/dp_gpu_worker.py: the data-parallel replica through the HIP kernels, the ranks sharing the box's one GPU over
+    gloo — two ranks (sums of two addends: bit for bit), and four (slices, padding and the gather of m at a world size
+    the scaling bench runs; sums to 1e-6)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / 'ok.txt')
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo')
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out], env=env))
     for p in procs:
-        assert p.wait(timeout=300) == 0
+        assert p.wait(timeout=400) == 0
     assert open(out).read() == '1'
 
 
