@@ -11,7 +11,6 @@ import os
 import socket
 import struct
 import time
-import zlib
 
 import numpy as np
 

@@ -6,7 +6,6 @@ RCCL).  Prints ONE JSON line on rank 0: whole-job images/s with inputs resident 
 kernel (HIP-event timed inside the timed region) and the CPU baseline (the numpy oracle on the host cores).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys

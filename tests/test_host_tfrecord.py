@@ -1,8 +1,6 @@
 """Host side of the dataset plugin (CPU): CRC32C, TFRecord framing and the Example wire format in liba3d.so against
 published check values, the pure-Python oracle, and google.protobuf with a dynamically built Example descriptor."""
-import ctypes
 import os
-import struct
 
 import numpy as np
 import pytest

@@ -1,7 +1,6 @@
 """TensorBoard event files (CPU): framing, Event / Summary encoding against google.protobuf with descriptors built
 here from tensorflow/core/util/event.proto + framework/summary.proto, PNG payloads against Pillow."""
 import io
-import struct
 
 import numpy as np
 

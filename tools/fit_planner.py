@@ -1,9 +1,7 @@
 """Offline check of the plan_gemm cost model against gpurun_out/sweep_full.json: prints, per problem, the measured
 time of the model's pick relative to the best measured configuration."""
 import json
-import math
 import os
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = {  # name: (bm, bn, eff)
