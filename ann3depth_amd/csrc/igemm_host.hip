@@ -727,8 +727,9 @@ static size_t bf16_image_filter_bytes(const a3d_conv_desc* d);
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
-  if (conv3_applicable(d, nullptr)) return conv3_ws_bytes(d);
+  // (a maximum over the paths a launch may take: which one it is also depends on the operands' alignment)
   size_t need = plan_gemm(fwd_problem(d), d->precision).ws_bytes;
+  if (conv3_applicable(d, nullptr)) need = std::max(need, conv3_ws_bytes(d));
   RunForm rf;
   if (run_form_ok(d, nullptr, &rf)) {
     GemmProblem g = fwd_problem(d);
@@ -1160,7 +1161,9 @@ static a3d_conv_desc dense_desc(int m, int k, int n) {
 
 size_t a3d_dense_fwd_ws_bytes(int m, int k, int n) {
   a3d_conv_desc d = dense_desc(m, k, n);
-  return std::max(a3d_conv2d_fwd_ws_bytes(&d), dense_stream_ws_bytes(m, k, n));
+  if (check_desc(&d) != A3D_OK) return 0;
+  // the GEMM a3d_dense_fwd plans (never the few-channel convolution paths: a dense layer of <= 4 inputs is still a GEMM)
+  return std::max(plan_gemm(fwd_problem(&d), A3D_PREC_F32).ws_bytes, dense_stream_ws_bytes(m, k, n));
 }
 
 int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,

@@ -191,7 +191,8 @@ def test_conv_fwd_bf16_image_form(ops, n, h, w, k, ks, st, y16):
 
 
 DENSE_CASES = [(32, 12288, 4096), (4, 512, 4070), (32, 4096, 4070), (7, 130, 66), (48, 12544, 128), (48, 128, 16),
-               (48, 16, 1), (9, 1024, 1031)]
+               (48, 16, 1), (9, 1024, 1031),
+               (64, 3, 4070), (2, 1, 8)]      # <= 4 inputs: still a GEMM (its workspace query once took the few-channel conv's)
 
 
 @pytest.mark.parametrize('m,k,n', DENSE_CASES)

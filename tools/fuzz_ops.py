@@ -129,6 +129,7 @@ def run_dense():
     m = int(rng.choice([1, 2, 5, 16, 32, 33, 64, 200]))
     k = int(rng.choice([1, 3, 16, 100, 128, 1000, 4096, 12288]))
     n = int(rng.choice([1, 2, 16, 63, 128, 1000, 4070, 4096]))
+    print('dense case', m, k, n, flush=True) if os.environ.get('FUZZ_VERBOSE') else None
     g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
     x = torch.randn((m, k), device='cuda', generator=g)
     w = torch.randn((k, n), device='cuda', generator=g) / np.sqrt(k)
@@ -174,7 +175,11 @@ while time.time() < t_end:
     forced = force_plan()
     u = rng.random()
     if u < 0.25:
-        case, err = run_dense()
+        try:
+            case, err = run_dense()
+        except Exception:
+            print('EXCEPTION in a dense case under', forced, {k: v for k, v in os.environ.items() if k.startswith('A3D_')}, flush=True)
+            raise
         case = ('dense',) + case
     elif u < 0.45:
         # bf16 storage on the bf16 kernels (a pinned tile configuration does not apply to them; split-K factors do)
