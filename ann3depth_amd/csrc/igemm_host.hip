@@ -192,9 +192,15 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
   const int force_cfg = tune_int("A3D_FORCE_CFG", -1), force_split = tune_int("A3D_FORCE_SPLITK", -1);
   const int force_streamk = std::min(tune_int("A3D_FORCE_STREAMK", 0), 1024);      // tuning aid: stream-K with this many blocks (the fixup lists at most 1024 contributors per tile)
   if (force_cfg >= 0 && force_cfg < kNumCfgs) {
+    // a pinned configuration still has to be one this problem can run on: the LDS-DMA kernels are forward-only, take
+    // 16-byte operands, and have neither the pooling epilogue nor a bf16 output — their register-staged twins do
+    int cfg = force_cfg;
+    if (cfg >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) cfg -= 2;
+    const int force_cfg = cfg;
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
     int splitk = std::max(1, std::min(force_split > 0 ? force_split : 1, nk));
+    if (g.plain) splitk = 1;                     // the fused pool takes whole K ranges
     while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
     int kps = (nk + splitk - 1) / splitk;
     splitk = (nk + kps - 1) / kps;

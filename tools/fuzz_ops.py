@@ -17,6 +17,7 @@ from ann3depth_amd import ops  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 TOL = 3e-6
+TOL_POOL = 2e-5
 TOL_BF16_OUT, TOL_BF16_DW = 4e-3, 1e-4      # bf16 storage: an output rounded to bf16 (2^-9 per element); fp32 accumulation
 
 
@@ -125,6 +126,33 @@ def conv_case_bf16s():
     return n, h, w, c, k, ks, st, pad
 
 
+def run_conv_pool(n, h, w, c, k, ks, st, pad):
+    """conv + ReLU + 2x2 max pool in one launch (the headline step's conv2d_0 / conv2d_1 / fine/first) against the two
+    launches (whose conv may add its K range in another order: split-K, stream-K): the pooled values to fp32 accumulation
+    error, and the recorded position must hold the window's maximum (to the same error; ties may resolve differently when
+    the two sums differ in their last bits)."""
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    if d.ho < 2 or d.wo < 2 or k == 1:
+        return 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, h, w, c), device='cuda', generator=g)
+    wt = torch.randn((ks, ks, c, k), device='cuda', generator=g) / np.sqrt(ks * ks * c)
+    b = torch.randn((k,), device='cuda', generator=g)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda')
+    ops.conv2d_fwd(d, x, wt, b, y, 'relu')
+    ph, pw = d.ho // 2, d.wo // 2
+    pooled = torch.full((n, ph, pw, k), float('nan'), device='cuda')
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x, wt, b, pooled, 'relu', arg)
+    win = y[:, :2 * ph, :2 * pw].reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4)
+    want = win.max(-1).values.double()
+    if int(arg.max()) > 3 or not bool(torch.isfinite(pooled).all()):
+        return 1.0
+    at_arg = win.gather(-1, arg.long().unsqueeze(-1)).squeeze(-1).double()
+    scale = max(float(y.double().norm()) / np.sqrt(y.numel()), 1e-30) * np.sqrt(want.numel())     # typical magnitude
+    return max(float((pooled.double() - want).norm()), float((at_arg - want).norm())) / scale
+
+
 def run_dense():
     m = int(rng.choice([1, 2, 5, 16, 32, 33, 64, 200]))
     k = int(rng.choice([1, 3, 16, 100, 128, 1000, 4096, 12288]))
@@ -188,6 +216,12 @@ while time.time() < t_end:
         e16, e32 = run_conv_bf16s(*case)
         err = max(e16 * TOL / TOL_BF16_OUT, e32 * TOL / TOL_BF16_DW)      # each judged against its own tolerance
         case = ('conv bf16s',) + case
+    elif u < 0.55:
+        os.environ.pop('A3D_FORCE_STREAMK', None)          # the fused pool takes whole K ranges only
+        os.environ.pop('A3D_FORCE_SPLITK', None)
+        case = conv_case()
+        err = run_conv_pool(*case) * TOL / TOL_POOL          # two fp32 sums of up to 16 k products against each other
+        case = ('conv+pool',) + case
     else:
         case = conv_case()
         err = run_conv(*case)
