@@ -153,6 +153,38 @@ def run_conv_pool(n, h, w, c, k, ks, st, pad):
     return max(float((pooled.double() - want).norm()), float((at_arg - want).norm())) / scale
 
 
+def run_dense_adam():
+    """a3d_dense_bwd_filter_adam_tf1 (the gradient never written; the reference's frozen optimizer) against
+    a3d_dense_bwd_filter + a3d_adam_apply_tf1 over two steps: m, v, var bit for bit (same MFMA sum order, the same
+    separate fp32 operations).  Batches of at most 64 rows, k * n >= 64 k (below that the two-pass path is a GEMM with
+    another sum order).  -> 0.0 or 1.0"""
+    m = int(rng.integers(1, 65))
+    k = int(rng.choice([64, 96, 130, 257, 512, 1028, 4488]))
+    n = int(rng.choice([64, 66, 257, 520, 772, 1030, 1538, 4070]))
+    while k * n < 65536:
+        k *= 2
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((m, k), device='cuda', generator=g)
+    fused = [torch.randn((k, n), device='cuda', generator=g), torch.zeros((k, n), device='cuda'),
+             torch.rand((k, n), device='cuda', generator=g) * 0.01, torch.randn((n,), device='cuda', generator=g),
+             torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')]
+    plain = [t.clone() for t in fused]
+    b1p, ok = np.float32(0.9), True
+    for step in range(2):
+        dz = torch.randn((m, n), device='cuda', generator=g)
+        if step == 1:
+            dz[0, 3 % n] = float('inf')                       # the poison path (v, var take a NaN)
+        ops.dense_bwd_filter_adam_tf1(x, dz, *fused, 0.1, 0.9, 1.0, float(b1p), 1.0, 0.5)
+        dw, db = torch.empty((k, n), device='cuda'), torch.empty(n, device='cuda')
+        ops.dense_bwd_filter(x, dz, dw, db)
+        ops.adam_apply_tf1(plain[0], plain[1], plain[2], dw, 0.1, 0.9, 1.0, 1e-8, float(b1p), 1.0, 0.5)
+        ops.adam_apply_tf1(plain[3], plain[4], plain[5], db, 0.1, 0.9, 1.0, 1e-8, float(b1p), 1.0, 0.5)
+        b1p = b1p * np.float32(0.9)
+        for a, b in zip(fused, plain):
+            ok &= bool(torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0)))
+    return (m, k, n), 0.0 if ok else 1.0
+
+
 def run_dense():
     m = int(rng.choice([1, 2, 5, 16, 32, 33, 64, 200]))
     k = int(rng.choice([1, 3, 16, 100, 128, 1000, 4096, 12288]))
@@ -202,7 +234,13 @@ count, worst = 0, (0.0, None)
 while time.time() < t_end:
     forced = force_plan()
     u = rng.random()
-    if u < 0.25:
+    if u < 0.05:
+        for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK', 'A3D_FORCE_SK_SLICED'):
+            os.environ.pop(v, None)                       # both paths on the weight-streaming kernels
+        forced = 'auto'
+        case, err = run_dense_adam()
+        case = ('dense dW+Adam',) + case
+    elif u < 0.25:
         try:
             case, err = run_dense()
         except Exception:
