@@ -19,6 +19,11 @@
 #include "a3d_internal.h"
 #include "igemm.h"
 
+// cache policy of the once-read streams (weights, Adam slots); -DA3D_DENSE_AUX=0 for the A/B
+#ifndef A3D_DENSE_AUX
+#define A3D_DENSE_AUX kAuxStream
+#endif
+
 namespace a3d {
 
 
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
     for (int r = 0; r < 8; ++r) {
       const __amdgpu_buffer_rsrc_t rr = row_rsrc(g, r);
 #pragma unroll
-      for (int h = 0; h < NI; ++h) load_vec_buf<CW>(rr, piece_off(h), mo[NI * r + h]);
+      for (int h = 0; h < NI; ++h) load_vec_buf<CW, A3D_DENSE_AUX>(rr, piece_off(h), mo[NI * r + h]);
     }
   };
 
@@ -498,9 +503,9 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
           mn[j] = __float_as_uint(t);
           chk += __fmul_rn(gr, gr) + fabsf(t);
         }
-        if constexpr (CW == 4) __builtin_amdgcn_raw_buffer_store_b128(mn, rr, (int)off, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b64(mn, rr, (int)off, 0, 0);
-        load_vec_buf<CW>(rn, off, mreg[NI * r + h]);
+        if constexpr (CW == 4) __builtin_amdgcn_raw_buffer_store_b128(mn, rr, (int)off, 0, A3D_DENSE_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b64(mn, rr, (int)off, 0, A3D_DENSE_AUX);
+        load_vec_buf<CW, A3D_DENSE_AUX>(rn, off, mreg[NI * r + h]);
         // ApplyAdam's v and var take a NaN where g*g or the new m is not finite (adam_frozen_kernel); a non-finite
         // term makes the piece's sum non-finite, and the per-element work happens only behind that test
         if (!isfinite(chk) & (off != kOOB) & (row < K)) {
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
         // 16 bytes at dword alignment; where a lane's four columns run past N they are the next row's first (or
         // past the buffer: zeros): accumulators of columns that do not exist, never stored
         const int k = kc + 8 * u + 4 * lh + j;
-        load_vec_buf<4>(rw, ((k < k1) & (col0 < p.N)) ? (uint32_t)(((size_t)k * p.N + col0) * 4) : kOOB, c.w[u][j]);
+        load_vec_buf<4, A3D_DENSE_AUX>(rw, ((k < k1) & (col0 < p.N)) ? (uint32_t)(((size_t)k * p.N + col0) * 4) : kOOB, c.w[u][j]);
       }
 #pragma unroll
       for (int b = 0; b < MB; ++b) {

@@ -104,17 +104,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, u
   const uint32_t nr = bytes > 0x7fffffffull ? 0x7fffffffu : (uint32_t)bytes;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)nr, 0x00020000);
 }
-template <int VEC>
+// AUX: the instruction's cache policy bits (gfx942+: 1 = sc0, 2 = nt, 16 = sc1).  kAuxStream marks data read once by a
+// kernel that streams hundreds of MB (dense-layer weights, Adam slots): non-temporal, so that it does not push the tiles
+// a GEMM of the other stream re-reads out of the L2.
+constexpr int kAuxStream = 2;
+template <int VEC, int AUX = 0>
 __device__ __forceinline__ void load_vec_buf(__amdgpu_buffer_rsrc_t r, uint32_t off, float (&out)[VEC]) {
   if constexpr (VEC == 4) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX);
     out[0] = __uint_as_float(v[0]); out[1] = __uint_as_float(v[1]);
     out[2] = __uint_as_float(v[2]); out[3] = __uint_as_float(v[3]);
   } else if constexpr (VEC == 2) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX);
     out[0] = __uint_as_float(v[0]); out[1] = __uint_as_float(v[1]);
   } else {
-    out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+    out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, AUX));
   }
 }
 
