@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
   }
 }
 
-template <int TM, int TN, bool POOL>
-__global__ __launch_bounds__(256, (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(const Conv3Params p) {
+// DEPTH: chunks of 8 k in registers per wave (one being multiplied, DEPTH - 1 in flight).  2 for the kernel that runs
+// alone — four wavefronts per SIMD cover each other's load latency; 4 under A3D_HINT_SHARE_CU, where two wavefronts per
+// SIMD have to cover it themselves so that the other stream's bandwidth-bound kernels find half the register file free.
+template <int TM, int TN, bool POOL, int DEPTH = 2>
+__global__ __launch_bounds__(256, DEPTH > 2 ? 2 : (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(const Conv3Params p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
   // XCD-aware order: the blocks an XCD receives (ids congruent mod 8) work on one contiguous eighth of the tiles
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(c
       for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
 
   const int nchunks = p.Kp / 8;
-  f32x4 af[2][TM], bf[2][TN];
+  f32x4 af[DEPTH][TM], bf[DEPTH][TN];
   auto fetch = [&](int u, int buf) {
     const int k = 8 * u + 4 * lh;                     // this half's four k: one filter row (RLP % 4 == 0)
     const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
@@ -129,15 +132,36 @@ __global__ __launch_bounds__(256, (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(c
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][a][j], bf[buf][b][j], acc[a][b], 0, 0, 0);
   };
-  fetch(0, 0);
-  int u = 0;
-  for (; u + 2 <= nchunks; u += 2) {                  // two chunks per trip: the register double buffer is static
-    fetch(u + 1, 1);
-    multiply(0);
-    if (u + 2 < nchunks) fetch(u + 2, 0);
-    multiply(1);
+  if constexpr (DEPTH == 2) {
+    fetch(0, 0);
+    int u = 0;
+    for (; u + 2 <= nchunks; u += 2) {                  // two chunks per trip: the register double buffer is static
+      fetch(u + 1, 1);
+      multiply(0);
+      if (u + 2 < nchunks) fetch(u + 2, 0);
+      multiply(1);
+    }
+    if (u < nchunks) multiply(0);
+  } else {
+    // ring of DEPTH register sets, DEPTH chunks per trip (static indices); a chunk past the end is fetched with every
+    // offset out of range (zeros: multiplying them adds nothing), so the trip needs no tail logic
+    auto fetch_or_zero = [&](int u, int buf) {
+      if (u < nchunks) { fetch(u, buf); return; }
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[buf][a] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[buf][b] = {0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i) fetch_or_zero(i, i);
+    for (int u = 0; u < nchunks; u += DEPTH) {
+#pragma unroll
+      for (int i = 0; i < DEPTH; ++i) {
+        fetch_or_zero(u + i + DEPTH - 1, (i + DEPTH - 1) % DEPTH);
+        multiply(i);
+      }
+    }
   }
-  if (u < nchunks) multiply(0);
 
   // ---- epilogue: bias, activation, (max pool + argmax), store ----
 #pragma unroll
@@ -223,15 +247,20 @@ static int conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, bool s
   const size_t lds = share ? kShare : 0;
   static bool attr_done = false;
   if (share && !attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, true, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShare) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_fwd_kernel<TM, TN, false, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kShare) != hipSuccess)
       return set_error(A3D_ELAUNCH, "conv3: hipFuncSetAttribute failed");
     attr_done = true;
   }
-  if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), lds, st, p);
+  if (share) {                 // two blocks per CU, three chunks in flight per wave
+    if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true, 4>), dim3(blocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false, 4>), dim3(blocks), dim3(256), lds, st, p);
+  } else {
+    if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), lds, st, p);
+  }
   return A3D_OK;
 }
 

@@ -157,11 +157,12 @@ class MSDNReplica:
         # is a quarter of the stretch, not all of it.  The dominant bwd-filter GEMMs run after the join, alone.
         self.overlap = os.environ.get('A3D_OVERLAP', '1') == '1'
         # A3D_SHARE_CU: which fine-network GEMMs are launched with A3D_HINT_SHARE_CU (at most two wavefronts per SIMD, so
-        # that the dense layers' weight-streaming kernels find room on every CU): 3 = fine/second only (default; measured
-        # 3.06 against 3.10 ms per step without any hint), 1 = fine/first too (3.07), 2 = fine/first only (3.11), 0 = none.
-        # Starting fine/first earlier (beside the coarse conv stack: 3.18 ms) or later (after the dense forward: 3.11 ms)
-        # both lose: an MFMA-bound grid beside another MFMA-bound grid only takes CU slots from it.
-        share = int(os.environ.get('A3D_SHARE_CU', '3')) if (self.overlap and dev.type == 'cuda') else 0
+        # that the dense layers' weight-streaming kernels find room on every CU): 1 = both (default: 2.939 ms per step,
+        # alternating runs), 3 = fine/second only (2.947), 2 = fine/first only (2.98), 0 = none (2.985).  (fine/first's
+        # few-channel kernel keeps three chunks in flight per wave under the hint; with its stand-alone schedule it lost.)
+        # Starting fine/first earlier (beside the coarse conv stack) or later (after the dense forward) both lose: an
+        # MFMA-bound grid beside another MFMA-bound grid only takes CU slots from it.
+        share = int(os.environ.get('A3D_SHARE_CU', '1')) if (self.overlap and dev.type == 'cuda') else 0
         self._share_names = {0: (), 1: ('fine/first/conv2d', 'fine/second/conv2d'), 2: ('fine/first/conv2d',),
                              3: ('fine/second/conv2d',)}[share]
         self._shared_desc = {}

@@ -660,6 +660,33 @@ def test_strided_bwd_data_on_bf16_tensors_is_one_launch(ops, n, h, w, c, k, ks, 
         assert (got[want == 0] == 0).all()                 # pixels no tap reaches, masked pixels: exact zeros
 
 
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad', [(4, 60, 76, 3, 63, 9, 2, 'VALID'), (3, 47, 64, 3, 96, 11, 4, 'VALID'),
+                                                  (2, 23, 29, 1, 40, 5, 1, 'VALID'), (4, 55, 74, 64, 64, 5, 1, 'SAME'),
+                                                  (2, 13, 18, 256, 384, 3, 1, 'SAME')])
+def test_share_cu_hint_changes_the_launch_not_the_result(ops, n, h, w, c, k, ks, st, pad):
+    """A3D_HINT_SHARE_CU (include/a3d.h): the forward GEMM leaves half of every CU to the other stream's bandwidth-bound
+    kernels — the few-channel kernel with two wavefronts per SIMD and three chunks in flight (conv3.hip), the generic
+    one with one block per CU — and returns the same bits, with and without the fused pool."""
+    rng = np.random.default_rng(h + k)
+    x = dev(rng.standard_normal((n, h, w, c)).astype(np.float32))
+    wt = dev((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32))
+    b = dev(rng.standard_normal(k).astype(np.float32))
+    plain = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad)
+    hinted = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, hints=ops.HINT_SHARE_CU)
+    y0 = torch.full((n, plain.ho, plain.wo, k), -7.0, device='cuda')
+    y1 = torch.full_like(y0, -7.0)
+    ops.conv2d_fwd(plain, x, wt, b, y0, 'relu')
+    ops.conv2d_fwd(hinted, x, wt, b, y1, 'relu')
+    assert torch.equal(y0, y1)
+    ph, pw = plain.ho // 2, plain.wo // 2
+    p0, p1 = torch.full((n, ph, pw, k), -7.0, device='cuda'), torch.full((n, ph, pw, k), -7.0, device='cuda')
+    a0 = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    a1 = torch.full_like(a0, 9)
+    ops.conv2d_pool_fwd(plain, x, wt, b, p0, 'relu', a0)
+    ops.conv2d_pool_fwd(hinted, x, wt, b, p1, 'relu', a1)
+    assert torch.equal(p0, p1) and torch.equal(a0, a1) and int(a0.max()) <= 3
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
