@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 // alone — four wavefronts per SIMD cover each other's load latency; 4 under A3D_HINT_SHARE_CU, where two wavefronts per
 // SIMD have to cover it themselves so that the other stream's bandwidth-bound kernels find half the register file free.
 template <int TM, int TN, bool POOL, int DEPTH = 2>
-__global__ __launch_bounds__(256, DEPTH > 2 ? 2 : (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(const Conv3Params p) {
+__global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4 ? 3 : 4)) void conv3_fwd_kernel(const Conv3Params p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
   // XCD-aware order: the blocks an XCD receives (ids congruent mod 8) work on one contiguous eighth of the tiles
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, DEPTH > 2 ? 2 : (TM * TN > 4 ? 3 : 4)) void co
     const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile = (int)bid * 4 + wave;               // wave task: tile_n fastest
+  const int tile = (int)bid * (DEPTH > 2 ? 8 : 4) + wave;       // wave task: tile_n fastest (8 waves per block under the hint)
   const int tiles_n = p.Np / (32 * TN);
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
   if (tile_m >= p.m_tiles) return;
@@ -239,11 +239,12 @@ size_t conv3_ws_bytes(const a3d_conv_desc* d) {
   return ((size_t)s.Kp * s.Np * 4 + 255) / 256 * 256;
 }
 
-// share: A3D_HINT_SHARE_CU — the kernel uses no LDS, so a dynamic request of 80 KiB + 1 KiB caps it at one 4-wave block
-// per CU... two blocks (8 waves, two per SIMD) need 160 / 3 KiB + 1 KiB each
+// share: A3D_HINT_SHARE_CU — the kernel uses no LDS, so a dynamic request of 80 KiB + 1 KiB caps it at ONE block per CU:
+// eight waves (two per SIMD), and the other half of the CU's LDS stays free for the other stream's kernels (the dense
+// layers' streaming kernels take 66 - 70 KiB per block: beside two 4-wave blocks of 54 KiB each they did not fit at all)
 template <int TM, int TN>
 static int conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, bool share, hipStream_t st) {
-  constexpr size_t kShare = (size_t)163840 / 3 + 1024;
+  constexpr size_t kShare = (size_t)163840 / 2 + 1024;
   const size_t lds = share ? kShare : 0;
   static bool attr_done = false;
   if (share && !attr_done) {
@@ -254,9 +255,9 @@ static int conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, bool s
       return set_error(A3D_ELAUNCH, "conv3: hipFuncSetAttribute failed");
     attr_done = true;
   }
-  if (share) {                 // two blocks per CU, three chunks in flight per wave
-    if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true, 4>), dim3(blocks), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false, 4>), dim3(blocks), dim3(256), lds, st, p);
+  if (share) {                 // one 8-wave block per CU, three chunks in flight per wave
+    if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true, 4>), dim3((blocks + 1) / 2), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false, 4>), dim3((blocks + 1) / 2), dim3(512), lds, st, p);
   } else {
     if (pool) hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, true>), dim3(blocks), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv3_fwd_kernel<TM, TN, false>), dim3(blocks), dim3(256), lds, st, p);

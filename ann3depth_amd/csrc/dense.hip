@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
   static_assert(G >= 1 && NI >= 1, "columns per lane");
   typedef float vec __attribute__((ext_vector_type(CW)));
   typedef uint32_t uvec __attribute__((ext_vector_type(CW)));
-  __shared__ __attribute__((aligned(16))) float tile[32 * TLD];
+  // the gradient tile passes through LDS sixteen rows at a time (33 KiB at MB = 1, not 66: two of these blocks fit beside
+  // a GEMM block of the other stream that leaves half of the CU's LDS free); wave w updates rows 4w .. 4w+3 of each half
+  __shared__ __attribute__((aligned(16))) float tile[16 * TLD];
   __shared__ __attribute__((aligned(16))) float xs[32 * MB * 32];   // x[batch row][weight row of the group]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -404,12 +406,13 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
     for (int b = 0; b < MB; ++b)
       *reinterpret_cast<f32x4v*>(&xs[(xm + 32 * b) * 32 + xk]) = (f32x4v){xv[b][0], xv[b][1], xv[b][2], xv[b][3]};
   };
-  // m tile of a group: this wave's rows 8*wave .. +7, NI pieces each.  One resource per row (scalar arithmetic: a row
-  // that does not exist gets zero records), one lane offset for all of them.
+  // m tile of a group: this wave's eight rows (wrow: 4 wave .. +3 of either half of the group), NI pieces each.  One
+  // resource per row (scalar arithmetic: a row that does not exist gets zero records), one lane offset for all of them.
   const int mcol = nb + lane * CW;
   const uint32_t mvoff = mcol < N ? (uint32_t)mcol * 4u : kOOB;       // N % CW == 0; later pieces: + 256*CW bytes each
+  auto wrow = [&](int r) { return 16 * (r >> 2) + 4 * wave + (r & 3); };
   auto row_rsrc = [&](int g, int r) {
-    const int row = 32 * g + wave * 8 + r;
+    const int row = 32 * g + wrow(r);
     const bool ok = (g < g1) & (row < K);
     return make_rsrc(m_w + (size_t)(ok ? row : 0) * N, ok ? (unsigned long long)N * 4 : 0ull);
   };
@@ -470,52 +473,58 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
         for (int j = 0; j < CW; ++j)
           acc[gq][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[u][gq][j], acc[gq][j], 0, 0, 0);
     }
-    // gradient tile -> LDS: register v of group gq's CW accumulators = columns 128*wave + (32 gq + li)*CW .. of row
-    // (v&3) + 8*(v>>2) + 4*lh
+    // gradient tile -> LDS, sixteen rows per pass: register v = 8 hh + vv of group gq's CW accumulators = columns
+    // 128*wave + (32 gq + li)*CW .. of row 16 hh + (vv&3) + 8*(vv>>2) + 4*lh
 #pragma unroll
-    for (int gq = 0; gq < G; ++gq)
+    for (int hh = 0; hh < 2; ++hh) {
+      if (hh) __syncthreads();               // the first half's rows have been read
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        vec t;
+      for (int gq = 0; gq < G; ++gq)
 #pragma unroll
-        for (int j = 0; j < CW; ++j) t[j] = acc[gq][j][v];
-        *reinterpret_cast<vec*>(&tile[((v & 3) + 8 * (v >> 2) + 4 * lh) * TLD + wave * WCOLS + (32 * gq + li) * CW]) = t;
-      }
-    __syncthreads();
-    load_x(xv, g + 1);        // before the m requests: loads come back in issue order
-    __builtin_amdgcn_sched_barrier(0);
+        for (int vv = 0; vv < 8; ++vv) {
+          vec t;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const __amdgpu_buffer_rsrc_t rr = row_rsrc(g, r), rn = row_rsrc(g + 1, r);
-      const int row = 32 * g + wave * 8 + r;
-#pragma unroll
-      for (int h = 0; h < NI; ++h) {
-        const int c = (h * 64 + lane) * CW;
-        const vec g4 = *reinterpret_cast<const vec*>(&tile[(wave * 8 + r) * TLD + c]);
-        const uint32_t off = piece_off(h);
-        uvec mn;
-        float chk = 0.f;
-#pragma unroll
-        for (int j = 0; j < CW; ++j) {
-          const float gr = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
-          const float mo = mreg[NI * r + h][j];
-          const float t = __fadd_rn(mo, __fmul_rn(__fsub_rn(gr, mo), omb1));
-          mn[j] = __float_as_uint(t);
-          chk += __fmul_rn(gr, gr) + fabsf(t);
+          for (int j = 0; j < CW; ++j) t[j] = acc[gq][j][8 * hh + vv];
+          *reinterpret_cast<vec*>(&tile[((vv & 3) + 8 * (vv >> 2) + 4 * lh) * TLD + wave * WCOLS + (32 * gq + li) * CW]) = t;
         }
-        if constexpr (CW == 4) __builtin_amdgcn_raw_buffer_store_b128(mn, rr, (int)off, 0, A3D_DENSE_AUX);
-        else __builtin_amdgcn_raw_buffer_store_b64(mn, rr, (int)off, 0, A3D_DENSE_AUX);
-        load_vec_buf<CW, A3D_DENSE_AUX>(rn, off, mreg[NI * r + h]);
-        // ApplyAdam's v and var take a NaN where g*g or the new m is not finite (adam_frozen_kernel); a non-finite
-        // term makes the piece's sum non-finite, and the per-element work happens only behind that test
-        if (!isfinite(chk) & (off != kOOB) & (row < K)) {
+      __syncthreads();
+      if (hh == 0) {
+        load_x(xv, g + 1);      // before the m requests: loads come back in issue order
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 4 * hh; r < 4 * hh + 4; ++r) {
+        const __amdgpu_buffer_rsrc_t rr = row_rsrc(g, r), rn = row_rsrc(g + 1, r);
+        const int row = 32 * g + wrow(r);
+#pragma unroll
+        for (int h = 0; h < NI; ++h) {
+          const int c = (h * 64 + lane) * CW;
+          const vec g4 = *reinterpret_cast<const vec*>(&tile[(4 * wave + (r & 3)) * TLD + c]);
+          const uint32_t off = piece_off(h);
+          uvec mn;
+          float chk = 0.f;
 #pragma unroll
           for (int j = 0; j < CW; ++j) {
             const float gr = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
-            const bool poison = !isfinite(__fmul_rn(gr, gr));
-            const size_t o = (size_t)row * N + nb + c + j;
-            if (poison) v_w[o] = qnan;
-            if (poison || !isfinite(__uint_as_float(mn[j]))) var_w[o] = qnan;
+            const float mo = mreg[NI * r + h][j];
+            const float t = __fadd_rn(mo, __fmul_rn(__fsub_rn(gr, mo), omb1));
+            mn[j] = __float_as_uint(t);
+            chk += __fmul_rn(gr, gr) + fabsf(t);
+          }
+          if constexpr (CW == 4) __builtin_amdgcn_raw_buffer_store_b128(mn, rr, (int)off, 0, A3D_DENSE_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b64(mn, rr, (int)off, 0, A3D_DENSE_AUX);
+          load_vec_buf<CW, A3D_DENSE_AUX>(rn, off, mreg[NI * r + h]);
+          // ApplyAdam's v and var take a NaN where g*g or the new m is not finite (adam_frozen_kernel); a non-finite
+          // term makes the piece's sum non-finite, and the per-element work happens only behind that test
+          if (!isfinite(chk) & (off != kOOB) & (row < K)) {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              const float gr = use_scale ? __fmul_rn(g4[j], gscale) : g4[j];
+              const bool poison = !isfinite(__fmul_rn(gr, gr));
+              const size_t o = (size_t)row * N + nb + c + j;
+              if (poison) v_w[o] = qnan;
+              if (poison || !isfinite(__uint_as_float(mn[j]))) var_w[o] = qnan;
+            }
           }
         }
       }
@@ -549,7 +558,9 @@ struct DenseStreamParams {
 // when the launch is not split; otherwise one slab per split for splitk_reduce_kernel).
 template <int MB>
 __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStreamParams p) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 132];
+  // (16 rows at a time: 33 KiB instead of 66 — two of these blocks fit beside a GEMM block of the other stream that
+  // leaves half of the CU's LDS free, A3D_HINT_SHARE_CU)
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 132];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * 128, split = blockIdx.y;
   const int kb0 = split * p.span, kb1 = min(p.K, kb0 + p.span);
@@ -610,37 +621,42 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
     }
   }
 
-  // the four waves' tiles -> LDS -> rows (one 32-row block of the batch at a time)
+  // the four waves' tiles -> LDS -> rows, sixteen rows of the batch at a time (accumulator registers 8 hh .. 8 hh + 7 hold
+  // rows 16 hh .. 16 hh + 15); the four partial sums are added in wave order
 #pragma unroll
   for (int b = 0; b < MB; ++b) {
-    if (b) __syncthreads();
-    float* mine = red + wave * (32 * 132);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const f32x4 q = {acc[b][0][v], acc[b][1][v], acc[b][2][v], acc[b][3][v]};
-      *reinterpret_cast<f32x4*>(mine + ((v & 3) + 8 * (v >> 2) + 4 * lh) * 132 + 4 * li) = q;
-    }
-    __syncthreads();
+    for (int hh = 0; hh < 2; ++hh) {
+      if (b || hh) __syncthreads();
+      float* mine = red + wave * (16 * 132);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int lr = wave * 8 + r, m = 32 * b + lr;
-      if (m >= p.M) continue;
+      for (int vv = 0; vv < 8; ++vv) {
+        const int v = 8 * hh + vv;
+        const f32x4 q = {acc[b][0][v], acc[b][1][v], acc[b][2][v], acc[b][3][v]};
+        *reinterpret_cast<f32x4*>(mine + ((vv & 3) + 8 * (vv >> 2) + 4 * lh) * 132 + 4 * li) = q;
+      }
+      __syncthreads();
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = lane + 64 * h, col = n0 + c;
-        if (col >= p.N) continue;
-        float s = red[lr * 132 + c];
-        s += red[(32 + lr) * 132 + c];
-        s += red[(64 + lr) * 132 + c];
-        s += red[(96 + lr) * 132 + c];
-        if (p.splits > 1) {
-          p.out[((size_t)split * p.M + m) * p.N + col] = s;
-        } else {
-          if (p.bias) s += p.bias[col];
-          if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
-          else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
-          if (p.keep) s = p.keep[(size_t)m * p.N + col] ? s * p.scale : 0.f;
-          p.out[(size_t)m * p.N + col] = s;
+      for (int r = 0; r < 4; ++r) {
+        const int lr = wave * 4 + r, m = 32 * b + 16 * hh + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = lane + 64 * h, col = n0 + c;
+          if (col >= p.N) continue;
+          float s = red[lr * 132 + c];
+          s += red[(16 + lr) * 132 + c];
+          s += red[(32 + lr) * 132 + c];
+          s += red[(48 + lr) * 132 + c];
+          if (p.splits > 1) {
+            p.out[((size_t)split * p.M + m) * p.N + col] = s;
+          } else {
+            if (p.bias) s += p.bias[col];
+            if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
+            else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
+            if (p.keep) s = p.keep[(size_t)m * p.N + col] ? s * p.scale : 0.f;
+            p.out[(size_t)m * p.N + col] = s;
+          }
         }
       }
     }
