@@ -57,8 +57,9 @@ typedef struct a3d_conv_desc {
 
 /* The forward launch will run beside bandwidth-bound kernels of ANOTHER stream (the fine network's forward beside the
  * coarse network's dense layers: src/models.py:289-290 builds both in one graph): keep at most two wavefronts per SIMD
- * resident, so that the other stream's kernels find free registers and wave slots on every CU instead of waiting for
- * GEMM blocks to retire. */
+ * resident — for the 8-wave kernels one block per CU, which also leaves half of the CU's LDS unclaimed — so that the
+ * other stream's kernels find free registers, wave slots and LDS on every CU instead of waiting for GEMM blocks to
+ * retire.  The result is bit-identical with and without the hint. */
 #define A3D_HINT_SHARE_CU 1
 
 /* BASELINE config 5 ("bf16 activations + bf16 weight copies, fp32 master and accumulate"): tensors marked here are bf16 in
