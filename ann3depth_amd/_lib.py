@@ -96,8 +96,9 @@ SIGNATURES = {
     'a3d_record_decode_u8': (c_int, [_P, c_size_t, c_int, _P, _P, c_size_t, _P, _P, c_size_t, POINTER(ExampleView),
                                      POINTER(c_int)]),
     'a3d_records_decode': (c_int, [POINTER(c_void_p), POINTER(c_size_t), c_int, c_int, POINTER(c_int64), _P, _P, _P, _P,
-                                   POINTER(c_int32), POINTER(c_int32)]),
-    'a3d_h2d_gather': (c_int, [_P, _P, POINTER(c_int32), c_int, c_size_t, _P]),
+                                   POINTER(c_int32), c_int, POINTER(c_int32)]),
+    'a3d_h2d_gather': (c_int, [_P, _P, POINTER(c_int32), c_int, c_int, c_size_t, _P]),
+    'a3d_sizeof_conv_desc': (c_size_t, []),
     'a3d_example_write': (c_int64, [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, c_size_t]),
 }
 
@@ -123,6 +124,9 @@ def load():
             raise A3dError(f'liba3d.so lacks symbol {name}: stale build?') from e
         fn.restype = res
         fn.argtypes = args
+    if lib.a3d_sizeof_conv_desc() != ctypes.sizeof(ConvDesc):
+        raise A3dError(f'liba3d.so reads a {lib.a3d_sizeof_conv_desc()}-byte a3d_conv_desc, this binding passes '
+                       f'{ctypes.sizeof(ConvDesc)} bytes: stale build?')
     _lib = lib
     return lib
 

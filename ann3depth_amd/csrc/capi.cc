@@ -30,11 +30,16 @@ int a3d_last_error(char* buf, size_t len) {
   return A3D_OK;
 }
 
-int a3d_h2d_gather(void* dst, const void* src_pool, const int32_t* slots, int n, size_t bytes_each, void* stream) {
-  if (!dst || !src_pool || !slots || n <= 0 || bytes_each == 0) return a3d::set_error(A3D_EINVAL, "h2d_gather: bad arguments");
+size_t a3d_sizeof_conv_desc(void) { return sizeof(a3d_conv_desc); }
+
+int a3d_h2d_gather(void* dst, const void* src_pool, const int32_t* slots, int n, int nslots, size_t bytes_each, void* stream) {
+  if (!dst || !src_pool || !slots || n <= 0 || nslots <= 0 || bytes_each == 0)
+    return a3d::set_error(A3D_EINVAL, "h2d_gather: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int b = 0; b < n; ++b)          // all slots before the first copy: a bad batch enqueues nothing
+    if (slots[b] < 0 || slots[b] >= nslots)
+      return a3d::set_error(A3D_EINVAL, "h2d_gather: slot %d outside the pool's %d slots", slots[b], nslots);
   for (int b = 0; b < n; ++b) {
-    if (slots[b] < 0) return a3d::set_error(A3D_EINVAL, "h2d_gather: negative slot");
     const hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + (size_t)b * bytes_each,
                                         static_cast<const char*>(src_pool) + (size_t)slots[b] * bytes_each, bytes_each,
                                         hipMemcpyHostToDevice, st);

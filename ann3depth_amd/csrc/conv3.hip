@@ -4,7 +4,9 @@
 //
 // With few channels a filter row (s, c) of one output pixel is ONE contiguous run of S*Cin floats of the image.  The K
 // axis is (r, q): filter row r, position q inside the run, the run padded to a multiple of 4 floats (the filter gets zero
-// rows for the pad, the image floats read there are the next pixels of the same row).  Then
+// rows for the pad; the image floats read there — the next pixels of the same row — are replaced by zeros before they
+// reach the matrix cores: a non-finite pixel OUTSIDE a window must not turn into 0 * inf = NaN inside it, TensorFlow's
+// Conv2D never touches it).  Then
 //   * the k -> (r, q) decode is the same for every pixel, so a lane's A address is `pixel base + offset(k)`: one add;
 //   * four consecutive k of one pixel are 16 contiguous bytes: lane (row li, half h) of a v_mfma_f32_32x32x2_f32 quad
 //     loads k = 8u+4h .. +3 of its row with ONE buffer_load_dwordx4 and feeds MFMA j with element j;
@@ -106,10 +108,12 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
 
   const int nchunks = p.Kp / 8;
   f32x4 af[DEPTH][TM], bf[DEPTH][TN];
+  int nv[DEPTH];                                      // how many of a chunk's four k lie inside the run (>= 4: all)
   auto fetch = [&](int u, int buf) {
     const int k = 8 * u + 4 * lh;                     // this half's four k: one filter row (RLP % 4 == 0)
     const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
     const uint32_t koff = k < p.Kreal ? (r * (uint32_t)p.rowpitch + q) * 4u : kOOB;      // K tail: nothing to read
+    nv[buf] = p.RL - (int)q;                          // q <= RLP - 4 < RL: element 0 is always inside
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const uint32_t off = (a_base[a] | koff) & kOOB ? kOOB : a_base[a] + koff;
@@ -124,6 +128,12 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
     }
   };
   auto multiply = [&](int buf) {
+    // pad positions of the run (only the last 4-group of a filter row has any) hold neighbouring pixels: zero them here,
+    // at the point of use — the selects sit where the wait for this chunk's loads is anyway, not behind the fetch
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[buf][a][j] = nv[buf] > j ? af[buf][a][j] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
     // offset out of range (zeros: multiplying them adds nothing), so the trip needs no tail logic
     auto fetch_or_zero = [&](int u, int buf) {
       if (u < nchunks) { fetch(u, buf); return; }
+      nv[buf] = 4;
 #pragma unroll
       for (int a = 0; a < TM; ++a) af[buf][a] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -478,10 +478,19 @@ int a3d_record_decode_u8(const uint8_t* frame, size_t len, int verify_crc, uint8
 // sizes dims = {image h, w, c, depth h, w, c}: records of different sizes cannot share a batch.
 int a3d_records_decode(const void* const* frames, const size_t* lens, int n, int verify_crc, const int64_t* dims,
                        uint8_t* image_u8_pool, float* image_f32_pool, uint8_t* depth_u8_pool, float* depth_f32_pool,
-                       const int32_t* slots, int32_t* kinds) {
-  if (!frames || !lens || !dims || !image_f32_pool || !depth_f32_pool || !slots || !kinds || n <= 0)
+                       const int32_t* slots, int nslots, int32_t* kinds) {
+  if (!frames || !lens || !dims || !image_f32_pool || !depth_f32_pool || !slots || !kinds || n <= 0 || nslots <= 0)
     return a3d::set_error(A3D_EINVAL, "records_decode: bad arguments");
-  const size_t ic = (size_t)(dims[0] * dims[1] * dims[2]), dc = (size_t)(dims[3] * dims[4] * dims[5]);
+  size_t cnt[2] = {1, 1};
+  for (int j = 0; j < 6; ++j) {        // positive, and the element counts (times the slot count) stay far inside size_t
+    if (dims[j] <= 0 || dims[j] > (int64_t)1 << 31) return a3d::set_error(A3D_EINVAL, "records_decode: dims[%d] = %lld", j, (long long)dims[j]);
+    if (cnt[j / 3] > ((size_t)1 << 40) / (size_t)dims[j]) return a3d::set_error(A3D_EINVAL, "records_decode: feature too large");
+    cnt[j / 3] *= (size_t)dims[j];
+  }
+  const size_t ic = cnt[0], dc = cnt[1];
+  for (int i = 0; i < n; ++i)
+    if (slots[i] < 0 || slots[i] >= nslots)
+      return a3d::set_error(A3D_EINVAL, "records_decode: slot %d outside the pool's %d slots", slots[i], nslots);
   for (int i = 0; i < n; ++i) {
     const size_t s = (size_t)slots[i];
     a3d_example_view ev;

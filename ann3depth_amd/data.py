@@ -179,7 +179,7 @@ class ShuffleBatch:
         u8 = self.images_u8 is not None
         _lib.check(_lib.load().a3d_records_decode(frames, lens, n, 1, dims, self.images_u8.ctypes.data if u8 else None,
                                                   self.images.ctypes.data, self.depths_u8.ctypes.data if u8 else None,
-                                                  self.depths.ctypes.data, ids, kinds),
+                                                  self.depths.ctypes.data, ids, len(self.images), kinds),
                    f'a3d_records_decode({recs[0][0].path}@{recs[0][1]})')
         for slot, k in zip(slots, kinds):
             self.kind[slot] = k

@@ -64,6 +64,35 @@ class GradReducer:
         assert n * self.world_size == flat.numel()
         dist.all_gather_into_tensor(flat, flat[self.rank * n:(self.rank + 1) * n], group=self.group)
 
+    def inplace_ok(self, device):
+        """Does THIS backend run the two aliasing collectives of the sharded dense path correctly?  reduce_scatter() writes
+        its result into a slice of its own input and all_gather() reads its contribution out of its own output — the
+        in-place forms NCCL / RCCL document (recvbuff == sendbuff + rank * count) and gloo accepts.  Every test of this
+        repository ran them over gloo (no pipeline box has had two GPUs: ADVICE r3), so the first RCCL job checks them
+        itself, once per reducer, on 4 KiB of known integers against a plain all-reduce: any wrong sum, or an exception,
+        on any rank makes every rank answer False, and MSDNReplica then exchanges the dense bucket with all-reduce (the
+        path without aliasing), saying so in its log line and in bench.py's JSON."""
+        if getattr(self, '_inplace_ok', None) is None:
+            ok = 1
+            try:
+                n = 256
+                base = torch.arange(self.world_size * n, device=device, dtype=torch.float32)
+                mine = base * (self.rank + 1)                        # rank r contributes (r + 1) * [0, 1, 2, ...]
+                want = base * (self.world_size * (self.world_size + 1) // 2)
+                work, own = self.reduce_scatter(mine)
+                self.wait(work)
+                lo = self.rank * n
+                ok &= int(torch.equal(own, want[lo:lo + n])) and own.data_ptr() == mine[lo:lo + n].data_ptr()
+                self.all_gather(mine)                                # every rank's slice of sums -> all of `want`
+                ok &= int(torch.equal(mine, want))
+            except Exception as e:                                   # noqa: BLE001 - a refusal of the aliasing form IS the answer
+                print(f'dp: in-place collectives refused by backend {dist.get_backend(self.group)}: {e}', flush=True)
+                ok = 0
+            t = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            self._inplace_ok = bool(t.item())
+        return self._inplace_ok
+
     def any(self, flag):
         """MAX of a small device tensor over the ranks (asynchronous; returns the handle)."""
         work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
@@ -104,6 +133,9 @@ class DetachedReducer:
 
     def __init__(self, world_size, rank=0):
         self.world_size, self.rank, self.pending = world_size, rank, []
+
+    def inplace_ok(self, device):
+        return True
 
     def start(self, flat_grad):
         return self._Done()

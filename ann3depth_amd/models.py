@@ -170,6 +170,18 @@ class MSDNReplica:
         # data-parallel replicas under the reference's frozen optimizer: the dense bucket is reduce-scattered and each
         # rank keeps the Adam `m` slot of its own slices only (dp.py); gather_state() reassembles it
         self._m_sharded = False
+        # A3D_DP_DENSE=allreduce forces the exchange without aliasing buffers (all-reduce + replicated ApplyAdam, what the
+        # flagged beta2 < 1 mode always uses); the default, reduce-scatter, is taken only if the backend passes the
+        # reducer's own check of the in-place collectives (dp.GradReducer.inplace_ok: RCCL has not run them on this pipeline)
+        self.dense_exchange = None
+        if reducer is not None:
+            want = os.environ.get('A3D_DP_DENSE', 'scatter')
+            if want not in ('scatter', 'allreduce'):
+                raise ValueError(f'A3D_DP_DENSE={want!r}: scatter or allreduce')
+            self.dense_exchange = 'reduce_scatter' if (want == 'scatter' and reducer.inplace_ok(dev)) else 'all_reduce'
+            if want == 'scatter' and self.dense_exchange == 'all_reduce':
+                print('MSDNReplica: in-place reduce-scatter failed its self-check on this backend; the dense bucket is '
+                      'all-reduced instead', flush=True)
         self._dense_pieces = None
         self._poison = None       # device flag: a non-finite gradient reached one of this rank's slices
         self._poison_seen = []    # [(event, pinned host copy of the all-rank MAX of the flag)] of earlier steps
@@ -800,7 +812,7 @@ class MSDNReplica:
                 # the 2.6 MB head is reduced on the critical path
                 handle, tail = [], []
                 cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
-                if gd.frozen():
+                if gd.frozen() and self.dense_exchange == 'reduce_scatter':
                     # the reference's optimizer: reduce-scatter, each rank updates m on its own slices only (dp.py)
                     early, late = self._dense_buckets()
                     if self._poison is None:
@@ -1198,7 +1210,7 @@ class TrainOp:
         with torch.cuda.stream(self.copy_stream):
             for which in (0, 1):
                 src = (self.pool_u8 if cur[which].dtype == torch.uint8 else self.pool)[which]
-                ops.check(_lib.load().a3d_h2d_gather(cur[which].data_ptr(), src.data_ptr(), ids, len(slots),
+                ops.check(_lib.load().a3d_h2d_gather(cur[which].data_ptr(), src.data_ptr(), ids, len(slots), len(src),
                                                      src[0].numel() * src.element_size(), self.copy_stream.cuda_stream),
                           'a3d_h2d_gather')                     # B copies from ONE call (no per-record host-language work)
             ev = torch.cuda.Event()

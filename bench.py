@@ -274,7 +274,7 @@ def comm_report(net, img, dep, masks, args, lib, world, dt):
     from ann3depth_amd import dp
     gd, gc = net.groups['CoarseDense'], net.groups['CoarseConv']
     cut = gc.offsets['coarse/conv/conv2d_2/kernel'][0]
-    if gd.frozen():       # the reference's optimizer: the dense bucket is reduce-scattered (models.MSDNReplica._dense_buckets)
+    if gd.frozen() and net.dense_exchange == 'reduce_scatter':       # models.MSDNReplica._dense_buckets
         (early,), late = net._dense_buckets()
         buckets = {'dense_1': ('reduce_scatter', gd.grad[early[0]:early[1]]),
                    'dense_0_piece': ('reduce_scatter', gd.grad[late[0][0]:late[0][1]])}
@@ -306,7 +306,7 @@ def comm_report(net, img, dep, masks, args, lib, world, dt):
                               precision=args.precision)
     n = max(3, args.steps // 2)
     dts, _ = run_phase(solo, img, dep, masks, n, 2, 0, lib, world, timed_kernels=False)
-    return {'rccl_ranks': world, 'allreduce_ms': times,
+    return {'rccl_ranks': world, 'dense_exchange': net.dense_exchange, 'allreduce_ms': times,
             'ms_per_step_without_comm': round(1e3 * dts / n, 3),
             'exposed_comm_ms': round(1e3 * (dt / args.steps - dts / n), 3)}
 

@@ -78,6 +78,9 @@ typedef struct a3d_conv_desc {
 
 const char* a3d_version(void);
 int a3d_last_error(char* buf, size_t len);
+/* sizeof(a3d_conv_desc) as THIS build of the library reads it: a binding written against an older header (the struct has
+ * grown: storage, hints) can compare it with the size of its own mirror of the struct before the first call. */
+size_t a3d_sizeof_conv_desc(void);
 
 /* A HIP stream of a given queue priority (hipStreamCreateWithPriority, non-blocking): `level` -1 = above, 0 = the same
  * as, +1 = below the streams the host framework hands out, clamped to what the device offers.  For the second stream of
@@ -87,7 +90,13 @@ int a3d_last_error(char* buf, size_t len);
 int a3d_stream_create(int level, void** stream);
 int a3d_stream_destroy(void* stream);
 
-/* Conv2D + BiasAdd (+ Relu)  — tf.layers.conv2d forward.  bias may be NULL. */
+/* Conv2D + BiasAdd (+ Relu)  — tf.layers.conv2d forward.  bias may be NULL.
+ * Non-finite inputs (the reference gives them meaning: src/models.py:262-264): with A3D_PREC_F32 an output is non-finite
+ * only if its own receptive field holds a non-finite value, as with TensorFlow's Conv2D — taps outside the image, K / M
+ * tails and the pad positions of the few-channel kernels' window runs all enter the matrix cores as zeros on the
+ * ACTIVATION side.  One stated deviation, opt-in modes only: A3D_PREC_BF16 / _BF16X3 on an unpadded conv of <= 4 input
+ * channels gather whole window runs whose pad positions hold the NEXT pixels of the image row and meet zero weights
+ * (0 * inf = NaN): there a non-finite pixel can also reach the windows immediately to its left. */
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                    int act, void* ws, size_t ws_bytes, void* stream);
@@ -330,15 +339,17 @@ int a3d_record_decode_u8(const uint8_t* frame, size_t len, int verify_crc, uint8
                          a3d_example_view* view, int* kinds);
 /* n framed records into slots slots[i] of the staging pool (dense arrays of image / depth features: float32, and uint8
  * twins or NULL) in one call: a3d_record_decode_u8 per record when the twins exist, a3d_record_decode otherwise; kinds[i]
- * as a3d_record_decode_u8's.  dims = {image h, w, c, depth h, w, c}: a record of any other size is an error. */
+ * as a3d_record_decode_u8's.  dims = {image h, w, c, depth h, w, c} (all positive): a record of any other size is an
+ * error.  The pools hold `nslots` slots; a slot number outside [0, nslots) is A3D_EINVAL and nothing is written. */
 int a3d_records_decode(const void* const* frames, const size_t* lens, int n, int verify_crc, const int64_t* dims,
                        uint8_t* image_u8_pool, float* image_f32_pool, uint8_t* depth_u8_pool, float* depth_f32_pool,
-                       const int32_t* slots, int32_t* kinds);
+                       const int32_t* slots, int nslots, int32_t* kinds);
 /* One dequeued batch from the pinned staging pool to its device buffer: record b of the batch is slot slots[b] of the pool
  * (`bytes_each` bytes per slot, both sides dense), n asynchronous host-to-device copies on `stream` issued from ONE call —
  * the shuffle queue hands out slot numbers (src/data.py:51-55: tf.train.shuffle_batch), and 2 x 32 copies per step issued
- * one by one from the host language cost more of the step's launch budget than the copies themselves. */
-int a3d_h2d_gather(void* dst, const void* src_pool, const int32_t* slots, int n, size_t bytes_each, void* stream);
+ * one by one from the host language cost more of the step's launch budget than the copies themselves.  The pool holds
+ * `nslots` slots; a slot number outside [0, nslots) is A3D_EINVAL and no copy is enqueued. */
+int a3d_h2d_gather(void* dst, const void* src_pool, const int32_t* slots, int n, int nslots, size_t bytes_each, void* stream);
 /* Serialise one framed record (writer side).  Returns bytes written, or the needed size if cap is too small
  * (nothing written then), or a negative error. */
 int64_t a3d_example_write(const float* image, int ih, int iw, int ic, const float* depth, int dh, int dw, int dc,

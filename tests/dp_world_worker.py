@@ -19,6 +19,25 @@ def main(out_path):
     rank, _, world = dp.init_from_env('gloo')
     red = dp.GradReducer()
     assert (red.rank, red.world_size) == (rank, world)
+    # the reducer's own check of the aliasing collectives (what the first RCCL job runs before it trusts reduce-scatter):
+    # passes on gloo; a reducer whose reduce-scatter returns a wrong sum on ONE rank makes EVERY rank fall back
+    assert red.inplace_ok(torch.device('cpu')) and red.inplace_ok(torch.device('cpu'))      # (cached)
+
+    class Broken(dp.GradReducer):
+        def reduce_scatter(self, flat):
+            work, self.own = super().reduce_scatter(flat)
+            return work, self.own
+
+        def wait(self, work):
+            super().wait(work)
+            if self.rank == world - 1:
+                self.own[3] += 1
+    assert not Broken().inplace_ok(torch.device('cpu'))
+
+    class Refusing(dp.GradReducer):
+        def all_gather(self, flat):
+            raise RuntimeError('input aliases output')
+    assert not Refusing().inplace_ok(torch.device('cpu'))
     numel = 1_000_003                                       # not a multiple of anything: the bucket is padded
     q = world * 64
     padded = -(-numel // q) * q

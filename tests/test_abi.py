@@ -28,6 +28,71 @@ def test_header_symbols_are_exported_and_bound():
     assert b'gfx950' in lib.a3d_version()
 
 
+def test_the_documented_binding_stub_matches_the_struct_the_library_reads():
+    """VERDICT r3 (weak 12): INTEGRATION.md's ctypes example of a3d_conv_desc fell two fields behind include/a3d.h.  The
+    field list is taken from the document itself, rebuilt as a ctypes struct, and its size and field names must be the
+    library's (a3d_sizeof_conv_desc) and the header's."""
+    import ctypes
+    lib = _lib.load()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r"class ConvDesc\(ctypes\.Structure\):.*?_fields_ = \[\(n, ctypes\.c_int32\) for n in\s*\((.*?)\)\]", doc, flags=re.S)
+    assert m, 'INTEGRATION.md no longer shows the ConvDesc stub'
+    doc_fields = re.findall(r"'(\w+)'", m.group(1))
+
+    class DocDesc(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in doc_fields]
+    assert ctypes.sizeof(DocDesc) == lib.a3d_sizeof_conv_desc() == ctypes.sizeof(_lib.ConvDesc)
+    header = open(os.path.join(ROOT, 'include', 'a3d.h')).read()
+    body = re.search(r'typedef struct a3d_conv_desc \{(.*?)\} a3d_conv_desc;', header, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    header_fields = [f.strip() for decl in re.findall(r'int32_t ([^;]+);', body) for f in decl.split(',')]
+    assert doc_fields == header_fields == [n for n, _ in _lib.ConvDesc._fields_]
+    assert 'a3d_sizeof_conv_desc' in doc
+
+
+def test_staging_pool_slots_are_range_checked():
+    """a3d_records_decode / a3d_h2d_gather index pinned pools with caller-supplied slot numbers; a slot outside
+    [0, nslots) or a non-positive dimension is A3D_EINVAL before a byte is written or a copy enqueued (no GPU needed: the
+    checks come first)."""
+    import ctypes
+
+    import numpy as np
+    lib = _lib.load()
+    img = np.full((2, 2, 3), 0.25, np.float32)
+    dep = np.full((1, 1, 1), 0.25, np.float32)
+    buf = ctypes.create_string_buffer(4096)
+    n = lib.a3d_example_write(img.ctypes.data, 2, 2, 3, dep.ctypes.data, 1, 1, 1, buf, 4096)
+    assert 0 < n < 4096
+    frame = np.frombuffer(buf.raw[:n], np.uint8).copy()
+    nslots = 3
+    ipool = np.full((nslots + 2, 2, 2, 3), 7.0, np.float32)            # two guard slots after the pool proper
+    dpool = np.full((nslots + 2, 1, 1, 1), 7.0, np.float32)
+    frames = (ctypes.c_void_p * 1)(frame.ctypes.data)
+    lens = (ctypes.c_size_t * 1)(frame.size)
+    kinds = (ctypes.c_int32 * 1)()
+    dims = (ctypes.c_int64 * 6)(2, 2, 3, 1, 1, 1)
+
+    def decode(slot, dims=dims, n=nslots):
+        return lib.a3d_records_decode(frames, lens, 1, 1, dims, None, ipool.ctypes.data, None, dpool.ctypes.data,
+                                      (ctypes.c_int32 * 1)(slot), n, kinds)
+    assert decode(1) == 0
+    np.testing.assert_array_equal(ipool[1], img + np.float32(0.5))
+    for bad in (-1, nslots, nslots + 1, 2 ** 31 - 1):
+        assert decode(bad) == -1 and 'slot' in _lib.last_error()
+    assert (ipool[[0, 2, 3, 4]] == 7.0).all() and (dpool[[0, 2, 3, 4]] == 7.0).all()     # nothing outside slot 1 was touched
+    assert decode(0, n=0) == -1
+    for j in range(6):
+        d = list(dims)
+        d[j] = 0
+        assert decode(0, dims=(ctypes.c_int64 * 6)(*d)) == -1
+        d[j] = -4
+        assert decode(0, dims=(ctypes.c_int64 * 6)(*d)) == -1
+    dst = np.zeros((1, 12), np.float32)
+    for bad in (-1, nslots, 10 ** 6):
+        rc = lib.a3d_h2d_gather(dst.ctypes.data, ipool.ctypes.data, (ctypes.c_int32 * 1)(bad), 1, nslots, 48, None)
+        assert rc == -1 and 'slot' in _lib.last_error()
+
+
 def test_errors_are_reported_not_thrown():
     lib = _lib.load()
     d = _lib.ConvDesc(n=1, h=8, w=8, c=4, k=4, r=3, s=3, stride=3, pad_t=1, pad_l=1, ho=8, wo=8, ldx=4, ldy=4)

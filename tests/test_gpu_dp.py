@@ -10,11 +10,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_ranks_share_one_gpu(tmp_path, world):
+@pytest.mark.parametrize('world,dense', [(2, 'scatter'), (4, 'scatter'), (2, 'allreduce')])
+def test_ranks_share_one_gpu(tmp_path, world, dense):
     """tests/dp_gpu_worker.py: the data-parallel replica through the HIP kernels, the ranks sharing the box's one GPU over
     gloo — two ranks (sums of two addends: bit for bit), and four (slices, padding and the gather of m at a world size
-    the scaling bench runs; sums to 1e-6)."""
+    the scaling bench runs; sums to 1e-6); and the exchange a backend that fails the in-place self-check falls back to
+    (A3D_DP_DENSE=allreduce: the dense bucket all-reduced, ApplyAdam replicated)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -23,7 +24,7 @@ def test_ranks_share_one_gpu(tmp_path, world):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo')
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo', A3D_DP_DENSE=dense)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out], env=env))
     for p in procs:
         assert p.wait(timeout=400) == 0
@@ -45,6 +46,42 @@ def test_two_ranks_at_batch_32_each_match_the_oracle_on_all_64(tmp_path):
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out, 'b32'], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
+    assert open(out).read() == '1'
+
+
+def test_a_non_finite_gradient_on_one_rank_is_repaired_on_all(tmp_path):
+    """_watch_poison / _poll_poison / _resync / gather_state of the rank-sharded dense optimizer state, at
+    replica level, two ranks (tests/dp_gpu_worker.py::main_poison)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'ok.txt')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out, 'poison'], env=env))
+    for p in procs:
+        assert p.wait(timeout=400) == 0
+    assert open(out).read() == '1'
+
+
+def test_two_bf16_storage_ranks_at_batch_64_each_match_the_oracle_on_all_128(tmp_path):
+    """BASELINE config 5's data-parallel rank — precision 'bf16s' with a reducer, B = 64 per rank — both
+    trained phases, against the oracle on the concatenated 128 samples (tests/dp_gpu_worker.py::main_bf16s)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'ok.txt')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), A3D_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, 'dp_gpu_worker.py'), out, 'bf16s'], env=env))
+    for p in procs:
+        assert p.wait(timeout=1100) == 0
     assert open(out).read() == '1'
 
 

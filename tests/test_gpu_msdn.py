@@ -193,6 +193,55 @@ def shifted_params(seed=3000, shift=1.0):
     return params
 
 
+def _window_argmax(x):
+    """[B,H,W,C] -> (first-maximum position 0..3 of every 2x2 / stride-2 window, its value): MaxPoolGrad's routing."""
+    B, H, W, C = x.shape
+    ho, wo = H // 2, W // 2
+    v = x[:, :2 * ho, :2 * wo, :].reshape(B, ho, 2, wo, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(B, ho, wo, C, 4)
+    return v.argmax(axis=-1), v.max(axis=-1)
+
+
+def decisions_taken_differently(net, a, keep, phase):
+    """The discontinuous decisions of the network under training — ReluGrad's `y > 0`, MaxPoolGrad's argmax — that the
+    GPU's forward took differently from the oracle's.  Returns (count, elements that carry a decision, a copy of the
+    oracle's activations in which exactly those elements / windows are replaced by what the GPU saw)."""
+    fix = dict(a)
+    flipped = total = 0
+    relu_layers = ('c2', 'c3', 'c4') if phase == 1 else ('f2',)
+    for k in relu_layers:
+        got = getattr(net, k).float().cpu().numpy()
+        diff = (got > 0) != (a[k] > 0)
+        flipped += int(diff.sum()); total += diff.size
+        if diff.any():
+            fix[k] = np.where(diff, got, a[k])
+    if phase == 1:
+        got = net.drop.cpu().numpy()                      # drop > 0  <=>  kept and dense_0's ReLU active
+        diff = (got > 0) != ((a['d0'] > 0) & keep)
+        flipped += int(diff.sum()); total += diff.size
+        if diff.any():
+            fix['d0'] = np.where(diff, np.where(got > 0, got, 0), a['d0'])
+            fix['drop'] = np.where(diff, got, a['drop'])
+        fix['flat'] = fix['c4'].reshape(fix['c4'].shape[0], -1)
+    pools = (('c0', 'a0', 'p0'), ('c1', 'a1', 'p1')) if phase == 1 else (('f1', 'af1', 'cat'),)
+    for full, argname, pooled in pools:
+        arg_ref, max_ref = _window_argmax(a[full])
+        arg_gpu = getattr(net, argname).cpu().numpy().astype(np.int64)
+        c = arg_gpu.shape[-1]
+        max_gpu = getattr(net, pooled).float().cpu().numpy()[..., :c]
+        # a window's decision: is its maximum positive (ReluGrad), and if so, where is it (MaxPoolGrad)
+        diff = ((max_gpu > 0) != (max_ref > 0)) | ((max_ref > 0) & (arg_gpu != arg_ref))
+        flipped += int(diff.sum()); total += diff.size
+        if diff.any():
+            eq = net.prepool_equivalent(full).cpu().numpy()          # zeros + the window's maximum where the GPU found it
+            B, H, W, C = a[full].shape
+            ho, wo = H // 2, W // 2
+            m6 = np.broadcast_to(diff[:, :, None, :, None, :], (B, ho, 2, wo, 2, C)).reshape(B, 2 * ho, 2 * wo, C)
+            out = a[full].copy()
+            out[:, :2 * ho, :2 * wo, :] = np.where(m6, eq[:, :2 * ho, :2 * wo, :], a[full][:, :2 * ho, :2 * wo, :])
+            fix[full] = out
+    return flipped, total, fix
+
+
 @pytest.mark.parametrize('phase,global_step', [(1, 0), (2, 2000000 // 32)])
 def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, global_step):
     """The replica bench.py and `make train` build on one GPU — keep_dense_grads=False: dense dW goes from the matrix
@@ -201,8 +250,11 @@ def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, glob
     m slot at 1e-4; weights untouched (beta2 = 1).  Outputs are shifted away from zero (shifted_params) so that the loss
     gradient does not amplify last-bit differences of the forward.  What is left end to end are the network's own
     discontinuities: a ReLU or max-pool decision taken the other way by a last-bit difference of the forward moves a
-    gradient by more than accumulation order does — 3.6e-4 on conv2d_3's kernel at this size — hence 1e-3 here (30x
-    tighter than GRAD_TOL_END_TO_END), while the chain test above, fed with identical activations, holds 1e-4."""
+    gradient by more than accumulation order does — 3.6e-4 on conv2d_3's kernel at this size — hence 1e-3 on the raw
+    comparison.  That explanation is SHOWN, not assumed: the decisions the two forwards took
+    differently are counted (a handful among ~10^7), and against the oracle's own end-to-end backward in which exactly
+    those elements / pool windows see what the GPU saw — every other activation, the loss gradient and all arithmetic
+    stay the oracle's — every gradient and m slot holds GRAD_TOL = 1e-4."""
     E2E = 1e-3
     B = 32
     img, dep, keep = synth(B, 4321)
@@ -232,6 +284,18 @@ def test_msdn_step_the_bench_times_matches_oracle_end_to_end(models, phase, glob
         np.testing.assert_array_equal(net.var(n).cpu().numpy(), params[n])
     if phase == 1:
         assert set(fused) <= set(g)
+    flipped, total, a_fix = decisions_taken_differently(net, a, keep, phase)
+    print(f'phase {phase}: {flipped} of {total} ReLU / max-pool decisions differ between the GPU forward and the oracle')
+    assert flipped <= 1e-5 * total                                           # 1e-7-sized forward differences flip very few
+    a_fix['keep_mask'] = keep
+    g_fix = (O.backward_coarse if phase == 1 else O.backward_fine)(params, a_fix)
+    worst_raw = max(rel(net.slot(n, 'm').cpu().numpy(), g[n] * omb1) for n in g)
+    for n, gref in g_fix.items():
+        assert rel(net.slot(n, 'm').cpu().numpy(), gref * omb1) < GRAD_TOL, (n, flipped)
+        if n not in fused:
+            assert rel(net.grad(n).cpu().numpy(), gref) < GRAD_TOL, (n, flipped)
+    if flipped == 0:
+        assert worst_raw < GRAD_TOL                                          # nothing flipped: nothing to explain
 
 
 def test_msdn_learning_mode_tracks_the_oracles_adam_slots(models):

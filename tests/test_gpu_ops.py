@@ -687,6 +687,56 @@ def test_share_cu_hint_changes_the_launch_not_the_result(ops, n, h, w, c, k, ks,
     assert torch.equal(p0, p1) and torch.equal(a0, a1) and int(a0.max()) <= 3
 
 
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad,px', [
+    (2, 47, 64, 3, 96, 11, 4, 'VALID', (5, 15, 0)),     # conv2d_0 kind: pixel 15 = the pad floats 33..35 of window ox = 1's run
+    (2, 40, 52, 3, 63, 9, 2, 'VALID', (7, 11, 2)),      # fine/first kind: run of 27 -> 28 floats, pad = pixel 2 ox + 9, channel 0
+    (2, 40, 52, 3, 63, 9, 2, 'VALID', (7, 11, 0)),
+    (2, 30, 35, 3, 64, 11, 1, 'VALID', (3, 12, 1)),     # DCNF's first conv kind (stride 1)
+    (2, 23, 29, 1, 40, 5, 1, 'VALID', (4, 6, 0)),       # one channel: run of 5 -> 8 floats, three pad pixels
+    (2, 21, 30, 64, 64, 5, 1, 'SAME', (10, 10, 7)),     # the generic kernel (out-of-image taps read as zeros)
+])
+def test_a_non_finite_pixel_reaches_only_the_windows_that_contain_it(ops, n, h, w, c, k, ks, st, pad, px):
+    """VERDICT r3 (weak 4) / ADVICE r3: the few-channel forward reads the pad positions of a window run from the
+    NEIGHBOURING pixels; they must not reach the matrix cores (0 * inf = NaN), or an image with one non-finite pixel
+    poisons windows that do not contain it, where TensorFlow's Conv2D would not (the reference treats non-finite values as
+    semantics: src/models.py:262-264).  One +inf, placed where a neighbouring window's pad reads it: the output is
+    non-finite exactly where the oracle's is — the windows that contain the pixel — with the oracle's sign (one infinite
+    product per such output: inf * w, no NaN), and unchanged elsewhere; with and without A3D_HINT_SHARE_CU (the two
+    schedules of conv3.hip) and through the fused pool."""
+    rng = np.random.default_rng(7 + h + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    wt[wt == 0] = 1e-3
+    b = rng.standard_normal(k).astype(np.float32)
+    clean = T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), st, pad, relu=False)
+    x[1, px[0], px[1], px[2]] = np.inf
+    with np.errstate(invalid='ignore', over='ignore'):
+        ref = T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), st, pad, relu=False)
+    hit = ~np.isfinite(ref)
+    assert hit.any() and not hit[0].any() and not np.isnan(ref).any()
+    assert 0 < hit[1, :, :, 0].sum() <= (-(-ks // st)) ** 2                 # a handful of windows, not the image
+    np.testing.assert_array_equal(ref[~hit], clean[~hit])
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    for hints in (0, ops.HINT_SHARE_CU):
+        d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, hints=hints)
+        y = torch.empty((n, d.ho, d.wo, k), device='cuda')
+        ops.conv2d_fwd(d, xd, wd, bd, y, None)
+        got = y.cpu().numpy()
+        np.testing.assert_array_equal(~np.isfinite(got), hit)
+        np.testing.assert_array_equal(got[hit], ref[hit])                   # +-inf, the sign of the weight it met
+        assert rel_l2(got[~hit], ref[~hit]) < RTOL_F32
+        if pad == 'VALID' and c <= 4:                                       # conv + ReLU + max pool in one launch
+            ph, pw = d.ho // 2, d.wo // 2
+            yp = torch.empty((n, ph, pw, k), device='cuda')
+            ops.conv2d_pool_fwd(d, xd, wd, bd, yp, 'relu')
+            with np.errstate(invalid='ignore'):
+                want = np.maximum(ref, 0)[:, :2 * ph, :2 * pw].reshape(n, ph, 2, pw, 2, k).max(axis=(2, 4))
+            gp = yp.cpu().numpy()
+            np.testing.assert_array_equal(np.isinf(gp), np.isinf(want))
+            assert not np.isnan(gp).any()
+            assert rel_l2(gp[np.isfinite(want)], want[np.isfinite(want)]) < RTOL_F32
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
