@@ -25,7 +25,7 @@ echo "traffic done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $out/pmc_mfma -o m -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/pmc_mfma.log 2>&1
 python3 tools/pmc_mfma.py $out/pmc_mfma/m_counter_collection.csv $out/pmc_mfma/m_kernel_trace.csv $P/${tag}_pmc_mfma_busy.json > $out/pmc_mfma.txt
 echo "mfma done"
-python3 bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --no-dp-rank --precision bf16s --also bf16,bf16x3,fp32 > $P/${tag}_bench_batch64_bf16_storage.json 2> $out/bench_b64.err
+python3 bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --precision bf16s --also bf16,bf16x3,fp32 > $P/${tag}_bench_batch64_bf16_storage.json 2> $out/bench_b64.err
 echo "b64 done"
 python3 bench.py --model dcnf --no-cpu-baseline > $P/${tag}_bench_dcnf.json 2> $out/bench_dcnf.err
 echo "dcnf done"
