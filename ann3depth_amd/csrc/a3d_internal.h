@@ -36,6 +36,7 @@ struct GemmPlan {
   int streamk;       // > 0: stream-K launch of this many blocks (splitk == 1)
   int sk_sliced;     // stream-K shares cut per XCD from eighths of the K axis (bwd-filter; SkSpace in igemm.h)
   size_t ws_bytes;   // split-K / stream-K slabs (0 if neither)
+  int ring;          // bf16 plans: 1 + tile configuration of the LDS-DMA kernel for bf16-stored operands (igemm_ring.h), 0 = igemm_bf16
 };
 
 struct GemmProblem {
@@ -44,6 +45,8 @@ struct GemmProblem {
   int avec, bvec;    // 1 or 4
   int plain = 0;     // 1: register-staged kernel without split-K only (fused-pool forward)
   int no_glds = 0;   // 1: not the LDS-DMA kernels (bf16 output)
+  int ring_ok = 0;   // 1: both operands are bf16 tensors whose 16-byte pieces lie inside one filter tap (channels % 8 == 0):
+                     //    forward / stride-1 bwd-data may run on igemm_ring.h
 };
 
 GemmPlan plan_gemm(const GemmProblem& g, int precision = 0);

@@ -23,6 +23,11 @@ int launch_fixup_mode1(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, h
 int launch_fixup_mode2(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st);
 int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
 int launch_igemm_bf16_multi_bwd_d(int bn, IgemmMulti& ps, unsigned grid_x, unsigned count, hipStream_t st);
+int launch_igemm_ring(int mode, int cfg, IgemmParams& p, unsigned grid, hipStream_t st);
+
+// tile configurations of the LDS-DMA bf16 kernel (igemm_ring.hip: A3D_RING_CFGS + the 96-column bwd-data tile)
+struct RingTile { int bm, bn; };
+static const RingTile kRingCfgs[] = {{256, 128}, {256, 64}, {256, 256}, {128, 128}, {256, 96}};
 
 struct TileCfg {
   int bm, bn;
@@ -117,9 +122,35 @@ static const int kFirstGldsCfg = 9;
 // bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
 // (even at one block per CU for the two-plane x3 variant); split-K factors: x3 by round 1's sweep
 // (profiles/r01_sweep_bf16.txt: ~600 blocks with >= 12 k-tiles each), plain bf16 by round 3's, below.
+// bf16-stored operands, forward / stride-1 bwd-data: igemm_ring.h.  One block of eight waves per CU works on a 256-row tile
+// (128 rows, two blocks per CU, where 256-row tiles would leave a third of the chip idle); never split (a launch that small
+// stays on igemm_bf16's split-K).  A3D_RING=0 turns the kernel off, A3D_RING_CFG pins a tile (tuning processes).
+static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
+  static const bool off = env_int("A3D_RING", 1) == 0;
+  if (off || !g.ring_ok || g.mode == MODE_BWD_F || g.plain) return false;
+  int cfg;
+  if (g.mode == MODE_BWD_D && g.N <= 96 && g.N > 64) cfg = 4;
+  else if (g.N <= 64) cfg = 1;
+  else if (g.N % 256 == 0 && (long)((g.M + 255) / 256) * (g.N / 256) >= 192) cfg = 2;
+  else cfg = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= 192 ? 0 : 3;
+  const int forced = tune_int("A3D_RING_CFG", -1);
+  if (forced >= 0 && forced <= 4 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
+  const int bm = kRingCfgs[cfg].bm, bn = kRingCfgs[cfg].bn;
+  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+  if (tiles < 96 && forced < 0) return false;
+  pl.ring = 1 + cfg;
+  pl.tiles_m = (g.M + bm - 1) / bm;
+  pl.tiles_n = (g.N + bn - 1) / bn;
+  pl.splitk = 1;
+  pl.ktiles_per_split = std::max(1, (g.K + 63) / 64);
+  pl.ws_bytes = 0;
+  return true;
+}
+
 static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
   GemmPlan pl{};
   pl.prec = precision;
+  if (precision == A3D_PREC_BF16 && ring_plan(g, pl)) return pl;
   pl.bf16_bn = g.N <= 64 ? 64 : 128;
   if (tune_int("A3D_BF16_BN", 0) == 64 || tune_int("A3D_BF16_BN", 0) == 128) pl.bf16_bn = tune_int("A3D_BF16_BN", 0);
   pl.tiles_m = (g.M + 127) / 128;
@@ -154,8 +185,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision);
 GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   if (tuning()) return plan_gemm_search(g, precision);
   static std::mutex mu;
-  static std::map<std::array<int, 9>, GemmPlan> cache;
-  const std::array<int, 9> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision};
+  static std::map<std::array<int, 10>, GemmPlan> cache;
+  const std::array<int, 10> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision, g.ring_ok};
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -461,13 +492,17 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   p.dbg = tune_int("A3D_DBG", 0);
   static const bool plan_log = env_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
   if (plan_log)
-    fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> cfg %d (%dx%d) splitk %d streamk %d%s grid %u\n", mode, p.M, p.N, p.K,
-            plan.cfg, kCfgs[plan.cfg].bm, kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, plan.sk_sliced ? " (K-sliced)" : "", grid);
+    fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> %s %d (%dx%d) splitk %d streamk %d%s grid %u\n", mode, p.M, p.N, p.K,
+            plan.ring ? "ring" : "cfg", plan.ring ? plan.ring - 1 : plan.cfg, plan.ring ? kRingCfgs[plan.ring - 1].bm : kCfgs[plan.cfg].bm,
+            plan.ring ? kRingCfgs[plan.ring - 1].bn : kCfgs[plan.cfg].bn, plan.splitk, plan.streamk, plan.sk_sliced ? " (K-sliced)" : "", grid);
   TimingSlot slot{};
   {
     a3d_timing_record& r = slot.rec;
     r.mode = mode; r.prec = plan.prec;
-    if (plan.prec != A3D_PREC_F32) {
+    if (plan.ring) {
+      r.bm = kRingCfgs[plan.ring - 1].bm; r.bn = kRingCfgs[plan.ring - 1].bn; r.waves_m = 0; r.nwaves = 8; r.bk = 64;
+      r.lds_dma = 3;                                        // 3: igemm_ring_kernel
+    } else if (plan.prec != A3D_PREC_F32) {
       r.bm = 128; r.bn = plan.bf16_bn; r.waves_m = 4; r.nwaves = 8; r.bk = plan.prec == A3D_PREC_BF16X3 ? 32 : 64;
     } else {
       r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
@@ -479,7 +514,8 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   }
   const bool timed = timing_wanted(slot.rec);
   if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
-  if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
+  if (plan.ring) rc = launch_igemm_ring(mode, plan.ring - 1, p, grid, st);
+  else if (plan.prec != A3D_PREC_F32) rc = launch_igemm_bf16(mode, plan.bf16_bn, plan.prec == A3D_PREC_BF16X3, p, grid, st);
   else if (mode == MODE_FWD) rc = launch_igemm_mode0(plan.cfg, avec, bvec, p, grid, st);
   else if (mode == MODE_BWD_D) rc = launch_igemm_mode1(plan.cfg, avec, bvec, p, grid, st);
   else rc = launch_igemm_mode2(plan.cfg, avec, bvec, p, grid, st);
@@ -890,6 +926,9 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
                        d->ldx, d->k, d->k, x, w, y, d->k, d->ldy);
     if (rc != A3D_OK) return rc;
     (void)keep;
+    // both operands bf16 tensors, whole 16-byte pieces inside one tap: the LDS-DMA kernel may take the launch
+    g.ring_ok = p.a16 && p.b16 && !pool && !run && d->precision == A3D_PREC_BF16 && d->c % 8 == 0 && d->ldx % 8 == 0 &&
+                d->k % 8 == 0 && d->ldy % 8 == 0 && d->r * d->s <= 128 && aligned16(y) && act != A3D_ACT_SIGMOID;
   }
   GemmPlan plan = plan_gemm(g, d->precision);
   if (ws_used + plan.ws_bytes > ws_bytes)
@@ -998,6 +1037,8 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
                          d->storage & A3D_STORE_X_BF16, d->k, d->ldy, d->k, d->k, dz, w, dx, d->c, d->ldx);
       if (rc != A3D_OK) return rc;
       A3D_CHECK_ARG(!p.c16 || !relu_mask || aligned16(relu_mask), "conv2d_bwd_data: bf16 mask must be 16-byte aligned");
+      g.ring_ok = d->stride == 1 && p.a16 && p.b16 && d->precision == A3D_PREC_BF16 && d->k % 8 == 0 && d->ldy % 8 == 0 &&
+                  d->c % 8 == 0 && d->ldx % 8 == 0 && aligned16(dx) && (!relu_mask || aligned16(relu_mask)) && c.rp * c.sp <= 128;
       GemmPlan plan = plan_gemm(g, d->precision);
       A3D_CHECK_ARG(!d->storage || plan.prec == A3D_PREC_BF16, "conv2d_bwd_data: bf16 storage needs vectorisable operands");
       if (try_multi) {                                   // 64x64 tiles, no split-K

@@ -54,6 +54,8 @@ def collect_timing(lib):
 
 
 def kernel_name(r):
+    if r.lds_dma == 3:
+        return f'igemm_ring_kernel<{r.mode}, {r.bm}, {r.bn}>'
     if r.prec:
         return f'igemm_bf16_kernel<{r.mode}, {r.bm}, {r.bn}, {"true" if r.prec == 1 else "false"}>'
     if r.lds_dma == 2:

@@ -737,6 +737,71 @@ def test_a_non_finite_pixel_reaches_only_the_windows_that_contain_it(ops, n, h, 
             assert rel_l2(gp[np.isfinite(want)], want[np.isfinite(want)]) < RTOL_F32
 
 
+RING_CASES = [
+    # n, h, w, c, k, ks, stride, pad, y bf16?, the tile the planner must pick (igemm_host.hip: kRingCfgs)
+    (28, 13, 18, 256, 384, 3, 1, 'SAME', True, (128, 128)),     # conv2d_2 kind, 128-row tiles (two blocks per CU), M tail
+    (106, 13, 18, 64, 200, 3, 1, 'SAME', True, (256, 128)),      # 256 x 128 tiles, N tail (200 = 128 + 72), K = 576 = 9 k-tiles
+    (26, 27, 37, 96, 128, 5, 1, 'SAME', True, (128, 128)),      # conv2d_1's 96 channels: a k-tile straddles two taps; K tail (2400)
+    (8, 55, 74, 64, 64, 5, 1, 'SAME', False, (256, 64)),        # fine/second kind: 64 columns, fp32 output
+    (50, 27, 37, 8, 256, 3, 1, 'SAME', True, (256, 256)),       # 256 x 256 tiles; 8 channels: every 16-byte piece is its own tap; K = 72
+    (64, 27, 37, 32, 128, 3, 2, 'VALID', True, (128, 128)),     # stride 2 forward (bwd-data of a strided conv is not a ring launch)
+    (26, 27, 37, 96, 64, 5, 1, 'SAME', True, (256, 64)),        # bwd-data: N = 96 input channels -> the 96-column tile
+]
+
+
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,pad,y16,tile', RING_CASES)
+def test_lds_dma_kernel_on_bf16_stored_operands(ops, n, h, w, c, k, ks, st, pad, y16, tile):
+    """igemm_ring.h: forward and stride-1 bwd-data of bf16-STORED tensors (BASELINE config 5's
+    activations and weight copies) staged by LDS-DMA — swizzled images, per-piece tap decode, out-of-range pieces as zeros.
+    Against the float64 oracle on the rounded operands: a bf16 output within bf16 rounding (4e-3 relative L2), an fp32
+    output within fp32 accumulation (2e-5); the launch must have been the ring kernel with the expected tile (timing
+    record), so a silent fallback to igemm_bf16 cannot pass for it."""
+    from ann3depth_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(c * 1000 + k + ks)
+    bf = torch.bfloat16
+    x = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).cuda().to(bf)
+    wt = torch.from_numpy((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)).cuda().to(bf)
+    b = dev(rng.standard_normal(k).astype(np.float32))
+    X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, precision='bf16')
+    x64, w64 = x.float().cpu().numpy().astype(np.float64), wt.float().cpu().numpy().astype(np.float64)
+    ydt = bf if y16 else torch.float32
+    tol = 4e-3 if y16 else 2e-5
+
+    def launched(fn):
+        from bench import collect_timing
+        lib.a3d_timing_select(None)
+        lib.a3d_timing_enable(1)
+        try:
+            fn()
+            torch.cuda.synchronize()
+        finally:
+            lib.a3d_timing_enable(0)
+        recs = collect_timing(lib)
+        assert len(recs) == 1
+        return recs[0]
+
+    y = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=ydt)
+    r = launched(lambda: ops.conv2d_fwd(ops.with_storage(d, X | W | (Y if y16 else 0)), x, wt, b, y, 'relu'))
+    assert r.lds_dma == 3 and (r.bm, r.bn) == tile, (r.lds_dma, r.bm, r.bn)
+    ref = T.conv2d_fwd(x64, w64, b.cpu().numpy().astype(np.float64), st, pad, relu=True)
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all() and rel_l2(got, ref) < tol
+    if st != 1:
+        return
+    dz = torch.from_numpy(rng.standard_normal((n, d.ho, d.wo, k)).astype(np.float32)).cuda().to(bf)
+    dx = torch.full((n, h, w, c), float('nan'), device='cuda', dtype=bf)
+    r = launched(lambda: ops.conv2d_bwd_data(ops.with_storage(d, X | W | Y), dz, wt, dx, relu_mask=x))
+    assert r.lds_dma == 3, (r.lds_dma, r.bm, r.bn)
+    if c == 96:
+        assert (r.bm, r.bn) == (256, 96)
+    dref = T.conv2d_bwd_data(dz.float().cpu().numpy().astype(np.float64), w64, x64.shape, st, pad) * (x64 > 0)
+    got = dx.float().cpu().numpy()
+    assert np.isfinite(got).all() and rel_l2(got, dref) < 4e-3
+    assert (got[x64 <= 0] == 0).all()                        # the fused ReluGrad of the layer below: exact zeros
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
