@@ -64,6 +64,11 @@ struct ReduceParams;
 int launch_splitk_reduce(const ReduceParams& r, hipStream_t st);
 int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float* dw, float* db, hipStream_t st);
 
+// ---- BiasAddGrad of a bf16 gradient tensor beside the LDS-DMA bwd-filter (igemm_ring.hip) ----
+size_t colsum_bf16_ws_bytes(int n);
+bool colsum_bf16_ok(int n);
+int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, hipStream_t st);
+
 // ---- single-output-channel 5x5 stencil (stencil1.hip) ----
 bool stencil1_applicable(const a3d_conv_desc* d);
 size_t stencil1_bwdf_ws_bytes(const a3d_conv_desc* d);

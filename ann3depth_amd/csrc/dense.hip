@@ -356,8 +356,11 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
 // Here dz is read once per block, and the next group's x rows and m tile are requested while the current group is
 // updated and stored, x FIRST, so that the contraction of the next group never waits on HBM.  Buffer loads and stores
 // throughout (rows and columns past the end go to the out-of-range offset): the loop body is straight-line code.
-template <int CW, int MB>
-__global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+// SL = 2 ("slim", CW = 2 only): half the columns per wave — 64 instead of 128, so half the dz, accumulator and m registers
+// (~120 instead of ~220): beside an 8-wave GEMM block of the other stream that holds half of every SIMD's register file
+// (A3D_HINT_SHARE_CU) TWO of these blocks are resident per CU instead of one.
+template <int CW, int MB, int SL = 1>
+__global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                       float* __restrict__ var_w, float* __restrict__ m_w,
                                                                       float* __restrict__ v_w, float* __restrict__ var_b,
                                                                       float* __restrict__ m_b, float* __restrict__ v_b,
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void dense_dw_adam_stream_kernel(const floa
                                                                       int gpb) {
   // MB = 1: up to 32 batch rows, a block owns 512 columns (128 per wave); MB = 2: up to 64 rows and 256 columns, so that
   // the dz registers stay at 64 per lane (batch rows x columns per wave is the same in both)
-  constexpr int BCOLS = 512 / MB, WCOLS = 128 / MB, TSTEPS = 16 * MB, TLD = BCOLS + 4;
+  constexpr int BCOLS = 512 / (MB * SL), WCOLS = 128 / (MB * SL), TSTEPS = 16 * MB, TLD = BCOLS + 4;
   constexpr int G = WCOLS / (32 * CW), NI = BCOLS / (64 * CW);
   static_assert(G >= 1 && NI >= 1, "columns per lane");
   typedef float vec __attribute__((ext_vector_type(CW)));
@@ -737,15 +740,20 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
   // at most 32 rows, 256 for up to 64
   static const bool no_stream = getenv("A3D_NO_DENSE_STREAM") && atoi(getenv("A3D_NO_DENSE_STREAM"));   // tuning aid
   static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
-  const int bcols = m <= 32 ? 512 : 256, colblocks = (n + bcols - 1) / bcols;
-  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + 511) / 512);
+  // A3D_DW_SLIM (read once; default on): the slim form for batches of at most 32 rows — measured in the step, beside the
+  // fine network's hinted GEMMs
+  static const bool slim_env = !getenv("A3D_DW_SLIM") || atoi(getenv("A3D_DW_SLIM")) != 0;
+  const bool slim = slim_env && m <= 32 && n % 2 == 0;
+  const int bcols = slim ? 256 : (m <= 32 ? 512 : 256), colblocks = (n + bcols - 1) / bcols;
+  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + (slim ? 1023 : 511)) / (slim ? 1024 : 512));
   const dim3 stream_grid(colblocks, ((k + 31) / 32 + gpb - 1) / gpb);
   const bool stream_ok = m <= 64 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream && cw != 4 && cw != 2;
   const hipStream_t hst = static_cast<hipStream_t>(stream);
-#define A3D_DW_STREAM(CWV, MBV)                                                                                          \
-  hipLaunchKernelGGL((dense_dw_adam_stream_kernel<CWV, MBV>), stream_grid, dim3(256), 0, hst, x, dz, var_w, m_w, v_w, var_b, \
+#define A3D_DW_STREAM(CWV, MBV, ...)                                                                                     \
+  hipLaunchKernelGGL((dense_dw_adam_stream_kernel<CWV, MBV, ##__VA_ARGS__>), stream_grid, dim3(256), 0, hst, x, dz, var_w, m_w, v_w, var_b, \
                      m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb)
-  if (stream_ok && m <= 32 && n % 4 == 0 && (slots & 15) == 0) A3D_DW_STREAM(4, 1);
+  if (stream_ok && slim && (slots & 7) == 0) A3D_DW_STREAM(2, 1, 2);
+  else if (stream_ok && m <= 32 && n % 4 == 0 && (slots & 15) == 0) A3D_DW_STREAM(4, 1);
   else if (stream_ok && m <= 32 && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 1);
   else if (stream_ok && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 2);
 #undef A3D_DW_STREAM

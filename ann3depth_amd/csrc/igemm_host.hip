@@ -127,7 +127,29 @@ static const int kFirstGldsCfg = 9;
 // stays on igemm_bf16's split-K).  A3D_RING=0 turns the kernel off, A3D_RING_CFG pins a tile (tuning processes).
 static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   static const bool off = env_int("A3D_RING", 1) == 0;
-  if (off || !g.ring_ok || g.mode == MODE_BWD_F || g.plain) return false;
+  if (off || !g.ring_ok || g.plain) return false;
+  if (g.mode == MODE_BWD_F) {
+    // filter gradient: few tiles (M = r s Cin rows) over a long pixel axis — 256-row tiles, split-K until every CU has one block
+    static const bool off_f = env_int("A3D_RING_BWDF", 1) == 0;
+    if (off_f || g.M < 512 || g.N < 64 || g.K < 64 * 64) return false;      // (short pixel axes stay with igemm_bf16's finer tiles)
+    int cfg = g.N <= 64 ? 1 : (g.N % 256 == 0 ? 2 : 0);
+    const int forced = tune_int("A3D_RING_CFG", -1);
+    if (forced >= 0 && forced <= 3) cfg = forced;
+    const int bm = kRingCfgs[cfg].bm, bn = kRingCfgs[cfg].bn;
+    pl.tiles_m = (g.M + bm - 1) / bm;
+    pl.tiles_n = (g.N + bn - 1) / bn;
+    const long tiles = (long)pl.tiles_m * pl.tiles_n;
+    const int nk = std::max(1, (g.K + 63) / 64);
+    int splitk = (int)std::min<long>(std::max<long>(256 / tiles, 1), std::max(1, nk / 8));
+    if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), nk);
+    while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
+    const int kps = (nk + splitk - 1) / splitk;
+    pl.ring = 1 + cfg;
+    pl.splitk = (nk + kps - 1) / kps;
+    pl.ktiles_per_split = kps;
+    pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * g.M * g.N * 4 : 0;
+    return true;
+  }
   int cfg;
   if (g.mode == MODE_BWD_D && g.N <= 96 && g.N > 64) cfg = 4;
   else if (g.N <= 64) cfg = 1;
@@ -1127,11 +1149,22 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
   return A3D_OK;
 }
 
+// bf16 x and bf16 dz, whole 16-byte pieces inside one filter tap, 31-bit byte offsets into x: the LDS-DMA kernel may take the
+// filter gradient (BiasAddGrad then comes from colsum_bf16)
+static bool bwd_f_ring_ok(const a3d_conv_desc* d) {
+  const int both = A3D_STORE_X_BF16 | A3D_STORE_Y_BF16;
+  return d->precision == A3D_PREC_BF16 && (d->storage & both) == both && d->c % 8 == 0 && d->ldx % 8 == 0 && d->k % 8 == 0 &&
+         d->ldy % 8 == 0 && (double)d->n * d->h * d->w * d->ldx * 2.0 < 2147483647.0 && colsum_bf16_ok(d->k) && d->ldy == d->k;
+}
+
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
-  GemmPlan plan = plan_gemm(bwd_f_problem(d), d->precision);
+  GemmProblem g0 = bwd_f_problem(d);
+  g0.ring_ok = bwd_f_ring_ok(d);
+  GemmPlan plan = plan_gemm(g0, d->precision);
   size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
+  if (plan.ring) need = plan.ws_bytes + colsum_bf16_ws_bytes(d->k);
   RunForm rf;
   if (run_form_ok(d, nullptr, &rf, true)) {
     GemmProblem g = bwd_f_problem(d);
@@ -1169,11 +1202,18 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   rc = apply_storage(p, g, d->precision, d->storage & A3D_STORE_X_BF16, d->storage & A3D_STORE_Y_BF16, false, d->c, d->ldx,
                      -1, d->ldy, x, dz, dw, d->k, d->k);
   if (rc != A3D_OK) return rc;
+  g.ring_ok = !run && p.a16 && p.b16 && bwd_f_ring_ok(d) && aligned16(dw);
   GemmPlan plan = plan_gemm(g, d->precision);
   A3D_CHECK_ARG(!d->storage || plan.prec == A3D_PREC_BF16, "conv2d_bwd_filter: bf16 storage needs vectorisable operands");
   size_t need = ws_used + plan.ws_bytes + (plan.splitk > 1 && db ? (size_t)plan.splitk * g.N * 4 : 0);
+  if (plan.ring) need = plan.ws_bytes + (db ? colsum_bf16_ws_bytes(d->k) : 0);
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (plan.ring && db) {                           // the LDS-DMA kernel never holds dz in registers: BiasAddGrad on the side
+    rc = colsum_bf16(dz, g.K, d->k, d->ldy, db, static_cast<char*>(ws) + plan.ws_bytes, st);
+    if (rc != A3D_OK) return rc;
+    db = nullptr;
+  }
   p.A = x; p.B = dz; p.C = out; p.dbias = db;     // BiasAddGrad = column sums of dz, fused into the same kernel
   p.npix = g.K; p.nrsc = g.M;
   p.H = d->h; p.W = d->w; p.ld = d->ldx; p.pHW = d->h * d->w;

@@ -1,5 +1,5 @@
 // igemm_ring.h — the implicit-GEMM convolution on the bf16 matrix cores for bf16-STORED operands (BASELINE config 5:
-// bf16 activations and weight copies in HBM), forward and bwd-data, with its tiles staged by LDS-DMA.
+// bf16 activations and weight copies in HBM), forward, stride-1 bwd-data and bwd-filter, with its tiles staged by LDS-DMA.
 //
 // Why a second bf16 kernel.  igemm_bf16.h stages global -> registers -> LDS: per k-tile a wave walks the serial chain
 // buffer_load x4 -> s_waitcnt vmcnt -> ds_write x4 -> s_barrier -> ds_read x20 -> 8 MFMA, all eight waves in lockstep behind
@@ -32,12 +32,13 @@ typedef __attribute__((address_space(3))) void* ring_lptr_t;
 
 template <int MODE, int BM, int BN, int WAVES_M>
 struct RingCfg {
-  static_assert(MODE == MODE_FWD || MODE == MODE_BWD_D, "forward and bwd-data only");
   static constexpr int BK = 64, NWAVES = 8, NT = 512, WAVES_N = NWAVES / WAVES_M;
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
   static_assert(TM >= 1 && TN >= 1 && TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN, "tile");
+  static constexpr bool A_KC = MODE != MODE_BWD_F;           // A tile k-contiguous ([BM][64]) or pixel-major ([64 pixels][BM])
   static constexpr bool B_KC = MODE == MODE_BWD_D;           // B tile k-contiguous ([BN][64]) or as stored ([64][BN])
-  static_assert(B_KC || BN == 64 || BN == 128 || BN == 256, "forward filter tile: 128-, 256- or 512-byte rows");
+  static_assert(B_KC || BN == 64 || BN == 128 || BN == 256, "[64][BN] tile: 128-, 256- or 512-byte rows");
+  static_assert(A_KC || BM == 128 || BM == 256, "[64][BM] tile: 256- or 512-byte rows");
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;     // 1-KiB LDS-DMA wave-instructions
   static constexpr int A_NI = (A_PIECES + 7) / 8, B_NI = (B_PIECES + 7) / 8;     // ... per wave
@@ -46,7 +47,8 @@ struct RingCfg {
   static constexpr int NSTAGE = 2;
   static constexpr int MAXTAPS = 128;
   // (the epilogue stages 32 x WN outputs per wave in the tile buffers: at most 8 x 32 x (4 WN + 16) bytes)
-  static constexpr size_t TILE_AND_TABLES = (size_t)NSTAGE * STAGE + (size_t)BM * 16 + (size_t)MAXTAPS * 16;
+  static constexpr int TAB_ROWS = BM > 256 ? BM : 256;       // row table (BM entries) / bwd-filter: four k-tiles' pixel tables
+  static constexpr size_t TILE_AND_TABLES = (size_t)NSTAGE * STAGE + (size_t)TAB_ROWS * 16 + (size_t)MAXTAPS * 16;
   static constexpr size_t EPI_BYTES = (size_t)8 * 32 * (WN * 4 + 16);
   static constexpr size_t LDS_BYTES = TILE_AND_TABLES > EPI_BYTES ? TILE_AND_TABLES : EPI_BYTES;
   // registers: one block per CU for the big tiles (two wavefronts per SIMD, up to 256 registers each)
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int4* rowtab = reinterpret_cast<int4*>(smem_raw + Cfg::NSTAGE * Cfg::STAGE);
-  int4* taptab = rowtab + BM;
+  int4* taptab = rowtab + Cfg::TAB_ROWS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,18 +126,31 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   //      valid}, one per filter tap {dy, dx, byte offset of the tap in the gathered image, byte offset of the tap in the
   //      filter (bwd-data)} ----
   const int pW = p.W, pld = p.ld;
-  uint32_t nf;
-  {
+  uint32_t nf = 0;
+  // bwd-filter: the pixel axis is K.  Table of k-tile kt (64 entries {byte offset of the pixel's reference position in the
+  // whole tensor, y0, x0}) lives in slot kt & 3; it is written three iterations before the tile's offsets are computed
+  auto write_pix = [&](int kt) {
+    if (tid < 64) {
+      int4 e = make_pix<false>(p, kt * BK + tid);
+      e.x = (e.x + e.y * pW + e.z) * pld * 2;
+      if (!e.w || kt >= kt_end) e.y = -(1 << 30);
+      rowtab[(kt & 3) * 64 + tid] = e;
+    }
+  };
+  if constexpr (MODE == MODE_BWD_F) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) write_pix(kt_begin + t);
+  } else {
     const int px = m0 < p.npix ? m0 : p.npix - 1;
     nf = __builtin_amdgcn_readfirstlane(fdiv((uint32_t)px, p.div_phw));
   }
-  if (tid < BM) {
+  if (MODE != MODE_BWD_F && tid < BM) {
     int4 e = make_pix<TRANSPOSED>(p, m0 + tid);
     e.x = ((e.x - (int)(nf * (uint32_t)p.pHW)) + e.y * pW + e.z) * pld * 2;
     if (!e.w) e.y = -(1 << 30);                   // rows past M fail the range test like any halo pixel
     rowtab[tid] = e;
   }
-  for (int t = tid; t < p.ntaps; t += Cfg::NT) {
+  for (int t = tid; MODE != MODE_BWD_F && t < p.ntaps; t += Cfg::NT) {
     const uint32_t r = fdiv((uint32_t)t, p.div_s), sx = (uint32_t)t - r * p.div_s.d;
     int4 e;
     e.x = SGN * (int)r;
@@ -151,10 +166,25 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   const int row0 = wave * 8 + (lane >> 3);
   const int kc = (lane & 7) ^ ring_swz(row0);     // this lane's SOURCE k-chunk (8 bf16) inside every k-tile
   int a_rowoff[Cfg::A_NI], a_y0[Cfg::A_NI], a_x0[Cfg::A_NI];
+  // bwd-filter: the A image is [64 pixels][BM] — a lane's pieces are one fixed 16-byte column chunk (one filter tap, eight
+  // channels: decoded once) of the pixel rows a_krow + 8 j (512 / BM) of every k-tile
+  constexpr int CPRA = BM / 8;
+  int a_krow = 0, a_dy = 0, a_dx = 0, a_coloff = 0;
+  bool a_mvalid = true;
+  if constexpr (MODE == MODE_BWD_F) {
+    const int id = wave * 64 + lane;
+    a_krow = id / CPRA;
+    const int cpos = id % CPRA, sw = (a_krow & 3) << 2;
+    const ColDec dc = decode_col(p, m0 + 8 * (cpos ^ sw));
+    a_dy = dc.r; a_dx = dc.s;
+    a_coloff = ((dc.r * pW + dc.s) * pld + dc.c) * 2;
+    a_mvalid = dc.valid;
+  } else {
 #pragma unroll
-  for (int j = 0; j < Cfg::A_NI; ++j) {
-    const int4 e = rowtab[row0 + 64 * j];
-    a_rowoff[j] = e.x; a_y0[j] = e.y; a_x0[j] = e.z;
+    for (int j = 0; j < Cfg::A_NI; ++j) {
+      const int4 e = rowtab[row0 + 64 * j];
+      a_rowoff[j] = e.x; a_y0[j] = e.y; a_x0[j] = e.z;
+    }
   }
   uint32_t b_voff[Cfg::B_NI];                     // loop-invariant part of the B pieces' offsets (kOOB: never valid)
 #pragma unroll
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     }
   }
   const unsigned long long a_boff = (unsigned long long)nf * (unsigned long long)p.pHW * (unsigned long long)pld;
-  const ring_u32x4 rsA = ring_rsrc(reinterpret_cast<const __bf16*>(p.A) + a_boff, (p.a_elems - a_boff) * 2ull);
+  const ring_u32x4 rsA = ring_rsrc(reinterpret_cast<const __bf16*>(p.A) + a_boff, (p.a_elems - a_boff) * 2ull);   // (bwd-filter: the whole tensor, < 2^31 bytes: host)
   const ring_u32x4 rsB = ring_rsrc(p.B, p.b_elems * 2ull);
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((ring_lptr_t)smem_raw);      // LDS byte address of the first stage
 
@@ -181,6 +211,20 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   // MFMAs of the third k-step; fire_a / fire_b are then nothing but the LDS-DMAs, issued behind the first / second k-step.
   uint32_t aoff[Cfg::A_NI], boff[Cfg::B_NI];
   auto prep = [&](int kt) {
+    if constexpr (MODE == MODE_BWD_F) {
+      const int4* tab = rowtab + (kt & 3) * 64;
+#pragma unroll
+      for (int j = 0; j < Cfg::A_NI; ++j) {
+        const int4 e = tab[a_krow + j * (8 * 64 / CPRA)];
+        const int y = e.y + a_dy, x = e.z + a_dx;
+        const bool ok = a_mvalid & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        aoff[j] = ok ? (uint32_t)(e.x + a_coloff) : kOOB;
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::B_NI; ++j)
+        boff[j] = (b_voff[j] != kOOB && kt < kt_end) ? b_voff[j] + (uint32_t)kt * (uint32_t)(BK * p.ldb * 2) : kOOB;   // pixels past the end: past the end
+      return;
+    }
     const int k0 = kt * BK + kc * 8;
     const uint32_t tap = fdiv((uint32_t)k0, p.div_c);
     const int ch = k0 - (int)(tap * p.div_c.d);
@@ -212,10 +256,17 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
 
   // ---- fragment addresses (bytes inside a stage) ----
   int a_fr[TM], b_fr[TN];
+  constexpr int ROWA = BM * 2;                    // bytes per pixel row of the bwd-filter A tile
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
-    const int row = wm * Cfg::WM + a * 32 + li;
-    a_fr[a] = row * 128 + ((lh ^ ring_swz(row)) << 4);          // k-step s: ^ (s << 5)
+    if constexpr (Cfg::A_KC) {
+      const int row = wm * Cfg::WM + a * 32 + li;
+      a_fr[a] = row * 128 + ((lh ^ ring_swz(row)) << 4);        // k-step s: ^ (s << 5)
+    } else {
+      const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
+      const int c = ((wm * Cfg::WM + a * 32) >> 3) + 2 * cb + (pp >> 1);
+      a_fr[a] = (8 * h + q) * ROWA + ((c ^ (q << 2)) << 4) + (pp & 1) * 8;                  // k-step s: + 16 s ROWA
+    }
   }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
@@ -247,7 +298,16 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   bf16x8 af[2][TM], bf[2][TN];
   auto read_frags = [&](const unsigned char* st, int s, int buf) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) af[buf][a] = *reinterpret_cast<const bf16x8*>(st + (a_fr[a] ^ (s << 5)));
+    for (int a = 0; a < TM; ++a) {
+      if constexpr (Cfg::A_KC) {
+        af[buf][a] = *reinterpret_cast<const bf16x8*>(st + (a_fr[a] ^ (s << 5)));
+      } else {
+        const __bf16* q0 = reinterpret_cast<const __bf16*>(st + a_fr[a] + s * 16 * ROWA);
+        const bf16x4 lo4 = lds_read_tr(q0), hi4 = lds_read_tr(q0 + 2 * ROWA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[buf][a][e] = lo4[e]; af[buf][a][4 + e] = hi4[e]; }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       if constexpr (Cfg::B_KC) {
@@ -267,7 +327,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       for (int b = 0; b < TN; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][a], bf[buf][b], acc[a][b], 0, 0, 0);
   };
-  constexpr int NREADS = TM + (Cfg::B_KC ? TN : 2 * TN), NMFMA = TM * TN;
+  constexpr int NREADS = (Cfg::A_KC ? TM : 2 * TM) + (Cfg::B_KC ? TN : 2 * TN), NMFMA = TM * TN;
   constexpr int PER = (NREADS + NMFMA - 1) / NMFMA;
   auto interleave = [&]() {                       // one MFMA, then its share of the LDS reads issued ahead of the group
 #pragma unroll
@@ -315,6 +375,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       if (dma_b) fire_b(it & 1);
     }
     prep(kt_begin + it + 3);
+    if constexpr (MODE == MODE_BWD_F) write_pix(kt_begin + it + 4);      // (slot of tile `it`: read three iterations ago)
   }
 
   // ---- epilogue: bias / activation in registers, then the tile leaves as WHOLE 16-byte row pieces.  A lane of the MFMA
@@ -331,6 +392,12 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   static_assert(LPR <= 64 && 32 % RPI == 0, "staging rows divide over the lanes");
   static_assert((size_t)8 * 32 * EP <= Cfg::LDS_BYTES, "staging rows fit the tile buffers");
   __syncthreads();                                 // every wave is done with the stages
+  float* Cout = p.C;                               // bwd-filter under split-K: this split's slab, rows of N floats
+  int ldc = p.ldc;
+  if (MODE == MODE_BWD_F && p.splitk > 1) {
+    Cout = p.C + (size_t)split * p.slab;
+    ldc = p.N;
+  }
   unsigned char* eb = smem_raw + wave * (32 * EP);
   const int er = lane / LPRP, ec = lane % LPRP;    // 16-byte phase: this lane's row within a group of RPI, its piece of the row
 #pragma unroll
@@ -377,7 +444,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       if (LPR != LPRP && ec >= LPR) continue;
       u32x4 q = *reinterpret_cast<const u32x4*>(eb + r * EP + ec * 16);
       if (row < p.M && col0 < p.N) {               // (N is a multiple of the piece: host)
-        const size_t o = (size_t)row * p.ldc + col0;
+        const size_t o = (size_t)row * ldc + col0;
         if (MODE == MODE_BWD_D && p.mask) {        // ReluGrad of the layer below: dx = 0 where its activation is not positive
           if constexpr (C16) {
             const u32x4 mk = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.mask) + o);
@@ -392,8 +459,8 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
             for (int e = 0; e < 4; ++e) q[e] = mk[e] > 0.f ? q[e] : 0u;
           }
         }
-        if constexpr (C16) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(p.C) + o) = q;
-        else *reinterpret_cast<u32x4*>(p.C + o) = q;
+        if constexpr (C16) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(Cout) + o) = q;
+        else *reinterpret_cast<u32x4*>(Cout + o) = q;
       }
     }
   }

@@ -800,6 +800,15 @@ def test_lds_dma_kernel_on_bf16_stored_operands(ops, n, h, w, c, k, ks, st, pad,
     got = dx.float().cpu().numpy()
     assert np.isfinite(got).all() and rel_l2(got, dref) < 4e-3
     assert (got[x64 <= 0] == 0).all()                        # the fused ReluGrad of the layer below: exact zeros
+    # filter gradient: bf16 x and dz through the pixel-major LDS images (both operands by the transposing read), float32 dw
+    # by split-K slabs, BiasAddGrad by the column-sum kernels; the old kernel where the GEMM has too few rows / columns
+    dw = torch.full((ks, ks, c, k), float('nan'), device='cuda')
+    db = torch.full((k,), float('nan'), device='cuda')
+    r = launched(lambda: ops.conv2d_bwd_filter(ops.with_storage(d, X | Y), x, dz, dw, db))
+    assert (r.lds_dma == 3) == (ks * ks * c >= 512 and k >= 64), (r.lds_dma, r.bm, r.bn)
+    wref, bref = T.conv2d_bwd_filter(x64, dz.float().cpu().numpy().astype(np.float64), wt.shape, st, pad)
+    assert rel_l2(dw.cpu().numpy(), wref) < 1e-4
+    assert rel_l2(db.cpu().numpy(), bref) < 1e-5
 
 
 def test_timing_brackets_every_launch_or_one_kernel(ops):
