@@ -76,6 +76,8 @@ SIGNATURES = {
     'a3d_maxpool2x2_bwd_idx_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P]),
     'a3d_dense_bwd_filter_adam_tf1': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                               c_float, c_float, c_float, _P]),
+    'a3d_dense_bwd_filter_adam_tf1_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
+                                                 c_float, c_float, c_float, c_int, _P]),
     'a3d_superpixel_mean': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     'a3d_superpixel_hist': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P]),
     'a3d_pair_similarity': (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P, c_float, _P, _P, _P]),

@@ -359,7 +359,14 @@ __global__ __launch_bounds__(256) void dense_dw_adam_rows_kernel(const float* __
 // SL = 2 ("slim", CW = 2 only): half the columns per wave — 64 instead of 128, so half the dz, accumulator and m registers
 // (~120 instead of ~220): beside an 8-wave GEMM block of the other stream that holds half of every SIMD's register file
 // (A3D_HINT_SHARE_CU) TWO of these blocks are resident per CU instead of one.
-template <int CW, int MB, int SL = 1>
+// BF (precision A3D_PREC_BF16, batches of up to 64 rows: BASELINE config 5): the contraction on the bf16 matrix cores —
+// x and dz rounded to bf16 once (dz into packed registers, x while it is parked in LDS, transposed so that a lane's eight
+// batch rows are one 16-byte read), fp32 accumulation, four v_mfma_f32_32x32x16_bf16 per tile instead of 32
+// v_mfma_f32_32x32x2_f32 of 64 cycles each: at 64 rows the fp32 form needs 56 % of the matrix pipe to keep up with HBM and
+// shares it with the other stream's GEMM (3.8 TB/s alone, 2.7 in the step); this one is a stream again.  Columns per block
+// as for 32 rows (512, 128 per wave).
+typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
+template <int CW, int MB, int SL = 1, bool BF = false>
 __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                       float* __restrict__ var_w, float* __restrict__ m_w,
                                                                       float* __restrict__ v_w, float* __restrict__ var_b,
@@ -368,15 +375,20 @@ __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_ker
                                                                       int gpb) {
   // MB = 1: up to 32 batch rows, a block owns 512 columns (128 per wave); MB = 2: up to 64 rows and 256 columns, so that
   // the dz registers stay at 64 per lane (batch rows x columns per wave is the same in both)
-  constexpr int BCOLS = 512 / (MB * SL), WCOLS = 128 / (MB * SL), TSTEPS = 16 * MB, TLD = BCOLS + 4;
+  constexpr int CDIV = BF ? SL : MB * SL;
+  constexpr int BCOLS = 512 / CDIV, WCOLS = 128 / CDIV, TSTEPS = BF ? 1 : 16 * MB, TLD = BCOLS + 4;
   constexpr int G = WCOLS / (32 * CW), NI = BCOLS / (64 * CW);
   static_assert(G >= 1 && NI >= 1, "columns per lane");
+  static_assert(!BF || MB == 2, "the bf16 form takes up to 64 batch rows");
+  constexpr int XLD = 72;                        // bf16 elements per weight row of the transposed x tile (144 bytes: conflict-free b128 reads)
   typedef float vec __attribute__((ext_vector_type(CW)));
   typedef uint32_t uvec __attribute__((ext_vector_type(CW)));
   // the gradient tile passes through LDS sixteen rows at a time (33 KiB at MB = 1, not 66: two of these blocks fit beside
   // a GEMM block of the other stream that leaves half of the CU's LDS free); wave w updates rows 4w .. 4w+3 of each half
   __shared__ __attribute__((aligned(16))) float tile[16 * TLD];
-  __shared__ __attribute__((aligned(16))) float xs[32 * MB * 32];   // x[batch row][weight row of the group]
+  __shared__ __attribute__((aligned(16))) float xs[32 * MB * 32];   // x[batch row][weight row of the group]; BF: bf16 [weight row][XLD batch rows]
+  __bf16* xsb = reinterpret_cast<__bf16*>(xs);
+  static_assert(32 * XLD * 2 <= 32 * 2 * 32 * 4, "transposed tile fits");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int nb = blockIdx.x * BCOLS, n0 = nb + wave * WCOLS;
@@ -386,15 +398,31 @@ __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_ker
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned long long)M * K * 4);
   const __amdgpu_buffer_rsrc_t rz = make_rsrc(dz, (unsigned long long)M * N * 4);
 
-  // dz: lane's CW columns of group gq, batch rows 2u + lh
+  // dz: lane's CW columns of group gq, batch rows 2u + lh (BF: rows 16 t + 8 lh + e as element e of the bf16 fragment of step t)
   float bq[TSTEPS][G][CW];
+  dbf16x8 bqb[BF ? 4 : 1][G][CW];
+  if constexpr (BF) {
 #pragma unroll
-  for (int u = 0; u < TSTEPS; ++u)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-      const int m = 2 * u + lh, col = n0 + (32 * gq + li) * CW;
-      load_vec_buf<CW>(rz, ((m < M) & (col < N)) ? (uint32_t)(((size_t)m * N + col) * 4) : kOOB, bq[u][gq]);
-    }
+      for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int m = 16 * t + 8 * lh + e, col = n0 + (32 * gq + li) * CW;
+          float v[CW];
+          load_vec_buf<CW>(rz, ((m < M) & (col < N)) ? (uint32_t)(((size_t)m * N + col) * 4) : kOOB, v);
+#pragma unroll
+          for (int j = 0; j < CW; ++j) bqb[t][gq][j][e] = (__bf16)v[j];
+        }
+  } else {
+#pragma unroll
+    for (int u = 0; u < TSTEPS; ++u)
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        const int m = 2 * u + lh, col = n0 + (32 * gq + li) * CW;
+        load_vec_buf<CW>(rz, ((m < M) & (col < N)) ? (uint32_t)(((size_t)m * N + col) * 4) : kOOB, bq[u][gq]);
+      }
+  }
   // x rows of a group: 32*MB batch rows x 32 weight rows = MB 16-byte loads per thread (K % 4 == 0)
   const int xm = tid >> 3, xk = (tid & 7) * 4;
   auto load_x = [&](float (&xv)[MB][4], int g) {
@@ -406,8 +434,14 @@ __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_ker
   };
   auto park_x = [&](const float (&xv)[MB][4]) {
 #pragma unroll
-    for (int b = 0; b < MB; ++b)
-      *reinterpret_cast<f32x4v*>(&xs[(xm + 32 * b) * 32 + xk]) = (f32x4v){xv[b][0], xv[b][1], xv[b][2], xv[b][3]};
+    for (int b = 0; b < MB; ++b) {
+      if constexpr (BF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xsb[(xk + i) * XLD + xm + 32 * b] = (__bf16)xv[b][i];
+      } else {
+        *reinterpret_cast<f32x4v*>(&xs[(xm + 32 * b) * 32 + xk]) = (f32x4v){xv[b][0], xv[b][1], xv[b][2], xv[b][3]};
+      }
+    }
   };
   // m tile of a group: this wave's eight rows (wrow: 4 wave .. +3 of either half of the group), NI pieces each.  One
   // resource per row (scalar arithmetic: a row that does not exist gets zero records), one lane offset for all of them.
@@ -467,6 +501,17 @@ __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_ker
       for (int j = 0; j < CW; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[gq][j][v] = 0.f;
+    if constexpr (BF) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const dbf16x8 a = *reinterpret_cast<const dbf16x8*>(&xsb[li * XLD + 16 * t + 8 * lh]);
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+          for (int j = 0; j < CW; ++j)
+            acc[gq][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bqb[t][gq][j], acc[gq][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < TSTEPS; ++u) {
       const float a = xs[(2 * u + lh) * 32 + li];
@@ -475,6 +520,7 @@ __global__ __launch_bounds__(256, SL == 2 ? 4 : 2) void dense_dw_adam_stream_ker
 #pragma unroll
         for (int j = 0; j < CW; ++j)
           acc[gq][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[u][gq][j], acc[gq][j], 0, 0, 0);
+    }
     }
     // gradient tile -> LDS, sixteen rows per pass: register v = 8 hh + vv of group gq's CW accumulators = columns
     // 128*wave + (32 gq + li)*CW .. of row 16 hh + (vv&3) + 8*(vv>>2) + 4*lh
@@ -725,6 +771,15 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
                                              float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1,
                                              float beta2, float beta1_power, float beta2_power, float grad_scale,
                                              void* stream) {
+  return a3d_dense_bwd_filter_adam_tf1_ex(m, k, n, x, dz, var_w, m_w, v_w, var_b, m_b, v_b, lr, beta1, beta2, beta1_power,
+                                          beta2_power, grad_scale, A3D_PREC_F32, stream);
+}
+
+extern "C" int a3d_dense_bwd_filter_adam_tf1_ex(int m, int k, int n, const float* x, const float* dz, float* var_w, float* m_w,
+                                                float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1,
+                                                float beta2, float beta1_power, float beta2_power, float grad_scale,
+                                                int precision, void* stream) {
+  A3D_CHECK_ARG(precision == A3D_PREC_F32 || precision == A3D_PREC_BF16, "dense_bwd_filter_adam: precision %d (float32 or bf16)", precision);
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0 && x && dz && var_w && m_w && v_w, "dense_bwd_filter_adam: bad arguments");
   A3D_CHECK_ARG((var_b && m_b && v_b) || (!var_b && !m_b && !v_b), "dense_bwd_filter_adam: bias slots come as a set");
   A3D_CHECK_ARG(dense_dw_applicable(m, k, n), "dense_bwd_filter_adam: batches of at most 64 rows only");
@@ -744,7 +799,8 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
   // fine network's hinted GEMMs
   static const bool slim_env = !getenv("A3D_DW_SLIM") || atoi(getenv("A3D_DW_SLIM")) != 0;
   const bool slim = slim_env && m <= 32 && n % 2 == 0;
-  const int bcols = slim ? 256 : (m <= 32 ? 512 : 256), colblocks = (n + bcols - 1) / bcols;
+  const bool bf_cols = precision == A3D_PREC_BF16 && m > 32;      // the bf16 form: 512 columns per block at any batch
+  const int bcols = slim ? 256 : ((m <= 32 || bf_cols) ? 512 : 256), colblocks = (n + bcols - 1) / bcols;
   const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + (slim ? 1023 : 511)) / (slim ? 1024 : 512));
   const dim3 stream_grid(colblocks, ((k + 31) / 32 + gpb - 1) / gpb);
   const bool stream_ok = m <= 64 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream && cw != 4 && cw != 2;
@@ -752,7 +808,11 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x
 #define A3D_DW_STREAM(CWV, MBV, ...)                                                                                     \
   hipLaunchKernelGGL((dense_dw_adam_stream_kernel<CWV, MBV, ##__VA_ARGS__>), stream_grid, dim3(256), 0, hst, x, dz, var_w, m_w, v_w, var_b, \
                      m_b, v_b, m, k, n, 1.f - beta1, grad_scale, gpb)
-  if (stream_ok && slim && (slots & 7) == 0) A3D_DW_STREAM(2, 1, 2);
+  // bf16 arithmetic (config 5): the bf16 matrix cores take the batch axis 16 rows per instruction — worth it above 32 rows
+  const bool bf = precision == A3D_PREC_BF16 && m > 32 && stream_ok;
+  if (bf && n % 4 == 0 && (slots & 15) == 0) A3D_DW_STREAM(4, 2, 1, true);
+  else if (bf && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 2, 1, true);
+  else if (stream_ok && slim && (slots & 7) == 0) A3D_DW_STREAM(2, 1, 2);
   else if (stream_ok && m <= 32 && n % 4 == 0 && (slots & 15) == 0) A3D_DW_STREAM(4, 1);
   else if (stream_ok && m <= 32 && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 1);
   else if (stream_ok && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 2);

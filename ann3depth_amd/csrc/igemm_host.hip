@@ -27,7 +27,7 @@ int launch_igemm_ring(int mode, int cfg, IgemmParams& p, unsigned grid, hipStrea
 
 // tile configurations of the LDS-DMA bf16 kernel (igemm_ring.hip: A3D_RING_CFGS + the 96-column bwd-data tile)
 struct RingTile { int bm, bn; };
-static const RingTile kRingCfgs[] = {{256, 128}, {256, 64}, {256, 256}, {128, 128}, {256, 96}};
+static const RingTile kRingCfgs[] = {{256, 128}, {256, 64}, {256, 256}, {128, 128}, {256, 96}, {512, 64}};
 
 struct TileCfg {
   int bm, bn;
@@ -152,11 +152,11 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   }
   int cfg;
   if (g.mode == MODE_BWD_D && g.N <= 96 && g.N > 64) cfg = 4;
-  else if (g.N <= 64) cfg = 1;
+  else if (g.N <= 64) cfg = (g.M + 511) / 512 >= 192 ? 5 : 1;      // 64 columns: 512-row tiles (wave tiles of 64 x 64) when they fill the chip
   else if (g.N % 256 == 0 && (long)((g.M + 255) / 256) * (g.N / 256) >= 192) cfg = 2;
   else cfg = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= 192 ? 0 : 3;
   const int forced = tune_int("A3D_RING_CFG", -1);
-  if (forced >= 0 && forced <= 4 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
+  if (forced >= 0 && forced <= 5 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
   const int bm = kRingCfgs[cfg].bm, bn = kRingCfgs[cfg].bn;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
   if (tiles < 96 && forced < 0) return false;

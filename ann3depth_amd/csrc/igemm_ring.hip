@@ -7,7 +7,7 @@
 namespace a3d {
 
 // index, BM, BN, WAVES_M  (keep in step with kRingCfgs in igemm_host.hip)
-#define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4)
+#define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4) X(5, 512, 64, 8)
 
 template <int MODE, int BM, int BN, int WAVES_M, bool C16>
 static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {

@@ -709,7 +709,7 @@ class MSDNReplica:
             kw = [g.view(buf, name + '/kernel') for buf in (g.var, g.m, g.v)]
             kb = [g.view(buf, name + '/bias') for buf in (g.var, g.m, g.v)]
             ops.dense_bwd_filter_adam_tf1(x, dz, *kw, *kb, g.lr, g.beta1, g.beta2, float(g.beta1_power),
-                                          float(g.beta2_power), 1.0)
+                                          float(g.beta2_power), 1.0, precision='bf16' if self.bf16s else 'fp32')
         else:
             ops.dense_bwd_filter(x, dz, self._g(name + '/kernel'), self._g(name + '/bias'))
 

@@ -266,13 +266,15 @@ def adam_apply_tf1(var, m, v, g, lr, beta1, beta2, eps, beta1_power, beta2_power
 
 
 def dense_bwd_filter_adam_tf1(x, dz, var_w, m_w, v_w, var_b, m_b, v_b, lr, beta1, beta2, beta1_power, beta2_power,
-                              grad_scale=1.0):
-    """dense_bwd_filter + ApplyAdam(beta2 = 1) of one dense layer in one pass; the gradient is not materialised."""
+                              grad_scale=1.0, precision='fp32'):
+    """dense_bwd_filter + ApplyAdam(beta2 = 1) of one dense layer in one pass; the gradient is not materialised.
+    precision 'bf16': x and dz rounded to bf16 for the contraction (batches above 32 rows; config 5)."""
     m, k = x.shape
     n = dz.shape[1]
-    check(_lib.load().a3d_dense_bwd_filter_adam_tf1(m, k, n, _ptr(x), _ptr(dz), _ptr(var_w), _ptr(m_w), _ptr(v_w),
-                                                    _ptr(var_b), _ptr(m_b), _ptr(v_b), lr, beta1, beta2, beta1_power,
-                                                    beta2_power, grad_scale, _stream()), 'a3d_dense_bwd_filter_adam_tf1')
+    check(_lib.load().a3d_dense_bwd_filter_adam_tf1_ex(m, k, n, _ptr(x), _ptr(dz), _ptr(var_w), _ptr(m_w), _ptr(v_w),
+                                                       _ptr(var_b), _ptr(m_b), _ptr(v_b), lr, beta1, beta2, beta1_power,
+                                                       beta2_power, grad_scale, PREC[precision], _stream()),
+          'a3d_dense_bwd_filter_adam_tf1_ex')
 
 
 def with_storage(d, storage):

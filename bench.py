@@ -137,8 +137,8 @@ def pmc_traffic(kernel):
         except (OSError, ValueError, KeyError):
             continue
         if k:
-            return k['hbm_bytes_per_launch']
-    return None
+            return k['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def roofline_from(recs, with_traffic=True):
@@ -156,7 +156,7 @@ def roofline_from(recs, with_traffic=True):
                  'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in groups.items()}
     roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            'traffic': pmc_traffic(name) if with_traffic else None,
+            'traffic': pmc_traffic(name)[0] if with_traffic else None,
             'calls': g['calls'], 'avg_launch_us': round(1e3 * g['ms'] / g['calls'], 2),
             'flops_per_launch': g['flops'] / g['calls']}
     if roof['traffic'] is not None:
@@ -165,6 +165,7 @@ def roofline_from(recs, with_traffic=True):
         # (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on every launch)
         roof['traffic_fabric'] = roof['traffic']
         roof['traffic_hbm'] = None
+        roof['traffic_source'] = pmc_traffic(name)[1]      # NOT measured by this run: the committed counter passes of this command
         roof['traffic_note'] = ('fabric-side bytes per launch from the committed PMC passes of this command (profiles/*_pmc_traffic.json), '
                                 'Infinity-Cache hits included; no gfx950 counter isolates HBM: see profiles/r03_ic_evidence.txt')
     return roof, table

@@ -235,6 +235,12 @@ int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argma
 int a3d_dense_bwd_filter_adam_tf1(int m, int k, int n, const float* x, const float* dz, float* var_w, float* m_w,
                                   float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1, float beta2,
                                   float beta1_power, float beta2_power, float grad_scale, void* stream);
+/* The same with the arithmetic of the contraction chosen: A3D_PREC_BF16 (BASELINE config 5: the conv stack's arithmetic)
+ * rounds x and dz to bf16 and accumulates in float32 on the bf16 matrix cores when m > 32 — at 64 rows the float32 form is
+ * no longer a pure weight stream; A3D_PREC_F32 is a3d_dense_bwd_filter_adam_tf1. */
+int a3d_dense_bwd_filter_adam_tf1_ex(int m, int k, int n, const float* x, const float* dz, float* var_w, float* m_w,
+                                  float* v_w, float* var_b, float* m_b, float* v_b, float lr, float beta1, float beta2,
+                                  float beta1_power, float beta2_power, float grad_scale, int precision, void* stream);
 
 /* tf.train.AdamOptimizer ApplyAdam (src/models.py:309): alpha = lr*sqrt(1-b2p)/(1-b1p);
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); var -= m*alpha/(sqrt(v)+eps).  grad_scale multiplies g first

@@ -423,6 +423,28 @@ def test_dense_bwd_filter_adam_fused_equals_two_passes(ops, m, k, n):
         ops.dense_bwd_filter_adam_tf1(xd, dzd, *fused, 0.1, 0.9, 0.999, float(b1p), 0.999, scale)
 
 
+@pytest.mark.parametrize('m,k,n', [(64, 1024, 1024), (64, 392, 4070), (48, 512, 520), (33, 256, 512)])
+def test_dense_bwd_filter_adam_with_bf16_arithmetic(ops, m, k, n):
+    """a3d_dense_bwd_filter_adam_tf1_ex(precision bf16), BASELINE config 5's batch: the contraction x^T dz on the bf16 matrix
+    cores (operands rounded to bf16 once, fp32 accumulation), ApplyAdam as before.  m = 0 + (g - 0)(1 - beta1) against the
+    float64 product of the ROUNDED operands at fp32 accumulation tolerance; against the unrounded product only at bf16's."""
+    rng = np.random.default_rng(m + k + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    dz = rng.standard_normal((m, n)).astype(np.float32)
+    xd, dzd = dev(x), dev(dz)
+    slots = [torch.zeros((k, n), device='cuda') for _ in range(3)] + [torch.zeros(n, device='cuda') for _ in range(3)]
+    slots[0].fill_(0.25)
+    ops.dense_bwd_filter_adam_tf1(xd, dzd, *slots, 0.1, 0.9, 1.0, 0.9, 1.0, 1.0, precision='bf16')
+    xr = xd.to(torch.bfloat16).float().cpu().numpy().astype(np.float64)
+    zr = dzd.to(torch.bfloat16).float().cpu().numpy().astype(np.float64)
+    omb1 = float(np.float32(1) - np.float32(0.9))
+    got = slots[1].cpu().numpy()
+    assert rel_l2(got, (xr.T @ zr) * omb1) < 1e-5
+    assert rel_l2(got, (x.astype(np.float64).T @ dz.astype(np.float64)) * omb1) < 1e-2
+    assert rel_l2(slots[4].cpu().numpy(), dz.astype(np.float64).sum(0) * omb1) < 1e-6       # BiasAddGrad stays fp32
+    assert (slots[0] == 0.25).all() and (slots[2] == 0).all()                                # alpha = 0: var, v untouched
+
+
 def test_large_problem_plans_without_split(ops):
     """An output larger than the split-K slab budget (DCNF conv2d at batch 16: 1.6 GB) must still get a plan."""
     n = 96
