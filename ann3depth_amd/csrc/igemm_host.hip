@@ -27,7 +27,7 @@ int launch_igemm_ring(int mode, int cfg, IgemmParams& p, unsigned grid, hipStrea
 
 // tile configurations of the LDS-DMA bf16 kernel (igemm_ring.hip: A3D_RING_CFGS + the 96-column bwd-data tile)
 struct RingTile { int bm, bn; };
-static const RingTile kRingCfgs[] = {{256, 128}, {256, 64}, {256, 256}, {128, 128}, {256, 96}, {512, 64}};
+static const RingTile kRingCfgs[] = {{256, 128}, {256, 64}, {256, 256}, {128, 128}, {256, 96}, {512, 64}, {64, 128}};
 
 struct TileCfg {
   int bm, bn;
@@ -127,7 +127,23 @@ static const int kFirstGldsCfg = 9;
 // stays on igemm_bf16's split-K).  A3D_RING=0 turns the kernel off, A3D_RING_CFG pins a tile (tuning processes).
 static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   static const bool off = env_int("A3D_RING", 1) == 0;
-  if (off || !g.ring_ok || g.plain) return false;
+  if (!g.ring_ok || g.plain) return false;
+  if (g.mode != MODE_BWD_F && g.M <= 64 && g.N >= 1024 && g.K >= 1024) {      // (not under A3D_RING: bf16 x / dz have no other kernel)
+    // a dense layer of a small batch: a weight stream.  64-row tiles of 128 columns, K split until ~512 blocks (three per
+    // CU) pull on HBM; the slabs are a few MB
+    pl.ring = 1 + 6;
+    pl.tiles_m = 1;
+    pl.tiles_n = (g.N + 127) / 128;
+    const int nk = std::max(1, (g.K + 63) / 64);
+    int splitk = (int)std::min<long>(std::max<long>(512 / pl.tiles_n, 1), std::max(1, nk / 4));
+    if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), nk);
+    const int kps = (nk + splitk - 1) / splitk;
+    pl.splitk = (nk + kps - 1) / kps;
+    pl.ktiles_per_split = kps;
+    pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * g.M * g.N * 4 : 0;
+    return true;
+  }
+  if (off) return false;
   if (g.mode == MODE_BWD_F) {
     // filter gradient: few tiles (M = r s Cin rows) over a long pixel axis — 256-row tiles, split-K until every CU has one block
     static const bool off_f = env_int("A3D_RING_BWDF", 1) == 0;
@@ -156,7 +172,7 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   else if (g.N % 256 == 0 && (long)((g.M + 255) / 256) * (g.N / 256) >= 192) cfg = 2;
   else cfg = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= 192 ? 0 : 3;
   const int forced = tune_int("A3D_RING_CFG", -1);
-  if (forced >= 0 && forced <= 5 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
+  if (forced >= 0 && forced <= 6 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
   const int bm = kRingCfgs[cfg].bm, bn = kRingCfgs[cfg].bn;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
   if (tiles < 96 && forced < 0) return false;
@@ -793,6 +809,13 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (stencil1_applicable(d)) return 0;
   // (a maximum over the paths a launch may take: which one it is also depends on the operands' alignment)
   size_t need = plan_gemm(fwd_problem(d), d->precision).ws_bytes;
+  {                                              // ... the LDS-DMA kernel's plan among them (its split-K slabs: dense layers)
+    const int both = A3D_STORE_X_BF16 | A3D_STORE_W_BF16;
+    GemmProblem g = fwd_problem(d);
+    g.ring_ok = d->precision == A3D_PREC_BF16 && (d->storage & both) == both && d->c % 8 == 0 && d->k % 8 == 0;
+    g.avec = g.bvec = 4;
+    if (g.ring_ok) need = std::max(need, plan_gemm(g, d->precision).ws_bytes);
+  }
   if (conv3_applicable(d, nullptr)) need = std::max(need, conv3_ws_bytes(d));
   RunForm rf;
   if (run_form_ok(d, nullptr, &rf)) {
@@ -1016,7 +1039,15 @@ static bool bwd_d_class(const a3d_conv_desc* d, int ph, int pw, BwdDClass* c) {
 
 size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
-  if (d->stride == 1) return plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
+  if (d->stride == 1) {
+    size_t need = plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
+    const int both = A3D_STORE_Y_BF16 | A3D_STORE_W_BF16;
+    GemmProblem g = bwd_d_problem(d);
+    g.ring_ok = d->precision == A3D_PREC_BF16 && (d->storage & both) == both && d->c % 8 == 0 && d->k % 8 == 0;
+    g.avec = g.bvec = 4;
+    if (g.ring_ok) need = std::max(need, plan_gemm(g, d->precision).ws_bytes);
+    return need;
+  }
   size_t need = 0;
   for (int ph = 0; ph < d->stride; ++ph)
     for (int pw = 0; pw < d->stride; ++pw) {
@@ -1261,7 +1292,7 @@ int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const flo
 int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                      const uint8_t* drop_keep, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_fwd: bad dims");
-  A3D_CHECK_ARG((storage & ~A3D_STORE_W_BF16) == 0, "dense_fwd: only the weights may be bf16");
+  A3D_CHECK_ARG((storage & ~(A3D_STORE_W_BF16 | A3D_STORE_X_BF16)) == 0, "dense_fwd: the weights and x may be bf16, y is float32");
   a3d_conv_desc d = dense_desc(m, k, n);
   d.precision = precision;
   int rc = check_desc(&d);
@@ -1275,10 +1306,12 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
   if (!aligned16(w)) g.bvec = 1;
   IgemmParams p;
   fill_common(p, g);
-  rc = apply_storage(p, g, precision, false, storage & A3D_STORE_W_BF16, false, k, k, n, n, x, w, y, n, n);
+  rc = apply_storage(p, g, precision, storage & A3D_STORE_X_BF16, storage & A3D_STORE_W_BF16, false, k, k, n, n, x, w, y, n, n);
   if (rc != A3D_OK) return rc;
+  g.ring_ok = p.a16 && p.b16 && precision == A3D_PREC_BF16 && k % 8 == 0 && n % 8 == 0 && aligned16(y) && act != A3D_ACT_SIGMOID;
   GemmPlan plan = plan_gemm(g, precision);
   A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_fwd: bf16 weights need vectorisable operands");
+  A3D_CHECK_ARG(!p.a16 || plan.ring, "dense_fwd: a bf16 x is taken by the LDS-DMA kernel only (bf16 weights, k and n multiples of 8)");
   if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_fwd: need %zu workspace bytes", plan.ws_bytes);
   p.A = x; p.B = w; p.C = y; p.bias = bias; p.act = act; p.keep = drop_keep; p.mask_scale = 2.f;
   p.npix = m; p.nrsc = k; p.H = 1; p.W = 1; p.ld = k; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1; p.Cg = k;
@@ -1302,7 +1335,7 @@ int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, flo
 int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
                           float scale, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_data: bad dims");
-  A3D_CHECK_ARG((storage & ~A3D_STORE_W_BF16) == 0, "dense_bwd_data: only the weights may be bf16");
+  // storage bits as a3d_conv2d_bwd_data's: Y = dz, W = w, X = dx and the mask
   A3D_CHECK_ARG(precision >= A3D_PREC_F32 && precision <= A3D_PREC_BF16, "dense_bwd_data: unknown precision %d", precision);
   A3D_CHECK_ARG(!mask || mask_act == A3D_ACT_RELU || mask_act == A3D_ACT_SIGMOID, "dense_bwd_data: bad mask_act");
   a3d_conv_desc d = dense_desc(m, k, n);
@@ -1314,10 +1347,14 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
   if (!aligned16(w)) g.bvec = 1;
   IgemmParams p;
   fill_common(p, g);
-  rc = apply_storage(p, g, precision, false, storage & A3D_STORE_W_BF16, false, n, n, n, n, dz, w, dx, k, k);
+  rc = apply_storage(p, g, precision, storage & A3D_STORE_Y_BF16, storage & A3D_STORE_W_BF16, storage & A3D_STORE_X_BF16, n, n, n, n,
+                     dz, w, dx, k, k);
   if (rc != A3D_OK) return rc;
+  g.ring_ok = p.a16 && p.b16 && precision == A3D_PREC_BF16 && k % 8 == 0 && n % 8 == 0 && aligned16(dx) &&
+              (!mask || (aligned16(mask) && mask_act == A3D_ACT_RELU && scale == 1.f));
   GemmPlan plan = plan_gemm(g, precision);
   A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_bwd_data: bf16 weights need vectorisable operands");
+  A3D_CHECK_ARG(!(p.a16 || p.c16) || plan.ring, "dense_bwd_data: bf16 dz / dx are taken by the LDS-DMA kernel only (bf16 weights, k and n multiples of 8, ReLU mask)");
   if (plan.ws_bytes > ws_bytes) return set_error(A3D_EWORKSPACE, "dense_bwd_data: need %zu workspace bytes", plan.ws_bytes);
   p.A = dz; p.B = w; p.C = dx; p.mask = mask; p.mask_scale = scale; p.mask_act = mask_act;
   p.npix = m; p.nrsc = n; p.H = 1; p.W = 1; p.ld = n; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1;

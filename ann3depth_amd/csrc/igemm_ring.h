@@ -47,7 +47,7 @@ struct RingCfg {
   static constexpr int NSTAGE = 2;
   static constexpr int MAXTAPS = 128;
   // (the epilogue stages 32 x WN outputs per wave in the tile buffers: at most 8 x 32 x (4 WN + 16) bytes)
-  static constexpr int TAB_ROWS = BM > 256 ? BM : 256;       // row table (BM entries) / bwd-filter: four k-tiles' pixel tables
+  static constexpr int TAB_ROWS = MODE == MODE_BWD_F ? 256 : BM;      // row table (BM entries) / bwd-filter: four k-tiles' pixel tables
   static constexpr size_t TILE_AND_TABLES = (size_t)NSTAGE * STAGE + (size_t)TAB_ROWS * 16 + (size_t)MAXTAPS * 16;
   static constexpr size_t EPI_BYTES = (size_t)8 * 32 * (WN * 4 + 16);
   static constexpr size_t LDS_BYTES = TILE_AND_TABLES > EPI_BYTES ? TILE_AND_TABLES : EPI_BYTES;
@@ -392,9 +392,10 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   static_assert(LPR <= 64 && 32 % RPI == 0, "staging rows divide over the lanes");
   static_assert((size_t)8 * 32 * EP <= Cfg::LDS_BYTES, "staging rows fit the tile buffers");
   __syncthreads();                                 // every wave is done with the stages
-  float* Cout = p.C;                               // bwd-filter under split-K: this split's slab, rows of N floats
+  float* Cout = p.C;                               // under split-K: this split's slab of raw sums, rows of N floats (C16 = false: host)
   int ldc = p.ldc;
-  if (MODE == MODE_BWD_F && p.splitk > 1) {
+  const bool partial = p.splitk > 1;
+  if (partial) {
     Cout = p.C + (size_t)split * p.slab;
     ldc = p.N;
   }
@@ -406,15 +407,19 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     for (int b = 0; b < TN; ++b) {
       const int col = n0 + wn * Cfg::WN + b * 32 + li;
       float bias = 0.f;
-      if (MODE == MODE_FWD && p.bias && col < p.N) bias = p.bias[col];
+      if (MODE == MODE_FWD && !partial && p.bias && col < p.N) bias = p.bias[col];
       float val[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         val[v] = acc[a][b][v];
-        if (MODE == MODE_FWD) {
+        if (MODE == MODE_FWD && !partial) {
           val[v] += bias;
           if (p.act == EPI_RELU) val[v] = fmaxf(val[v], 0.f);
           else if (p.act == EPI_SIGMOID) val[v] = 1.f / (1.f + expf(-val[v]));
+          if (p.keep) {                            // tf.layers.dropout fused (dense layers: a handful of rows)
+            const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (row < p.M && col < p.N) val[v] = p.keep[(size_t)row * p.N + col] ? val[v] * p.mask_scale : 0.f;
+          }
         }
       }
       if constexpr (C16) {
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       u32x4 q = *reinterpret_cast<const u32x4*>(eb + r * EP + ec * 16);
       if (row < p.M && col0 < p.N) {               // (N is a multiple of the piece: host)
         const size_t o = (size_t)row * ldc + col0;
-        if (MODE == MODE_BWD_D && p.mask) {        // ReluGrad of the layer below: dx = 0 where its activation is not positive
+        if (MODE == MODE_BWD_D && !partial && p.mask) {        // ReluGrad of the layer below: dx = 0 where its activation is not positive
           if constexpr (C16) {
             const u32x4 mk = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(p.mask) + o);
 #pragma unroll

@@ -7,7 +7,7 @@
 namespace a3d {
 
 // index, BM, BN, WAVES_M  (keep in step with kRingCfgs in igemm_host.hip)
-#define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4) X(5, 512, 64, 8)
+#define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4) X(5, 512, 64, 8) X(6, 64, 128, 2)
 
 template <int MODE, int BM, int BN, int WAVES_M, bool C16>
 static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {
@@ -27,14 +27,15 @@ static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {
 
 template <int MODE>
 static int launch_ring_mode(int cfg, IgemmParams& p, unsigned grid, hipStream_t st) {
+  const bool c16 = p.c16 && p.splitk == 1;       // split-K slabs are float32; the reduction writes the bf16 tensor
   switch (cfg) {
 #define X(i, bm, bn, wm) \
-  case i: return p.c16 ? launch_ring_one<MODE, bm, bn, wm, true>(p, grid, st) : launch_ring_one<MODE, bm, bn, wm, false>(p, grid, st);
+  case i: return c16 ? launch_ring_one<MODE, bm, bn, wm, true>(p, grid, st) : launch_ring_one<MODE, bm, bn, wm, false>(p, grid, st);
     A3D_RING_CFGS(X)
 #undef X
   }
   if (MODE == MODE_BWD_D && cfg == 4)      // 96 input channels (conv2d_1's bwd-data): one 96-column tile, k-contiguous filter rows
-    return p.c16 ? launch_ring_one<MODE_BWD_D, 256, 96, 8, true>(p, grid, st) : launch_ring_one<MODE_BWD_D, 256, 96, 8, false>(p, grid, st);
+    return c16 ? launch_ring_one<MODE_BWD_D, 256, 96, 8, true>(p, grid, st) : launch_ring_one<MODE_BWD_D, 256, 96, 8, false>(p, grid, st);
   return set_error(A3D_EINVAL, "igemm ring: unknown config %d", cfg);
 }
 

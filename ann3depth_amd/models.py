@@ -253,7 +253,8 @@ class MSDNReplica:
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = buf(B, OUT_H, OUT_W, 64)
         self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
         if self.bf16s:
-            self.c4_32 = buf(B, 6, 8, 256); self.dc4_32 = buf(B, 6, 8, 256)      # the dense layers' fp32 side of c4 / dc4
+            self.c4_32 = buf(B, 6, 8, 256)                                          # the fp32 copy of c4 dense_0's filter gradient reads
+            self.dz0_16 = torch.empty((B, 4096), device=dev, dtype=torch.bfloat16)  # dense_0's bwd-data takes dz0 as bf16
         # descriptors
         def D(*a):
             return ops.conv_desc(*a, precision=precision)
@@ -669,10 +670,9 @@ class MSDNReplica:
         if not self._sharded_in_flight():
             self.settle()           # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
-        if self.bf16s:              # c4 crosses to the dense layers' fp32 side; dense_0 reads its 100 MB bf16 weight copy
-            ops.cast_bf16(self.c4, self.c4_32)
-            ops.dense_fwd_ex(self.c4_32.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
-                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W)
+        if self.bf16s:              # dense_0 streams its 100 MB bf16 weight copy against c4 as it stands (bf16): LDS-DMA kernel
+            ops.dense_fwd_ex(self.c4.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
+                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W | ops.STORE_X)
         else:
             ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
@@ -726,12 +726,14 @@ class MSDNReplica:
         # (train=False, src/models.py:230: tf.layers.dropout is the identity; only the ReluGrad remains)
         ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
         n = 'coarse/dense/dense_0'
+        if self.bf16s:              # the filter gradient takes c4 on the dense layers' fp32 side
+            ops.cast_bf16(self.c4, self.c4_32)
         flat = (self.c4_32 if self.bf16s else self.c4).view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
-        if self.bf16s:
-            ops.dense_bwd_data_ex(self.dz0, self.wcopy[n], self.dc4_32.view(B, -1), mask=flat, scale=1.0, precision='bf16',
-                                  storage=ops.STORE_W)
-            ops.cast_bf16(self.dc4_32, self.dc4)
+        if self.bf16s:              # dz0 -> bf16 (1 MB); dc4 leaves as bf16, masked by the bf16 c4: no fp32 detour
+            ops.cast_bf16(self.dz0, self.dz0_16)
+            ops.dense_bwd_data_ex(self.dz0_16, self.wcopy[n], self.dc4.view(B, -1), mask=self.c4.view(B, -1), scale=1.0,
+                                  precision='bf16', storage=ops.STORE_W | ops.STORE_X | ops.STORE_Y)
         else:
             ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:

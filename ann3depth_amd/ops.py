@@ -286,7 +286,7 @@ def with_storage(d, storage):
 
 
 def _dense_ws(lib, m, k, n, precision, storage, device):
-    d = conv_desc(m, 1, 1, k, n, 1, 1, 1, 'VALID', precision=precision)
+    d = conv_desc(m, 1, 1, k, n, 1, 1, 1, 'VALID', precision=precision, storage=storage)
     need = max(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), lib.a3d_conv2d_bwd_data_ws_bytes(ctypes.byref(d)))
     return _ws().get(need, device)
 

@@ -445,6 +445,32 @@ def test_dense_bwd_filter_adam_with_bf16_arithmetic(ops, m, k, n):
     assert (slots[0] == 0.25).all() and (slots[2] == 0).all()                                # alpha = 0: var, v untouched
 
 
+@pytest.mark.parametrize('m,k,n', [(64, 12288, 4096), (64, 4096, 2048), (37, 1024, 1032), (2, 12288, 4096)])
+def test_dense_layers_on_bf16_tensors_through_the_lds_dma_kernel(ops, m, k, n):
+    """a3d_dense_fwd_ex / a3d_dense_bwd_data_ex with x / dz / dx stored as bf16 beside the bf16 weight copy (BASELINE config
+    5's dense_0: c4 and dc4 are bf16 activations): a small batch against a [k, n] weight stream on igemm_ring.h's 64-row
+    tiles, K split over several blocks per column tile, ReLU + dropout (forward) and the ReluGrad mask (bwd-data) applied by
+    the split-K reduction.  Against float64 on the rounded operands."""
+    rng = np.random.default_rng(m + n)
+    bf = torch.bfloat16
+    x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).cuda().to(bf)
+    w = torch.from_numpy((rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)).cuda().to(bf)
+    b = dev(rng.standard_normal(n).astype(np.float32))
+    keep = dev(rng.random((m, n)) >= 0.5, torch.uint8)
+    x64, w64 = x.float().cpu().numpy().astype(np.float64), w.float().cpu().numpy().astype(np.float64)
+    y = torch.full((m, n), float('nan'), device='cuda')
+    ops.dense_fwd_ex(x, w, b, y, 'relu', drop_keep=keep, precision='bf16', storage=ops.STORE_W | ops.STORE_X)
+    ref = np.maximum(x64 @ w64 + b.cpu().numpy().astype(np.float64), 0) * 2.0 * keep.cpu().numpy()
+    assert rel_l2(y.cpu().numpy(), ref) < 2e-5
+    assert (y.cpu().numpy()[keep.cpu().numpy() == 0] == 0).all()
+    dz = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32)).cuda().to(bf)
+    dx = torch.full((m, k), float('nan'), device='cuda', dtype=bf)
+    ops.dense_bwd_data_ex(dz, w, dx, mask=x, scale=1.0, precision='bf16', storage=ops.STORE_W | ops.STORE_X | ops.STORE_Y)
+    dref = (dz.float().cpu().numpy().astype(np.float64) @ w64.T) * (x64 > 0)
+    got = dx.float().cpu().numpy()
+    assert np.isfinite(got).all() and rel_l2(got, dref) < 4e-3 and (got[x64 <= 0] == 0).all()
+
+
 def test_large_problem_plans_without_split(ops):
     """An output larger than the split-K slab budget (DCNF conv2d at batch 16: 1.6 GB) must still get a plan."""
     n = 96
