@@ -797,8 +797,8 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1_ex(int m, int k, int n, const float
   static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
   // A3D_DW_SLIM (read once; default on): the slim form for batches of at most 32 rows — measured in the step, beside the
   // fine network's hinted GEMMs
-  static const bool slim_env = !getenv("A3D_DW_SLIM") || atoi(getenv("A3D_DW_SLIM")) != 0;
-  const bool slim = slim_env && m <= 32 && n % 2 == 0;
+  static const int slim_env = getenv("A3D_DW_SLIM") ? atoi(getenv("A3D_DW_SLIM")) : 1;      // 2: layers of at most 2^25 weights only
+  const bool slim = slim_env != 0 && m <= 32 && n % 2 == 0 && (slim_env != 2 || (long)k * n <= (1L << 25));
   const bool bf_cols = precision == A3D_PREC_BF16 && m > 32;      // the bf16 form: 512 columns per block at any batch
   const int bcols = slim ? 256 : ((m <= 32 || bf_cols) ? 512 : 256), colblocks = (n + bcols - 1) / bcols;
   const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + (slim ? 1023 : 511)) / (slim ? 1024 : 512));

@@ -156,6 +156,20 @@ def test_planner_handles_every_layer_shape_on_the_host():
         for fn in (lib.a3d_conv2d_fwd_ws_bytes, lib.a3d_conv2d_bwd_data_ws_bytes, lib.a3d_conv2d_bwd_filter_ws_bytes):
             ws = fn(ctypes.byref(d))
             assert 0 <= ws <= 200 << 20, (d.n, d.c, d.k, d.r, fn.__name__, ws)
+    # bf16-stored operands (BASELINE config 5): the LDS-DMA kernel's plans — never-split forward / bwd-data, split-K slabs of the
+    # filter gradient + the column-sum partials, the dense layers' 64-row tiles with their slabs
+    X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+    for B in (2, 32, 64):
+        for shape in [(B, 27, 37, 96, 256, 5, 5, 1, 'SAME'), (B, 13, 18, 256, 384, 3, 3, 1, 'SAME'),
+                      (B, 13, 18, 384, 384, 3, 3, 1, 'SAME'), (B, 13, 18, 384, 256, 3, 3, 2, 'VALID'),
+                      (B, 55, 74, 64, 64, 5, 5, 1, 'SAME'), (B, 1, 1, 12288, 4096, 1, 1, 1, 'VALID')]:
+            d = ops.conv_desc(*shape, precision='bf16')
+            for fn, bits in ((lib.a3d_conv2d_fwd_ws_bytes, X | W | Y), (lib.a3d_conv2d_bwd_data_ws_bytes, X | W | Y),
+                             (lib.a3d_conv2d_bwd_filter_ws_bytes, X | Y)):
+                ws = fn(ctypes.byref(ops.with_storage(d, bits)))
+                assert 0 <= ws <= 200 << 20, (shape, fn.__name__, ws)
+    d = ops.with_storage(ops.conv_desc(64, 27, 37, 96, 256, 5, 5, 1, 'SAME', precision='bf16'), X | Y)
+    assert lib.a3d_conv2d_bwd_filter_ws_bytes(ctypes.byref(d)) >= 2 * 2400 * 256 * 4      # split-K slabs of the LDS-DMA bwd-filter
     for m, k, n in [(32, 12288, 4096), (32, 4096, 4070), (64, 12288, 4096), (768, 12544, 128), (768, 128, 16), (768, 16, 1)]:
         for fn in (lib.a3d_dense_fwd_ws_bytes, lib.a3d_dense_bwd_data_ws_bytes, lib.a3d_dense_bwd_filter_ws_bytes):
             assert 0 <= fn(m, k, n) <= 200 << 20
