@@ -742,6 +742,10 @@ class MSDNReplica:
         self._bwd_filter(n, self.c3, self.dc4)
         self._bwd_data(n, self.dc4, self.dc3, relu_mask=self.c3)
         self._join()               # the fine forward has had the dense / conv2d_4 stretch; the big GEMMs below run alone
+        # (round 4: the join costs the main queue ~25 us — the side stream's loss kernel ends 14 us after conv2d_4's backward,
+        # plus the cross-queue signal.  Joining later — after conv2d_3's filter gradient, after its bwd-data, at the end of the
+        # backward — was measured at 2.97 ms against 2.92: a stream-K grid sized for all CU slots starts lopsided when the
+        # side stream's blocks still hold some.  bf16 storage: 1.504 against 1.506, noise.)
         # (measured, round 3: the filter-gradient GEMMs on the side stream beside the bwd-data chain — to fill its tails and
         # launch gaps — make the step 2 % SLOWER, 3.20 vs 3.14 ms: two MFMA-bound grids only take CU slots from each other)
         dw = self._bwd_filter
