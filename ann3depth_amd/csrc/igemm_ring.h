@@ -24,6 +24,8 @@
 //     chunk c of row k at c ^ ((k & 3) << 2) (BN = 64: c ^ (((k >> 1) & 1) << 2)): the four k rows a 16-lane group reads
 //     land 64 bytes apart in the bank row.
 #pragma once
+#include <type_traits>
+
 #include "igemm_bf16.h"
 
 namespace a3d {
@@ -47,7 +49,7 @@ struct RingCfg {
   static constexpr int NSTAGE = 2;
   static constexpr int MAXTAPS = 128;
   // (the epilogue stages 32 x WN outputs per wave in the tile buffers: at most 8 x 32 x (4 WN + 16) bytes)
-  static constexpr int TAB_ROWS = MODE == MODE_BWD_F ? 256 : BM;      // row table (BM entries) / bwd-filter: four k-tiles' pixel tables
+  static constexpr int TAB_ROWS = MODE == MODE_BWD_F ? 512 : BM;      // row table (BM entries) / bwd-filter: eight k-tiles' pixel tables
   static constexpr size_t TILE_AND_TABLES = (size_t)NSTAGE * STAGE + (size_t)TAB_ROWS * 16 + (size_t)MAXTAPS * 16;
   static constexpr size_t EPI_BYTES = (size_t)8 * 32 * (WN * 4 + 16);
   static constexpr size_t LDS_BYTES = TILE_AND_TABLES > EPI_BYTES ? TILE_AND_TABLES : EPI_BYTES;
@@ -128,18 +130,20 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   const int pW = p.W, pld = p.ld;
   uint32_t nf = 0;
   // bwd-filter: the pixel axis is K.  Table of k-tile kt (64 entries {byte offset of the pixel's reference position in the
-  // whole tensor, y0, x0}) lives in slot kt & 3; it is written three iterations before the tile's offsets are computed
+  // whole tensor, y0, x0}) lives in slot kt & 7.  Iteration it writes the table of tile it + 6 and reads (prep_head, in the
+  // shadow of its first k-steps) the one of tile it + 3: barriers lie between a table's write and its read, and between
+  // its read and the slot's next write.  Every wave writes the same 64 entries — identical values to identical
+  // addresses — so that the write is unconditional: a wave-0-only store is a branch, and a branch inside the loop body ends
+  // the scheduling region the MFMA shadows are filled from.
   auto write_pix = [&](int kt) {
-    if (tid < 64) {
-      int4 e = make_pix<false>(p, kt * BK + tid);
-      e.x = (e.x + e.y * pW + e.z) * pld * 2;
-      if (!e.w || kt >= kt_end) e.y = -(1 << 30);
-      rowtab[(kt & 3) * 64 + tid] = e;
-    }
+    int4 e = make_pix<false>(p, kt * BK + lane);
+    e.x = (e.x + e.y * pW + e.z) * pld * 2;
+    if (!e.w || kt >= kt_end) e.y = -(1 << 30);
+    rowtab[(kt & 7) * 64 + lane] = e;
   };
   if constexpr (MODE == MODE_BWD_F) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) write_pix(kt_begin + t);
+    for (int t = 0; t < 6; ++t) write_pix(kt_begin + t);
   } else {
     const int px = m0 < p.npix ? m0 : p.npix - 1;
     nf = __builtin_amdgcn_readfirstlane(fdiv((uint32_t)px, p.div_phw));
@@ -207,77 +211,112 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
 
   // The requests of a k-tile in two steps, so that neither sits between the barrier and the first MFMA of an iteration
   // (where all eight waves would do it at once with the matrix pipe idle: counters of the first version, 48 % of the wave
-  // cycles parked, 34 % matrix-pipe busy): prep() computes the pieces' offsets ONE TILE EARLY, in the shadow of the
-  // MFMAs of the third k-step; fire_a / fire_b are then nothing but the LDS-DMAs, issued behind the first / second k-step.
+  // cycles parked, 34 % matrix-pipe busy): the pieces' offsets are computed in the shadow of the MFMAs of k-steps 0 .. 2,
+  // the LDS-DMAs themselves are issued one by one behind the MFMAs of the last k-step.
   uint32_t aoff[Cfg::A_NI], boff[Cfg::B_NI];
-  auto prep = [&](int kt) {
+#ifdef A3D_RING_DIAG      // timing-only diagnostic build (results wrong): A3D_DBG bit 0 / 1: the A / B requests inside the loop fetch nothing
+  const uint32_t dbg_a = (p.dbg & 1) ? kOOB : 0u, dbg_b = (p.dbg & 2) ? kOOB : 0u;
+#else
+  constexpr uint32_t dbg_a = 0u, dbg_b = 0u;
+#endif
+  // Offsets of a k-tile's pieces, in pieces of work that fit an MFMA's shadow.  prep_head(kt) decodes this lane's k-chunk of
+  // tile kt (filter tap, channel) and REQUESTS the tap's table entry (bwd-filter: the pixel entries of its A_NI rows); the
+  // pieces that follow — an iteration later inside the loop — turn it into the A_NI + B_NI offsets.
+  int4 tt = make_int4(0, 0, 0, 0), pe[MODE == MODE_BWD_F ? Cfg::A_NI : 1];
+  int p_ch = 0, p_kt = 0;
+  bool p_kvalid = false;
+  auto prep_head = [&](int kt) {
+    p_kt = kt;
     if constexpr (MODE == MODE_BWD_F) {
-      const int4* tab = rowtab + (kt & 3) * 64;
+      const int4* tab = rowtab + (kt & 7) * 64;
 #pragma unroll
-      for (int j = 0; j < Cfg::A_NI; ++j) {
-        const int4 e = tab[a_krow + j * (8 * 64 / CPRA)];
-        const int y = e.y + a_dy, x = e.z + a_dx;
+      for (int j = 0; j < Cfg::A_NI; ++j) pe[j] = tab[a_krow + j * (8 * 64 / CPRA)];
+    } else {
+      const int k0 = kt * BK + kc * 8;
+      const uint32_t tap = fdiv((uint32_t)k0, p.div_c);
+      p_ch = k0 - (int)(tap * p.div_c.d);
+      p_kvalid = (k0 < p.K) & (kt < kt_end);
+      tt = taptab[p_kvalid ? tap : 0u];
+    }
+  };
+  constexpr int NPREP = Cfg::A_NI + Cfg::B_NI + 1;
+  // piece pc of the tile prep_head() was last called for; the last piece is prep_head(kt_next)
+  auto prep_piece = [&](int pc, int kt_next, uint32_t (&ao)[Cfg::A_NI], uint32_t (&bo)[Cfg::B_NI]) {
+    if (pc < Cfg::A_NI) {
+      const int j = pc;
+      if constexpr (MODE == MODE_BWD_F) {
+        const int y = pe[j].y + a_dy, x = pe[j].z + a_dx;
         const bool ok = a_mvalid & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
-        aoff[j] = ok ? (uint32_t)(e.x + a_coloff) : kOOB;
+        ao[j] = (ok ? (uint32_t)(pe[j].x + a_coloff) : kOOB) | dbg_a;
+      } else {
+        const int y = a_y0[j] + tt.x, x = a_x0[j] + tt.y;
+        const bool ok = p_kvalid & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
+        ao[j] = (ok ? (uint32_t)(a_rowoff[j] + tt.z + p_ch * 2) : kOOB) | dbg_a;
       }
-#pragma unroll
-      for (int j = 0; j < Cfg::B_NI; ++j)
-        boff[j] = (b_voff[j] != kOOB && kt < kt_end) ? b_voff[j] + (uint32_t)kt * (uint32_t)(BK * p.ldb * 2) : kOOB;   // pixels past the end: past the end
-      return;
-    }
-    const int k0 = kt * BK + kc * 8;
-    const uint32_t tap = fdiv((uint32_t)k0, p.div_c);
-    const int ch = k0 - (int)(tap * p.div_c.d);
-    const bool kvalid = (k0 < p.K) & (kt < kt_end);
-    const int4 tt = taptab[kvalid ? tap : 0u];
-#pragma unroll
-    for (int j = 0; j < Cfg::A_NI; ++j) {
-      const int y = a_y0[j] + tt.x, x = a_x0[j] + tt.y;
-      const bool ok = kvalid & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
-      aoff[j] = ok ? (uint32_t)(a_rowoff[j] + tt.z + ch * 2) : kOOB;
-    }
-#pragma unroll
-    for (int j = 0; j < Cfg::B_NI; ++j) {
-      if constexpr (Cfg::B_KC) boff[j] = (kvalid && b_voff[j] != kOOB) ? b_voff[j] + (uint32_t)tt.w + (uint32_t)ch * 2u : kOOB;
-      else boff[j] = (b_voff[j] != kOOB && kt < kt_end) ? b_voff[j] + (uint32_t)kt * (uint32_t)(BK * p.ldb * 2) : kOOB;   // rows past K: past the end
+    } else if (pc < Cfg::A_NI + Cfg::B_NI) {
+      const int j = pc - Cfg::A_NI;
+      // (b_voff = kOOB stays past the end under the additions: filter and slab offsets are below 2^31, checked on the host)
+      if constexpr (Cfg::B_KC) bo[j] = (b_voff[j] + (uint32_t)tt.w + (uint32_t)p_ch * 2u) | (p_kvalid ? 0u : kOOB) | dbg_b;
+      else bo[j] = (b_voff[j] + (uint32_t)p_kt * (uint32_t)(BK * p.ldb * 2)) | (p_kt < kt_end ? 0u : kOOB) | dbg_b;   // rows (bwd-filter: pixels) past the end: past the end
+    } else {
+      prep_head(kt_next);
     }
   };
-  auto fire_a = [&](int stg) {
-    const uint32_t sa = lds0 + (uint32_t)(stg * Cfg::STAGE);
+  auto prep_all = [&](uint32_t (&ao)[Cfg::A_NI], uint32_t (&bo)[Cfg::B_NI]) {
 #pragma unroll
-    for (int j = 0; j < Cfg::A_NI; ++j) ring_dma(rsA, aoff[j], sa + (uint32_t)((j * 8 + wave) * 1024));
+    for (int pc = 0; pc < Cfg::A_NI + Cfg::B_NI; ++pc) prep_piece(pc, 0, ao, bo);
   };
-  auto fire_b = [&](int stg) {
-    const uint32_t sb = lds0 + (uint32_t)(stg * Cfg::STAGE + Cfg::A_BYTES);
+  // request number d of a k-tile's A_NI + B_NI (this wave's share), into stage `stg`
+  auto fire_one = [&](int stg, int d) {
+    if (d < Cfg::A_NI) {
+      ring_dma(rsA, aoff[d], lds0 + (uint32_t)(stg * Cfg::STAGE) + (uint32_t)((d * 8 + wave) * 1024));
+    } else {
+      const int j = d - Cfg::A_NI;
+      if (Cfg::B_PIECES % 8 == 0 || j * 8 + wave < Cfg::B_PIECES)
+        ring_dma(rsB, boff[j], lds0 + (uint32_t)(stg * Cfg::STAGE + Cfg::A_BYTES) + (uint32_t)((j * 8 + wave) * 1024));
+    }
+  };
+  constexpr int NDMA = Cfg::A_NI + Cfg::B_NI;
+  auto fire = [&](int stg) {
 #pragma unroll
-    for (int j = 0; j < Cfg::B_NI; ++j)
-      if (Cfg::B_PIECES % 8 == 0 || j * 8 + wave < Cfg::B_PIECES) ring_dma(rsB, boff[j], sb + (uint32_t)((j * 8 + wave) * 1024));
+    for (int d = 0; d < NDMA; ++d) fire_one(stg, d);
   };
 
-  // ---- fragment addresses (bytes inside a stage) ----
-  int a_fr[TM], b_fr[TN];
+  // ---- fragment addresses: LDS byte offsets per STAGE, loop-invariant registers (made opaque so that the compiler keeps them
+  //      instead of re-deriving one from another with a VALU add ahead of every read: a read without address arithmetic
+  //      can be issued in any MFMA shadow).  k-contiguous images: one register per (stage, k-step) — the k-step is an XOR
+  //      inside the swizzled row — with the sub-tiles 4 KiB apart as immediates; [64 k][columns] images: one per (stage,
+  //      sub-tile), the k-steps as immediates ----
   constexpr int ROWA = BM * 2;                    // bytes per pixel row of the bwd-filter A tile
+  constexpr int NAF = Cfg::A_KC ? 4 : TM, NBF = Cfg::B_KC ? 4 : TN;
+  int a_fr[2][NAF], b_fr[2][NBF];
+  {
+    const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    if constexpr (Cfg::A_KC) {
-      const int row = wm * Cfg::WM + a * 32 + li;
-      a_fr[a] = row * 128 + ((lh ^ ring_swz(row)) << 4);        // k-step s: ^ (s << 5)
-    } else {
-      const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
-      const int c = ((wm * Cfg::WM + a * 32) >> 3) + 2 * cb + (pp >> 1);
-      a_fr[a] = (8 * h + q) * ROWA + ((c ^ (q << 2)) << 4) + (pp & 1) * 8;                  // k-step s: + 16 s ROWA
-    }
-  }
+    for (int stg = 0; stg < 2; ++stg) {
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    if constexpr (Cfg::B_KC) {
-      const int row = wn * Cfg::WN + b * 32 + li;
-      b_fr[b] = Cfg::A_BYTES + row * 128 + ((lh ^ ring_swz(row)) << 4);
-    } else {
-      const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
-      const int c = ((wn * Cfg::WN + b * 32) >> 3) + 2 * cb + (pp >> 1);
-      const int sw = CPR >= 16 ? (q << 2) : ((q >> 1) << 2);      // of rows 16 s + 8 h + q and + 4: the same
-      b_fr[b] = Cfg::A_BYTES + (8 * h + q) * ROWB + ((c ^ sw) << 4) + (pp & 1) * 8;     // k-step s: + 16 s ROWB
+      for (int i = 0; i < NAF; ++i) {
+        if constexpr (Cfg::A_KC) {
+          const int row = wm * Cfg::WM + li;        // (+ 32 a: the same swizzle)
+          a_fr[stg][i] = stg * Cfg::STAGE + ((row * 128 + ((lh ^ ring_swz(row)) << 4)) ^ (i << 5));
+        } else {
+          const int c = ((wm * Cfg::WM + i * 32) >> 3) + 2 * cb + (pp >> 1);
+          a_fr[stg][i] = stg * Cfg::STAGE + (8 * h + q) * ROWA + ((c ^ (q << 2)) << 4) + (pp & 1) * 8;      // k-step s: + 16 s ROWA
+        }
+        asm volatile("" : "+v"(a_fr[stg][i]));
+      }
+#pragma unroll
+      for (int i = 0; i < NBF; ++i) {
+        if constexpr (Cfg::B_KC) {
+          const int row = wn * Cfg::WN + li;
+          b_fr[stg][i] = stg * Cfg::STAGE + Cfg::A_BYTES + ((row * 128 + ((lh ^ ring_swz(row)) << 4)) ^ (i << 5));
+        } else {
+          const int c = ((wn * Cfg::WN + i * 32) >> 3) + 2 * cb + (pp >> 1);
+          const int sw = CPR >= 16 ? (q << 2) : ((q >> 1) << 2);      // of rows 16 s + 8 h + q and + 4: the same
+          b_fr[stg][i] = stg * Cfg::STAGE + Cfg::A_BYTES + (8 * h + q) * ROWB + ((c ^ sw) << 4) + (pp & 1) * 8;     // k-step s: + 16 s ROWB
+        }
+        asm volatile("" : "+v"(b_fr[stg][i]));
+      }
     }
   }
 
@@ -296,87 +335,105 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   //      fragment reads, the requests' issue (60 - 180 cycles apiece) and the offsets' arithmetic all ran with the matrix
   //      pipe idle on all eight waves at once: a build without requests ran as long as (empty loop) + (MFMA time). ----
   bf16x8 af[2][TM], bf[2][TN];
-  auto read_frags = [&](const unsigned char* st, int s, int buf) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
+  // fragment number u of k-step s of this iteration's tile (stg 0) or the next one's (stg 1): A sub-tile u (u < TM) or B sub-tile u - TM
+  auto read_unit = [&](int stg, int s, int buf, int u) {
+    if (u < TM) {
+      const int a = u;
       if constexpr (Cfg::A_KC) {
-        af[buf][a] = *reinterpret_cast<const bf16x8*>(st + (a_fr[a] ^ (s << 5)));
+        af[buf][a] = *reinterpret_cast<const bf16x8*>(smem_raw + a_fr[stg][s] + a * 4096);
       } else {
-        const __bf16* q0 = reinterpret_cast<const __bf16*>(st + a_fr[a] + s * 16 * ROWA);
+        const __bf16* q0 = reinterpret_cast<const __bf16*>(smem_raw + a_fr[stg][a] + s * 16 * ROWA);
         const bf16x4 lo4 = lds_read_tr(q0), hi4 = lds_read_tr(q0 + 2 * ROWA);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { af[buf][a][e] = lo4[e]; af[buf][a][4 + e] = hi4[e]; }
       }
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
+    } else {
+      const int b = u - TM;
       if constexpr (Cfg::B_KC) {
-        bf[buf][b] = *reinterpret_cast<const bf16x8*>(st + (b_fr[b] ^ (s << 5)));
+        bf[buf][b] = *reinterpret_cast<const bf16x8*>(smem_raw + b_fr[stg][s] + b * 4096);
       } else {
-        const __bf16* q0 = reinterpret_cast<const __bf16*>(st + b_fr[b] + s * 16 * ROWB);
+        const __bf16* q0 = reinterpret_cast<const __bf16*>(smem_raw + b_fr[stg][b] + s * 16 * ROWB);
         const bf16x4 lo4 = lds_read_tr(q0), hi4 = lds_read_tr(q0 + 2 * ROWB);      // rows k and k + 4 (ROWB / 2 elements each)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bf[buf][b][e] = lo4[e]; bf[buf][b][4 + e] = hi4[e]; }
       }
     }
   };
-  auto mfmas = [&](int buf) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][a], bf[buf][b], acc[a][b], 0, 0, 0);
-  };
-  constexpr int NREADS = (Cfg::A_KC ? TM : 2 * TM) + (Cfg::B_KC ? TN : 2 * TN), NMFMA = TM * TN;
-  constexpr int PER = (NREADS + NMFMA - 1) / NMFMA;
-  auto interleave = [&]() {                       // one MFMA, then its share of the LDS reads issued ahead of the group
-#pragma unroll
-    for (int i = 0; i < NMFMA; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
-    }
-  };
-#ifdef A3D_RING_DIAG      // timing-only diagnostic build (results wrong): A3D_DBG bit 0 / 1 no A / B requests inside the loop, bit 2 no math
-  const bool dma_a = !(p.dbg & 1), dma_b = !(p.dbg & 2), math = !(p.dbg & 4);
+  constexpr int NMFMA = TM * TN, NU = TM + TN, NS1 = 3 * NMFMA;
+#ifdef A3D_RING_DIAG      // A3D_DBG bit 2: no fragment reads, no MFMAs; bit 3: no barrier; bit 4: no wait for the requests; bit 5: no fragment reads
+  const bool math = !(p.dbg & 4), dbar = !(p.dbg & 8), dland = !(p.dbg & 16), dreads = !(p.dbg & 32);
 #else
-  constexpr bool dma_a = true, dma_b = true, math = true;
+  constexpr bool math = true, dbar = true, dland = true, dreads = true;
 #endif
   if (nkt > 0) {
-    prep(kt_begin);
-    fire_a(0);
-    fire_b(0);
-    prep(kt_begin + 1);
+    prep_head(kt_begin);
+    prep_all(aoff, boff);
+    fire(0);
+    prep_head(kt_begin + 1);
+    prep_all(aoff, boff);
     ring_landed();
     __syncthreads();
-    if (nkt > 1) { fire_a(1); fire_b(1); }
-    prep(kt_begin + 2);
-    read_frags(smem_raw, 0, 0);
-  }
-  for (int it = 0; it < nkt; ++it) {
-    const unsigned char* st = smem_raw + (it & 1) * Cfg::STAGE;
-    const unsigned char* stn = smem_raw + ((it + 1) & 1) * Cfg::STAGE;
-    if (math) {
+    if (nkt > 1) fire(1);
+    prep_head(kt_begin + 2);
 #pragma unroll
-      for (int s = 0; s < BK / 16 - 1; ++s) {
-        read_frags(st, s + 1, (s + 1) & 1);
-        mfmas(s & 1);
-        interleave();
+    for (int u = 0; u < NU; ++u) read_unit(0, 0, 0, u);
+  }
+  // One iteration.  The instruction order is pinned slot by slot: a slot is ONE MFMA and what rides
+  // in its shadow; the compiler may not move anything across a slot's end.
+  //   k-steps 0 .. 2   the slot's share of the next k-step's fragment reads, and of the offset arithmetic of tile it + 2
+  //                    (whose tap entry was read an iteration ago; the last piece requests the entry of tile it + 3)
+  //   barrier          tile it + 1 has landed on every wave, no wave reads stage it & 1 again
+  //   last k-step      the slot's share of the first fragment reads of tile it + 1 and of the requests of tile it + 2
+  // STEADY (tiles it + 1 and it + 2 exist): no branch between the top and the bottom of the iteration.
+  auto body = [&](int it, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const int par = it & 1;
+    if constexpr (MODE == MODE_BWD_F) write_pix(kt_begin + it + 6);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int i = 0; i < NMFMA; ++i) {
+        const int a = i / TN, b = i % TN, q = s * NMFMA + i;
+        if (math) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int u = i * NU / NMFMA; dreads && u < (i + 1) * NU / NMFMA; ++u) read_unit(0, s + 1, (s + 1) & 1, u);
+        }
+#pragma unroll
+        for (int pc = q * NPREP / NS1; pc < (q + 1) * NPREP / NS1; ++pc) prep_piece(pc, kt_begin + it + 3, aoff, boff);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // tile it + 1 has landed (requested most of an iteration ago) on every wave, and no wave will read stage it & 1 again
-    ring_landed();
-    __syncthreads();
+    if (dland) ring_landed();
+    if (dbar) __syncthreads();
+    const bool rd = (STEADY || it + 1 < nkt) && dreads, rq = STEADY || it + 2 < nkt;
     if (math) {
-      if (it + 1 < nkt) read_frags(stn, 0, 0);
-      mfmas((BK / 16 - 1) & 1);
+#pragma unroll
+      for (int i = 0; i < NMFMA; ++i) {
+        const int a = i / TN, b = i % TN;
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][a], bf[1][b], acc[a][b], 0, 0, 0);
+        if (rd) {
+#pragma unroll
+          for (int u = i * NU / NMFMA; u < (i + 1) * NU / NMFMA; ++u) read_unit(1, 0, 0, u);
+        }
+        if (rq) {
+#pragma unroll
+          for (int d = i * NDMA / NMFMA; d < (i + 1) * NDMA / NMFMA; ++d) fire_one(par, d);
+        }
+        if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (rq) {
+      fire(par);
     }
-    if (it + 2 < nkt) {
-      if (dma_a) fire_a(it & 1);
-      if (dma_b) fire_b(it & 1);
-    }
-    prep(kt_begin + it + 3);
-    if constexpr (MODE == MODE_BWD_F) write_pix(kt_begin + it + 4);      // (slot of tile `it`: read three iterations ago)
-  }
+    // the stages trade places: the address registers of "this tile's stage" (index 0) and "the next tile's" (index 1)
+#pragma unroll
+    for (int i = 0; i < NAF; ++i) { const int t = a_fr[0][i]; a_fr[0][i] = a_fr[1][i]; a_fr[1][i] = t; }
+#pragma unroll
+    for (int i = 0; i < NBF; ++i) { const int t = b_fr[0][i]; b_fr[0][i] = b_fr[1][i]; b_fr[1][i] = t; }
+  };
+  int it = 0;
+  for (; it + 2 < nkt; ++it) body(it, std::true_type{});
+  for (; it < nkt; ++it) body(it, std::false_type{});
 
   // ---- epilogue: bias / activation in registers, then the tile leaves as WHOLE 16-byte row pieces.  A lane of the MFMA
   //      result holds one column: storing from there means 2-byte stores, 64 bytes of each cache line per instruction —

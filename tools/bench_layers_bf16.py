@@ -31,11 +31,14 @@ def main():
         fine = name == 'fine2'                              # f2 / df2 stay fp32 there
         bits = {'fwd': X | W if fine else X | W | Y, 'bwd_d': X | W if fine else X | W | Y, 'bwd_f': X if fine else X | Y}
         x = torch.randn((B, h, w, c), device='cuda').to(bf)
+        zero = os.environ.get('ZERO') == '1'      # all-zero operands: the clock the chip holds without switching activity (DVFS check)
         wt = (torch.randn((ks, ks, c, k), device='cuda') * 0.01)
         wb = wt.to(bf)
         bias = torch.zeros(k, device='cuda')
         y = torch.empty((B, d.ho, d.wo, k), device='cuda', dtype=torch.float32 if fine else bf)
         dz = torch.randn((B, d.ho, d.wo, k), device='cuda').to(torch.float32 if fine else bf)
+        if zero:
+            x.zero_(), wt.zero_(), wb.zero_(), dz.zero_()
         dx = torch.empty_like(x)
         dw = torch.empty_like(wt)
         db = torch.empty(k, device='cuda')

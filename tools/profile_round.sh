@@ -26,6 +26,9 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_A
 python3 tools/pmc_mfma.py $out/pmc_mfma/m_counter_collection.csv $out/pmc_mfma/m_kernel_trace.csv $P/${tag}_pmc_mfma_busy.json > $out/pmc_mfma.txt
 echo "mfma done"
 python3 bench.py --batch 64 --steps 20 --warmup 3 --no-cpu-baseline --precision bf16s --also bf16,bf16x3,fp32 > $P/${tag}_bench_batch64_bf16_storage.json 2> $out/bench_b64.err
+rocprofv3 --kernel-trace --output-format csv -d $out/kt16 -o kt -- python3 bench.py --batch 64 --precision bf16s --steps 6 --warmup 3 --no-cpu-baseline --no-fine --no-dp-rank --also "" > $out/kt16.log 2>&1
+python3 tools/timeline.py "$out/kt16/kt_kernel_trace.csv" adam_frozen -v > $P/${tag}_step_timeline_bf16_storage.txt
+rm -rf $out/kt16
 echo "b64 done"
 python3 bench.py --model dcnf --no-cpu-baseline > $P/${tag}_bench_dcnf.json 2> $out/bench_dcnf.err
 echo "dcnf done"
