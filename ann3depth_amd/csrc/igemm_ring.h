@@ -25,6 +25,7 @@
 //     land 64 bytes apart in the bank row.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "igemm_bf16.h"
 
@@ -59,6 +60,16 @@ struct RingCfg {
 
 __device__ __forceinline__ int ring_swz(int row) { return (row >> 1) & 7; }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression inside the body
+template <class F, int... I>
+__device__ __forceinline__ void ring_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void ring_static_for(F&& f) {
+  ring_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // Buffer descriptor in four scalar registers (make_rsrc's words; every word made provably wave-uniform: it is an "s"
 // operand of the statement below).
 typedef uint32_t ring_u32x4 __attribute__((ext_vector_type(4)));
@@ -88,7 +99,22 @@ __device__ __forceinline__ void ring_dma(ring_u32x4 rs, uint32_t voff, uint32_t 
 // every LDS-DMA this wave has requested has landed
 __device__ __forceinline__ void ring_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int MODE, int BM, int BN, int WAVES_M, bool C16>
+// Which k rows of a [64 k][columns] image move a 16-byte chunk, and where to (XOR on the chunk index), so that the transposing
+// read of a fragment touches every bank once.  32x32x16 fragments (a half-wave reads rows q = 0..3 at two column halves):
+// the row's low two bits move a chunk by 4 (128-byte rows: bit 1 only).  16x16x32 fragments (a half-wave reads rows q and
+// 8 + q, 32 bytes of each): row bits 0, 1 and 3 move a chunk PAIR by 1..7 pairs (128-byte rows: bits 1 and 3, 1..3 pairs).
+template <bool M16>
+__device__ __forceinline__ int ring_swz_tr(int k, int chunks_per_row) {
+  if constexpr (M16)
+    return chunks_per_row >= 16 ? (((k & 3) | (((k >> 3) & 1) << 2)) << 1) : ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1);
+  else
+    return chunks_per_row >= 16 ? ((k & 3) << 2) : (((k >> 1) & 1) << 2);
+}
+
+// M16: the contraction runs on v_mfma_f32_16x16x32_bf16 (sixteen-row sub-tiles, k-steps of 32) instead of 32x32x16 — the same
+// FLOPs per cycle, the same LDS bytes, the same results up to the order of the fp32 additions; the chip holds a higher
+// clock on this shape in MFMA-dense loops.
+template <int MODE, int BM, int BN, int WAVES_M, bool C16, bool M16 = false>
 __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) void igemm_ring_kernel(const IgemmParams p) {
   using Cfg = RingCfg<MODE, BM, BN, WAVES_M>;
   constexpr int BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN;
@@ -178,7 +204,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   if constexpr (MODE == MODE_BWD_F) {
     const int id = wave * 64 + lane;
     a_krow = id / CPRA;
-    const int cpos = id % CPRA, sw = (a_krow & 3) << 2;
+    const int cpos = id % CPRA, sw = ring_swz_tr<M16>(a_krow, CPRA);
     const ColDec dc = decode_col(p, m0 + 8 * (cpos ^ sw));
     a_dy = dc.r; a_dx = dc.s;
     a_coloff = ((dc.r * pW + dc.s) * pld + dc.c) * 2;
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     } else {                                      // [64 k][BN] as stored: filter [K][ldb]
       const int id = (j * 8 + wave) * 64 + lane;
       const int krow = id / CPR, cpos = id % CPR;
-      const int sw = CPR >= 16 ? ((krow & 3) << 2) : (((krow >> 1) & 1) << 2);
+      const int sw = ring_swz_tr<M16>(krow, CPR);
       const int col = n0 + 8 * (cpos ^ sw);
       b_voff[j] = col < p.ldb ? (uint32_t)(krow * p.ldb + col) * 2u : kOOB;      // (pad columns of a row are zeros)
     }
@@ -288,7 +314,10 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   //      inside the swizzled row — with the sub-tiles 4 KiB apart as immediates; [64 k][columns] images: one per (stage,
   //      sub-tile), the k-steps as immediates ----
   constexpr int ROWA = BM * 2;                    // bytes per pixel row of the bwd-filter A tile
-  constexpr int NAF = Cfg::A_KC ? 4 : TM, NBF = Cfg::B_KC ? 4 : TN;
+  constexpr int TM16 = 2 * TM, TN16 = 2 * TN;     // M16: sixteen-row sub-tiles of the wave tile
+  // 16x16x32: k-contiguous images one register per (stage, k-step of 32), the sub-tiles 2 KiB apart as immediates;
+  // [64 k][columns] images ONE per stage: sub-tile t is an XOR with 32 t bytes, the k-step an immediate
+  constexpr int NAF = M16 ? (Cfg::A_KC ? 2 : 1) : (Cfg::A_KC ? 4 : TM), NBF = M16 ? (Cfg::B_KC ? 2 : 1) : (Cfg::B_KC ? 4 : TN);
   int a_fr[2][NAF], b_fr[2][NBF];
   {
     const int g = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
@@ -296,7 +325,13 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     for (int stg = 0; stg < 2; ++stg) {
 #pragma unroll
       for (int i = 0; i < NAF; ++i) {
-        if constexpr (Cfg::A_KC) {
+        if constexpr (M16 && Cfg::A_KC) {
+          const int row = wm * Cfg::WM + l16;       // (+ 16 a: the same swizzle); this lane's k-chunk of k-step i: 4 i + g
+          a_fr[stg][i] = stg * Cfg::STAGE + row * 128 + (((4 * i + g) ^ ring_swz(row)) << 4);
+        } else if constexpr (M16) {
+          const int krow = 8 * g + q, c = ((wm * Cfg::WM) >> 3) + (pp >> 1);
+          a_fr[stg][i] = stg * Cfg::STAGE + krow * ROWA + ((c ^ ring_swz_tr<true>(krow, CPRA)) << 4) + (pp & 1) * 8;   // k-step s: + 32 s ROWA; sub-tile t: ^ 32 t
+        } else if constexpr (Cfg::A_KC) {
           const int row = wm * Cfg::WM + li;        // (+ 32 a: the same swizzle)
           a_fr[stg][i] = stg * Cfg::STAGE + ((row * 128 + ((lh ^ ring_swz(row)) << 4)) ^ (i << 5));
         } else {
@@ -307,7 +342,13 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       }
 #pragma unroll
       for (int i = 0; i < NBF; ++i) {
-        if constexpr (Cfg::B_KC) {
+        if constexpr (M16 && Cfg::B_KC) {
+          const int row = wn * Cfg::WN + l16;
+          b_fr[stg][i] = stg * Cfg::STAGE + Cfg::A_BYTES + row * 128 + (((4 * i + g) ^ ring_swz(row)) << 4);
+        } else if constexpr (M16) {
+          const int krow = 8 * g + q, c = ((wn * Cfg::WN) >> 3) + (pp >> 1);
+          b_fr[stg][i] = stg * Cfg::STAGE + Cfg::A_BYTES + krow * ROWB + ((c ^ ring_swz_tr<true>(krow, CPR)) << 4) + (pp & 1) * 8;
+        } else if constexpr (Cfg::B_KC) {
           const int row = wn * Cfg::WN + li;
           b_fr[stg][i] = stg * Cfg::STAGE + Cfg::A_BYTES + ((row * 128 + ((lh ^ ring_swz(row)) << 4)) ^ (i << 5));
         } else {
@@ -320,13 +361,25 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     }
   }
 
-  f32x16 acc[TM][TN];
+  // accumulators: 32x32 sub-tiles of sixteen registers, or (M16) 16x16 sub-tiles of four — the same count either way
+  f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+  f32x4 acc16[M16 ? TM16 : 1][M16 ? TN16 : 1];
+  if constexpr (M16) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM16; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < TN16; ++b)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+        for (int v = 0; v < 4; ++v) acc16[a][b][v] = 0.f;
+  }
+  if constexpr (!M16) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+  }
 
   // ---- main loop, rotated: the ONE barrier of an iteration sits BEFORE its last k-step.  At that point the wave holds the
   //      last k-step's fragments in registers (nothing of stage it & 1 will be read again) and tile it + 1 has landed, so
@@ -334,6 +387,95 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   //      are issued IN THE SHADOW of the last k-step's MFMAs.  With the barrier at the top of the iteration the first
   //      fragment reads, the requests' issue (60 - 180 cycles apiece) and the offsets' arithmetic all ran with the matrix
   //      pipe idle on all eight waves at once: a build without requests ran as long as (empty loop) + (MFMA time). ----
+  if constexpr (M16) {
+    // ---- 16x16x32: the k-tile is a sequence of NF = 2 TN16 B fragments (k-step 0's, then k-step 1's), each multiplied
+    //      into the TM16 accumulators of its column by one MFMA per A fragment: NSLOT = NF TM16 MFMA slots of 16 cycles.
+    //      B fragments live in a window of four registers sets, fragment f + 3 requested behind the first MFMA of fragment f
+    //      (past the end of the tile: the next tile's, behind the barrier); A fragments of k-step 1 are requested during
+    //      k-step 0, the next tile's k-step 0 behind the barrier.  The barrier follows the slot in which the tile's last B
+    //      fragment is requested: sixteen MFMAs' worth of operands are then in registers (or in flight), and in their
+    //      shadow go the requests of tile it + 2 and the first reads of tile it + 1, as in the 32x32x16 form. ----
+    constexpr int NF = 2 * TN16, NB = 4, AHEAD = NB - 1, NSLOT = NF * TM16, TB = (NF - NB) * TM16, NPOST = NSLOT - TB - 1;
+    static_assert(TN16 >= 4 && TM16 >= 2 && NF % NB == 0, "16x16x32 form: wave tiles of at least 32 x 64");
+    static_assert(NPOST >= TM16 && TB >= 4, "room behind and ahead of the barrier");
+    bf16x8 a16[2][TM16], bw[NB];
+    auto read_a = [&](int stg, int s, int a) {
+      if constexpr (Cfg::A_KC) {
+        a16[s & 1][a] = *reinterpret_cast<const bf16x8*>(smem_raw + a_fr[stg][s] + a * 2048);
+      } else {
+        const __bf16* q0 = reinterpret_cast<const __bf16*>(smem_raw + (a_fr[stg][0] ^ (a << 5)) + s * 32 * ROWA);
+        const bf16x4 lo4 = lds_read_tr(q0), hi4 = lds_read_tr(q0 + 2 * ROWA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a16[s & 1][a][e] = lo4[e]; a16[s & 1][a][4 + e] = hi4[e]; }
+      }
+    };
+    auto read_b = [&](int stg, int f) {
+      const int s = f / TN16, b = f % TN16;
+      if constexpr (Cfg::B_KC) {
+        bw[f % NB] = *reinterpret_cast<const bf16x8*>(smem_raw + b_fr[stg][s] + b * 2048);
+      } else {
+        const __bf16* q0 = reinterpret_cast<const __bf16*>(smem_raw + (b_fr[stg][0] ^ (b << 5)) + s * 32 * ROWB);
+        const bf16x4 lo4 = lds_read_tr(q0), hi4 = lds_read_tr(q0 + 2 * ROWB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bw[f % NB][e] = lo4[e]; bw[f % NB][4 + e] = hi4[e]; }
+      }
+    };
+    if (nkt > 0) {
+      prep_head(kt_begin);
+      prep_all(aoff, boff);
+      fire(0);
+      prep_head(kt_begin + 1);
+      prep_all(aoff, boff);
+      ring_landed();
+      __syncthreads();
+      if (nkt > 1) fire(1);
+      prep_head(kt_begin + 2);
+#pragma unroll
+      for (int a = 0; a < TM16; ++a) read_a(0, 0, a);
+#pragma unroll
+      for (int f = 0; f < AHEAD; ++f) read_b(0, f);
+    }
+    auto body16 = [&](int it, auto steady) {
+      constexpr bool STEADY = decltype(steady)::value;
+      const int par = it & 1;
+      const bool rd = STEADY || it + 1 < nkt, rq = STEADY || it + 2 < nkt;
+      if constexpr (MODE == MODE_BWD_F) write_pix(kt_begin + it + 6);
+      ring_static_for<NSLOT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int f = t / TM16, a = t % TM16, s = f / TN16, b = f % TN16;
+        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[s & 1][a], bw[f % NB], acc16[a][b], 0, 0, 0);
+        if (a == 0) {                                           // the window moves on
+          if (f + AHEAD < NF) read_b(0, f + AHEAD);
+          else if (rd) read_b(1, f + AHEAD - NF);
+        }
+#pragma unroll
+        for (int j = 0; j < TM16; ++j) {
+          if (t == (TM16 * j + 1 < TB ? TM16 * j + 1 : TB)) read_a(0, 1, j);        // k-step 1 of this tile
+          if (t == TB + 1 + j && rd) read_a(1, 0, j);                               // k-step 0 of the next one
+        }
+        if (t < TB) {
+#pragma unroll
+          for (int pc = t * NPREP / TB; pc < (t + 1) * NPREP / TB; ++pc) prep_piece(pc, kt_begin + it + 3, aoff, boff);
+        } else if (t > TB && rq) {
+#pragma unroll
+          for (int d = (t - TB - 1) * NDMA / NPOST; d < (t - TB) * NDMA / NPOST; ++d) fire_one(par, d);
+        }
+        if (t == TB) {
+          ring_landed();
+          __syncthreads();
+        } else if (STEADY) {
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+#pragma unroll
+      for (int i = 0; i < NAF; ++i) { const int t = a_fr[0][i]; a_fr[0][i] = a_fr[1][i]; a_fr[1][i] = t; }
+#pragma unroll
+      for (int i = 0; i < NBF; ++i) { const int t = b_fr[0][i]; b_fr[0][i] = b_fr[1][i]; b_fr[1][i] = t; }
+    };
+    int it = 0;
+    for (; it + 2 < nkt; ++it) body16(it, std::true_type{});
+    for (; it < nkt; ++it) body16(it, std::false_type{});
+  } else {
   bf16x8 af[2][TM], bf[2][TN];
   // fragment number u of k-step s of this iteration's tile (stg 0) or the next one's (stg 1): A sub-tile u (u < TM) or B sub-tile u - TM
   auto read_unit = [&](int stg, int s, int buf, int u) {
@@ -435,6 +577,8 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   for (; it + 2 < nkt; ++it) body(it, std::true_type{});
   for (; it < nkt; ++it) body(it, std::false_type{});
 
+  }
+
   // ---- epilogue: bias / activation in registers, then the tile leaves as WHOLE 16-byte row pieces.  A lane of the MFMA
   //      result holds one column: storing from there means 2-byte stores, 64 bytes of each cache line per instruction —
   //      measured (a build of this kernel with requests and math removed): 35 of conv2d_1's 95 us.  Each wave passes its
@@ -458,44 +602,54 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   }
   unsigned char* eb = smem_raw + wave * (32 * EP);
   const int er = lane / LPRP, ec = lane % LPRP;    // 16-byte phase: this lane's row within a group of RPI, its piece of the row
+  // element e (0 .. 15) of a lane's share of a 32 x 32 sub-tile: its row and column inside the sub-tile.  32x32x16: column li,
+  // rows (e & 3) + 8 (e >> 2) + 4 lh.  16x16x32: four 16 x 16 accumulators (a2, b2), e = 8 a2 + 4 b2 + v: row 16 a2 + 4 (lane >> 4) + v,
+  // column 16 b2 + (lane & 15).  Either way e and e + 1 (e even) are rows r, r + 1 of one column, and lane ^ 1 holds the
+  // neighbouring column of the same rows.
+  auto erow = [&](int e) { return M16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * lh; };
+  auto ecol = [&](int e) { return M16 ? 16 * ((e >> 2) & 1) + (lane & 15) : li; };
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int col = n0 + wn * Cfg::WN + b * 32 + li;
-      float bias = 0.f;
-      if (MODE == MODE_FWD && !partial && p.bias && col < p.N) bias = p.bias[col];
+      float bias[2] = {0.f, 0.f};
+#pragma unroll
+      for (int h2 = 0; h2 < (M16 ? 2 : 1); ++h2) {
+        const int col = n0 + wn * Cfg::WN + b * 32 + ecol(4 * h2);
+        if (MODE == MODE_FWD && !partial && p.bias && col < p.N) bias[h2] = p.bias[col];
+      }
       float val[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        val[v] = acc[a][b][v];
+        if constexpr (M16) val[v] = acc16[2 * a + (v >> 3)][2 * b + ((v >> 2) & 1)][v & 3];
+        else val[v] = acc[a][b][v];
         if (MODE == MODE_FWD && !partial) {
-          val[v] += bias;
+          val[v] += bias[M16 ? (v >> 2) & 1 : 0];
           if (p.act == EPI_RELU) val[v] = fmaxf(val[v], 0.f);
           else if (p.act == EPI_SIGMOID) val[v] = 1.f / (1.f + expf(-val[v]));
           if (p.keep) {                            // tf.layers.dropout fused (dense layers: a handful of rows)
-            const int row = m0 + wm * Cfg::WM + a * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            const int row = m0 + wm * Cfg::WM + a * 32 + erow(v), col = n0 + wn * Cfg::WN + b * 32 + ecol(v);
             if (row < p.M && col < p.N) val[v] = p.keep[(size_t)row * p.N + col] ? val[v] * p.mask_scale : 0.f;
           }
         }
       }
       if constexpr (C16) {
-        // rows r (register v even) and r + 1 (v + 1) of column li: the even lane takes over its neighbour's row-r value and
-        // writes columns li, li + 1 of row r; the odd lane gets the neighbour's row-(r + 1) value: columns li - 1, li
+        // rows r (register v even) and r + 1 (v + 1) of one column: the even lane takes over its neighbour's row-r value and
+        // writes columns c, c + 1 of row r; the odd lane gets the neighbour's row-(r + 1) value: columns c - 1, c
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const bool odd = li & 1;
+        const bool odd = lane & 1;
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
           const float give = odd ? val[v] : val[v + 1];
           const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
           const bf16x2 pk = odd ? bf16x2{(__bf16)got, (__bf16)val[v + 1]} : bf16x2{(__bf16)val[v], (__bf16)got};
-          const int row = (v & 3) + 8 * (v >> 2) + 4 * lh + (odd ? 1 : 0);
-          *reinterpret_cast<bf16x2*>(eb + row * EP + (b * 32 + (li & ~1)) * 2) = pk;
+          const int row = erow(v) + (odd ? 1 : 0);
+          *reinterpret_cast<bf16x2*>(eb + row * EP + (b * 32 + (ecol(v) & ~1)) * 2) = pk;
         }
       } else {
 #pragma unroll
         for (int v = 0; v < 16; ++v)
-          *reinterpret_cast<float*>(eb + ((v & 3) + 8 * (v >> 2) + 4 * lh) * EP + (b * 32 + li) * 4) = val[v];
+          *reinterpret_cast<float*>(eb + erow(v) * EP + (b * 32 + ecol(v)) * 4) = val[v];
       }
     }
     // the same wave reads what it wrote: LDS serves a wave's accesses in order

@@ -9,10 +9,17 @@ namespace a3d {
 // index, BM, BN, WAVES_M  (keep in step with kRingCfgs in igemm_host.hip)
 #define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4) X(5, 512, 64, 8) X(6, 64, 128, 2)
 
-template <int MODE, int BM, int BN, int WAVES_M, bool C16>
+// A3D_RING_M16 (tuning aid, read once): 0 = every launch on v_mfma_f32_32x32x16_bf16, 1 = on 16x16x32 wherever that form
+// exists (wave tiles of at least 32 x 64), unset = the shipped choice per tile (ring_m16_default)
+static int ring_m16_env() {
+  static const int v = getenv("A3D_RING_M16") ? atoi(getenv("A3D_RING_M16")) : -1;
+  return v;
+}
+
+template <int MODE, int BM, int BN, int WAVES_M, bool C16, bool M16>
 static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {
   using Cfg = RingCfg<MODE, BM, BN, WAVES_M>;
-  auto kern = igemm_ring_kernel<MODE, BM, BN, WAVES_M, C16>;
+  auto kern = igemm_ring_kernel<MODE, BM, BN, WAVES_M, C16, M16>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -25,17 +32,42 @@ static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {
   return check_launch("igemm_ring");
 }
 
+static bool ring_m16_default(int mode, int cfg) { return false; }
+
+template <int MODE, int BM, int BN, int WAVES_M>
+static int launch_ring_tile(int cfg, bool c16, IgemmParams& p, unsigned grid, hipStream_t st) {
+  // The 16x16x32 form (igemm_ring.h, M16) is parity-green and measured: within 1 % of the 32x32x16 form on every layer
+  // (DESIGN.md 6, round 4).  It is instantiated only in builds made with -DA3D_RING_M16 (twice the kernels to compile).
+#ifdef A3D_RING_M16
+  constexpr bool HAS16 = RingCfg<MODE, BM, BN, WAVES_M>::TN >= 2;      // it needs four 16-column sub-tiles per wave
+#else
+  constexpr bool HAS16 = false;
+#endif
+  const int env = ring_m16_env();
+  const bool m16 = HAS16 && (env < 0 ? ring_m16_default(MODE, cfg) : env != 0);
+  if constexpr (HAS16) {
+    if (m16) {
+      if constexpr (MODE != MODE_BWD_F)
+        if (c16) return launch_ring_one<MODE, BM, BN, WAVES_M, true, true>(p, grid, st);
+      return launch_ring_one<MODE, BM, BN, WAVES_M, false, true>(p, grid, st);
+    }
+  }
+  if constexpr (MODE != MODE_BWD_F)
+    if (c16) return launch_ring_one<MODE, BM, BN, WAVES_M, true, false>(p, grid, st);
+  return launch_ring_one<MODE, BM, BN, WAVES_M, false, false>(p, grid, st);
+}
+
 template <int MODE>
 static int launch_ring_mode(int cfg, IgemmParams& p, unsigned grid, hipStream_t st) {
   const bool c16 = p.c16 && p.splitk == 1;       // split-K slabs are float32; the reduction writes the bf16 tensor
   switch (cfg) {
 #define X(i, bm, bn, wm) \
-  case i: return c16 ? launch_ring_one<MODE, bm, bn, wm, true>(p, grid, st) : launch_ring_one<MODE, bm, bn, wm, false>(p, grid, st);
+  case i: return launch_ring_tile<MODE, bm, bn, wm>(cfg, c16, p, grid, st);
     A3D_RING_CFGS(X)
 #undef X
   }
   if (MODE == MODE_BWD_D && cfg == 4)      // 96 input channels (conv2d_1's bwd-data): one 96-column tile, k-contiguous filter rows
-    return c16 ? launch_ring_one<MODE_BWD_D, 256, 96, 8, true>(p, grid, st) : launch_ring_one<MODE_BWD_D, 256, 96, 8, false>(p, grid, st);
+    return launch_ring_tile<MODE_BWD_D, 256, 96, 8>(cfg, c16, p, grid, st);
   return set_error(A3D_EINVAL, "igemm ring: unknown config %d", cfg);
 }
 
@@ -43,10 +75,10 @@ int launch_igemm_ring(int mode, int cfg, IgemmParams& p, unsigned grid, hipStrea
   if (mode == MODE_FWD) return launch_ring_mode<MODE_FWD>(cfg, p, grid, st);
   if (mode == MODE_BWD_D) return launch_ring_mode<MODE_BWD_D>(cfg, p, grid, st);
   switch (cfg) {                               // bwd-filter: float32 gradient (or split-K slabs), tiles of at least 128 rows / 64 columns
-    case 0: return launch_ring_one<MODE_BWD_F, 256, 128, 4, false>(p, grid, st);
-    case 1: return launch_ring_one<MODE_BWD_F, 256, 64, 8, false>(p, grid, st);
-    case 2: return launch_ring_one<MODE_BWD_F, 256, 256, 4, false>(p, grid, st);
-    case 3: return launch_ring_one<MODE_BWD_F, 128, 128, 4, false>(p, grid, st);
+    case 0: return launch_ring_tile<MODE_BWD_F, 256, 128, 4>(cfg, false, p, grid, st);
+    case 1: return launch_ring_tile<MODE_BWD_F, 256, 64, 8>(cfg, false, p, grid, st);
+    case 2: return launch_ring_tile<MODE_BWD_F, 256, 256, 4>(cfg, false, p, grid, st);
+    case 3: return launch_ring_tile<MODE_BWD_F, 128, 128, 4>(cfg, false, p, grid, st);
   }
   return set_error(A3D_EINVAL, "igemm ring: unknown bwd-filter config %d", cfg);
 }
