@@ -123,6 +123,10 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   constexpr int ROWB = BN * 2;                    // bytes per k row of the forward filter tile
   constexpr int CPR = BN / 8;                     // its 16-byte chunks per row
 
+#ifdef A3D_STAMPS           // diagnostic build (never shipped): cycle stamps of the loop's phases, per wave (tools/stamps_ring.py)
+  unsigned long long st_entry = 0, st_beg = 0, st_end = 0, st_s0 = 0, st_s1 = 0, st_s2 = 0, st_d1 = 0, st_dw = 0, st_d2 = 0, st_rt0 = 0, st_rt1 = 0;
+  A3D_STAMP(st_entry);
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int4* rowtab = reinterpret_cast<int4*>(smem_raw + Cfg::NSTAGE * Cfg::STAGE);
   int4* taptab = rowtab + Cfg::TAB_ROWS;
@@ -502,6 +506,18 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     }
   };
   constexpr int NMFMA = TM * TN, NU = TM + TN, NS1 = 3 * NMFMA;
+  // The CU's address unit takes 16 cycles per request (64 lanes x 16 bytes), 64 requests per k-tile of a 256 x 256 block:
+  // 1 024 of the 2 048 cycles the matrix pipe needs.  All of them behind the barrier — the only place the two-stage ring
+  // allows a whole tile's requests — made the last k-step (512 MFMA cycles per SIMD) take 1 050 (in-kernel stamps).  So only
+  // NEARLY requests per wave go there (what their shadow hides: half as many as MFMA slots); the other NLATE follow in the
+  // first slots of the NEXT iteration, still an iteration's k-steps 0 .. 2 ahead of the barrier that waits for them.
+#ifdef A3D_RING_NEARLY
+  constexpr int NEARLY_ = A3D_RING_NEARLY;
+#else
+  constexpr int NEARLY_ = NMFMA / 2;
+#endif
+  constexpr int NEARLY = NEARLY_ < 1 ? 1 : NEARLY_ > NDMA ? NDMA : (NDMA - NEARLY_ >= NS1 ? NDMA - NS1 + 1 : NEARLY_), NLATE = NDMA - NEARLY;
+  static_assert(NLATE < NS1, "a slot is left for the offsets");
 #ifdef A3D_RING_DIAG      // A3D_DBG bit 2: no fragment reads, no MFMAs; bit 3: no barrier; bit 4: no wait for the requests; bit 5: no fragment reads
   const bool math = !(p.dbg & 4), dbar = !(p.dbg & 8), dland = !(p.dbg & 16), dreads = !(p.dbg & 32);
 #else
@@ -515,21 +531,29 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     prep_all(aoff, boff);
     ring_landed();
     __syncthreads();
-    if (nkt > 1) fire(1);
+    if (nkt > 1) {
+#pragma unroll
+      for (int d = 0; d < NEARLY; ++d) fire_one(1, d);       // (the rest of tile 1: first slots of iteration 0)
+    }
     prep_head(kt_begin + 2);
 #pragma unroll
     for (int u = 0; u < NU; ++u) read_unit(0, 0, 0, u);
   }
   // One iteration.  The instruction order is pinned slot by slot: a slot is ONE MFMA and what rides
   // in its shadow; the compiler may not move anything across a slot's end.
-  //   k-steps 0 .. 2   the slot's share of the next k-step's fragment reads, and of the offset arithmetic of tile it + 2
-  //                    (whose tap entry was read an iteration ago; the last piece requests the entry of tile it + 3)
+  //   k-steps 0 .. 2   the slot's share of the next k-step's fragment reads; in the first NLATE slots the remaining requests
+  //                    of tile it + 1, in the others the offset arithmetic of tile it + 2 (whose tap entry was read an
+  //                    iteration ago; the last piece requests the entry of tile it + 3)
   //   barrier          tile it + 1 has landed on every wave, no wave reads stage it & 1 again
-  //   last k-step      the slot's share of the first fragment reads of tile it + 1 and of the requests of tile it + 2
+  //   last k-step      the slot's share of the first fragment reads of tile it + 1 and of the first NEARLY requests of tile it + 2
   // STEADY (tiles it + 1 and it + 2 exist): no branch between the top and the bottom of the iteration.
   auto body = [&](int it, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;
     const int par = it & 1;
+#ifdef A3D_STAMPS
+    A3D_STAMP(st_s0);
+    if (it > 0) st_d2 += st_s0 - st_s2;
+#endif
     if constexpr (MODE == MODE_BWD_F) write_pix(kt_begin + it + 6);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -541,13 +565,26 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
 #pragma unroll
           for (int u = i * NU / NMFMA; dreads && u < (i + 1) * NU / NMFMA; ++u) read_unit(0, s + 1, (s + 1) & 1, u);
         }
+        if (q < NLATE) {
+          if (STEADY || it + 1 < nkt) fire_one(par ^ 1, NEARLY + q);
+        } else {
 #pragma unroll
-        for (int pc = q * NPREP / NS1; pc < (q + 1) * NPREP / NS1; ++pc) prep_piece(pc, kt_begin + it + 3, aoff, boff);
+          for (int pc = (q - NLATE) * NPREP / (NS1 - NLATE); pc < (q - NLATE + 1) * NPREP / (NS1 - NLATE); ++pc)
+            prep_piece(pc, kt_begin + it + 3, aoff, boff);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef A3D_STAMPS
+    A3D_STAMP(st_s1);
+    st_d1 += st_s1 - st_s0;
+#endif
     if (dland) ring_landed();
     if (dbar) __syncthreads();
+#ifdef A3D_STAMPS
+    A3D_STAMP(st_s2);
+    st_dw += st_s2 - st_s1;
+#endif
     const bool rd = (STEADY || it + 1 < nkt) && dreads, rq = STEADY || it + 2 < nkt;
     if (math) {
 #pragma unroll
@@ -560,12 +597,13 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
         }
         if (rq) {
 #pragma unroll
-          for (int d = i * NDMA / NMFMA; d < (i + 1) * NDMA / NMFMA; ++d) fire_one(par, d);
+          for (int d = i * NEARLY / NMFMA; d < (i + 1) * NEARLY / NMFMA; ++d) fire_one(par, d);
         }
         if constexpr (STEADY) __builtin_amdgcn_sched_barrier(0);
       }
     } else if (rq) {
-      fire(par);
+#pragma unroll
+      for (int d = 0; d < NEARLY; ++d) fire_one(par, d);
     }
     // the stages trade places: the address registers of "this tile's stage" (index 0) and "the next tile's" (index 1)
 #pragma unroll
@@ -573,9 +611,18 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
 #pragma unroll
     for (int i = 0; i < NBF; ++i) { const int t = b_fr[0][i]; b_fr[0][i] = b_fr[1][i]; b_fr[1][i] = t; }
   };
+#ifdef A3D_STAMPS
+  A3D_STAMP(st_beg);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
+#endif
   int it = 0;
   for (; it + 2 < nkt; ++it) body(it, std::true_type{});
   for (; it < nkt; ++it) body(it, std::false_type{});
+#ifdef A3D_STAMPS
+  A3D_STAMP(st_end);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1)::"memory");
+  st_d2 += st_end - st_s2;
+#endif
 
   }
 
@@ -680,6 +727,17 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       }
     }
   }
+#ifdef A3D_STAMPS
+  {
+    unsigned long long st_exit = 0;
+    A3D_STAMP(st_exit);
+    if (p.stamps && lane == 0) {
+      unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 16;
+      o[0] = st_d1; o[1] = st_dw; o[2] = st_d2; o[3] = st_end - st_beg; o[4] = st_rt1 - st_rt0; o[5] = (unsigned long long)nkt;
+      o[6] = st_beg - st_entry; o[7] = st_exit - st_end; o[8] = st_entry; o[9] = st_exit;
+    }
+  }
+#endif
 }
 
 }  // namespace a3d
