@@ -4,7 +4,8 @@ algorithmic bytes through the fabric (FETCH_SIZE): every XCD streams all of x an
 Cache: scale past L3 before reading FETCH_SIZE as over-fetch evidence).  This script times the launch at a given batch,
 tile-major (default) or K-sliced per XCD (A3D_SK_SLICED=1, read once per process); run it under
     rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum
-for the byte counts (tools/profile_round.sh does).      python tools/ic_evidence.py BATCH"""
+for the byte counts (tools/profile_ic.sh runs exactly these passes and writes profiles/<round>_ic_evidence.txt).
+    python tools/ic_evidence.py BATCH"""
 import json
 import os
 import sys
