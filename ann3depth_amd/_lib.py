@@ -74,6 +74,7 @@ SIGNATURES = {
     'a3d_maxpool2x2_bwd_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
     'a3d_copy_channel_bf16': (c_int, [c_size_t, _P, c_int, c_int, _P, c_int, c_int, _P]),
     'a3d_maxpool2x2_bwd_idx_bf16': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P]),
+    'a3d_maxpool2x2_bwd_idx_bf16s': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P]),
     'a3d_dense_bwd_filter_adam_tf1': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                               c_float, c_float, c_float, _P]),
     'a3d_dense_bwd_filter_adam_tf1_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,

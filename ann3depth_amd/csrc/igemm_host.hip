@@ -127,7 +127,7 @@ static const int kFirstGldsCfg = 9;
 // stays on igemm_bf16's split-K).  A3D_RING=0 turns the kernel off, A3D_RING_CFG pins a tile (tuning processes).
 static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   static const bool off = env_int("A3D_RING", 1) == 0;
-  if (!g.ring_ok || g.plain) return false;
+  if (!g.ring_ok || (g.plain && g.mode != MODE_FWD)) return false;      // (plain = the forward with the 2x2 max pool fused: never split)
   if (g.mode != MODE_BWD_F && g.M <= 64 && g.N >= 1024 && g.K >= 1024) {      // (not under A3D_RING: bf16 x / dz have no other kernel)
     // a dense layer of a small batch: a weight stream.  64-row tiles of 128 columns, K split until ~512 blocks (three per
     // CU) pull on HBM; the slabs are a few MB
@@ -172,10 +172,10 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
   else if (g.N % 256 == 0 && (long)((g.M + 255) / 256) * (g.N / 256) >= 192) cfg = 2;
   else cfg = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) >= 192 ? 0 : 3;
   const int forced = tune_int("A3D_RING_CFG", -1);
-  if (forced >= 0 && forced <= 6 && !(forced == 4 && g.mode != MODE_BWD_D)) cfg = forced;
+  if (forced >= 0 && forced <= 6 && !(forced == 4 && g.mode != MODE_BWD_D) && !(forced == 6 && g.plain)) cfg = forced;
   const int bm = kRingCfgs[cfg].bm, bn = kRingCfgs[cfg].bn;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
-  if (tiles < 96 && forced < 0) return false;
+  if (tiles < 96 && forced < 0 && !g.plain) return false;      // (a pooled forward on bf16 inputs has no other kernel)
   pl.ring = 1 + cfg;
   pl.tiles_m = (g.M + bm - 1) / bm;
   pl.tiles_n = (g.N + bn - 1) / bn;
@@ -906,8 +906,11 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
   if (pool) {
-    A3D_CHECK_ARG(d->precision == A3D_PREC_F32 || bf16_image_form_ok(d, x),
-                  "conv2d_pool_fwd: fp32, or the bf16 image form (4-channel bf16 image, a3d_pad_channels_bf16)");
+    const int all16 = A3D_STORE_X_BF16 | A3D_STORE_W_BF16 | A3D_STORE_Y_BF16;
+    A3D_CHECK_ARG(d->precision == A3D_PREC_F32 || bf16_image_form_ok(d, x) ||
+                      (d->precision == A3D_PREC_BF16 && (d->storage & all16) == all16),
+                  "conv2d_pool_fwd: fp32, the bf16 image form (4-channel bf16 image, a3d_pad_channels_bf16), or bf16 arithmetic on "
+                  "bf16 x, w and y (LDS-DMA kernel)");
     A3D_CHECK_ARG(d->ho >= 2 && d->wo >= 2 && ld_out >= d->k, "conv2d_pool_fwd: output smaller than one pool window");
     A3D_CHECK_ARG(!stencil1_applicable(d), "conv2d_pool_fwd: single-output-channel convs are not supported");
   } else if (stencil1_applicable(d)) {
@@ -964,18 +967,24 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   fill_common(p, g);
   {
     const int sb = d->storage;
-    A3D_CHECK_ARG(!sb || ((!pool || sb == A3D_STORE_Y_BF16) && !(run && (sb & A3D_STORE_W_BF16))),
-                  "conv2d_fwd: the fused pool takes float32 inputs (its output may be bf16); 3-channel filters stay float32");
+    const int all16 = A3D_STORE_X_BF16 | A3D_STORE_W_BF16 | A3D_STORE_Y_BF16;
+    A3D_CHECK_ARG(!sb || ((!pool || sb == A3D_STORE_Y_BF16 || (sb == all16 && d->precision == A3D_PREC_BF16)) &&
+                          !(run && (sb & A3D_STORE_W_BF16))),
+                  "conv2d_fwd: the fused pool takes float32 inputs (its output may be bf16) or bf16 x, w and y; 3-channel filters stay float32");
     const IgemmParams keep = p;
     rc = apply_storage(p, g, d->precision, sb & A3D_STORE_X_BF16, sb & A3D_STORE_W_BF16, sb & A3D_STORE_Y_BF16, d->c,
                        d->ldx, d->k, d->k, x, w, y, d->k, d->ldy);
     if (rc != A3D_OK) return rc;
     (void)keep;
     // both operands bf16 tensors, whole 16-byte pieces inside one tap: the LDS-DMA kernel may take the launch
-    g.ring_ok = p.a16 && p.b16 && !pool && !run && d->precision == A3D_PREC_BF16 && d->c % 8 == 0 && d->ldx % 8 == 0 &&
-                d->k % 8 == 0 && d->ldy % 8 == 0 && d->r * d->s <= 128 && aligned16(y) && act != A3D_ACT_SIGMOID;
+    // (pooled: the pooled map's pixel stride and the argmax rows in whole 16-byte pieces too)
+    g.ring_ok = p.a16 && p.b16 && !run && d->precision == A3D_PREC_BF16 && d->c % 8 == 0 && d->ldx % 8 == 0 &&
+                d->k % 8 == 0 && d->ldy % 8 == 0 && d->r * d->s <= 128 && aligned16(y) && act != A3D_ACT_SIGMOID &&
+                (!pool || (p.c16 && ld_out % 8 == 0 && (!argmax || (d->k % 16 == 0 && aligned16(argmax)))));
   }
   GemmPlan plan = plan_gemm(g, d->precision);
+  A3D_CHECK_ARG(!(pool && (p.a16 || p.b16)) || plan.ring,
+                "conv2d_pool_fwd: on bf16 inputs the fused pool is the LDS-DMA kernel's (channels and strides in whole 16-byte pieces, k %% 16 == 0)");
   if (ws_used + plan.ws_bytes > ws_bytes)
     return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
   A3D_CHECK_ARG(!(p.a16 || p.b16) || plan.prec == A3D_PREC_BF16, "conv2d_fwd: bf16 operands need vectorisable tensors");

@@ -647,6 +647,9 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     Cout = p.C + (size_t)split * p.slab;
     ldc = p.N;
   }
+  // the fused 2x2 max pool (forward only, never split: host) leaves through the same staging rows, eight pooled rows per group
+  constexpr bool POOLABLE = MODE == MODE_FWD && !M16 && 8 % RPI == 0 && Cfg::WN % 16 == 0 && 8 * (Cfg::WN / 16) <= 64;
+  const bool pooled = POOLABLE && p.pool != 0;
   unsigned char* eb = smem_raw + wave * (32 * EP);
   const int er = lane / LPRP, ec = lane % LPRP;    // 16-byte phase: this lane's row within a group of RPI, its piece of the row
   // element e (0 .. 15) of a lane's share of a 32 x 32 sub-tile: its row and column inside the sub-tile.  32x32x16: column li,
@@ -680,6 +683,47 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
           }
         }
       }
+      if constexpr (POOLABLE) {
+        if (pooled) {
+          // forward with the 2x2 max pool fused (rows enumerated window by window, make_pix): registers 4 j .. 4 j + 3 are the
+          // four conv outputs of window 2 j + lh of this 32-row group.  The values a separate conv would have stored (rounded
+          // to bf16 if its output tensor is), compared the way MaxPool / MaxPoolGrad scan them: first maximum wins.
+          float pv[4];
+          int pa[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v4[i] = C16 ? (float)(__bf16)val[4 * j + i] : val[4 * j + i];
+            pv[j] = v4[0];
+            pa[j] = 0;
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+              if (v4[i] > pv[j]) { pv[j] = v4[i]; pa[j] = i; }
+          }
+          unsigned char* eb8 = eb + 8 * EP;          // the argmax bytes of the eight windows: rows of WN + 16 bytes
+          if constexpr (C16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int jp = 0; jp < 4; jp += 2) {
+              const float give = odd ? pv[jp] : pv[jp + 1];
+              const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));
+              const bf16x2 pk = odd ? bf16x2{(__bf16)got, (__bf16)pv[jp + 1]} : bf16x2{(__bf16)pv[jp], (__bf16)got};
+              const int wrow = 2 * (jp + (odd ? 1 : 0)) + lh;
+              *reinterpret_cast<bf16x2*>(eb + wrow * EP + (b * 32 + (li & ~1)) * 2) = pk;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float*>(eb + (2 * j + lh) * EP + (b * 32 + li) * 4) = pv[j];
+          }
+          if (p.argmax) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) eb8[(2 * j + lh) * (Cfg::WN + 16) + b * 32 + li] = (unsigned char)pa[j];
+          }
+          continue;
+        }
+      }
       if constexpr (C16) {
         // rows r (register v even) and r + 1 (v + 1) of one column: the even lane takes over its neighbour's row-r value and
         // writes columns c, c + 1 of row r; the odd lane gets the neighbour's row-(r + 1) value: columns c - 1, c
@@ -700,6 +744,32 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       }
     }
     // the same wave reads what it wrote: LDS serves a wave's accesses in order
+    if constexpr (POOLABLE) {
+      if (pooled) {
+        const int prow0 = (m0 + wm * Cfg::WM + a * 32) >> 2;      // first pooled pixel of this group of eight windows
+#pragma unroll
+        for (int i = 0; i < 8 / RPI; ++i) {
+          const int r = i * RPI + er;
+          const int col0 = n0 + wn * Cfg::WN + ec * (16 / ESZ);
+          if (LPR != LPRP && ec >= LPR) continue;
+          const u32x4 q = *reinterpret_cast<const u32x4*>(eb + r * EP + ec * 16);
+          if (4 * (prow0 + r) < p.M && col0 < p.N) {
+            const size_t o = (size_t)(prow0 + r) * ldc + col0;
+            if constexpr (C16) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(Cout) + o) = q;
+            else *reinterpret_cast<u32x4*>(Cout + o) = q;
+          }
+        }
+        if (p.argmax) {                                            // sixteen window positions per lane, whole 16-byte pieces (N % 16 == 0: host)
+          constexpr int APR = Cfg::WN / 16;                       // pieces per row
+          const int r = lane / APR, c16 = lane % APR, col0 = n0 + wn * Cfg::WN + c16 * 16;
+          if (lane < 8 * APR) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(eb + 8 * EP + r * (Cfg::WN + 16) + c16 * 16);
+            if (4 * (prow0 + r) < p.M && col0 < p.N) *reinterpret_cast<u32x4*>(p.argmax + (size_t)(prow0 + r) * p.N + col0) = q;
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 32 / RPI; ++i) {
       const int r = i * RPI + er;

@@ -10,6 +10,7 @@
 namespace a3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline unsigned grid_for(size_t total, int per_block = 256, unsigned cap = 8192) {
   size_t g = (total + per_block - 1) / per_block;
@@ -598,6 +599,47 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_bf16_kernel(const uint8_t
     }
   }
 }
+// The same with a bf16 dx (config 5: the conv stack's activation gradients are bf16 tensors), eight channels per thread:
+// 8 argmax bytes, 16 bytes of pooled values and of dy in, four 16-byte pieces of dx out.
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_bf16s_kernel(const uint8_t* __restrict__ argmax,
+                                                                    const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
+                                                                    __bf16* __restrict__ dx, int n, int h, int w, int c, int ho,
+                                                                    int wo, int ldy, int lddy, int relu_mask) {
+  const int hc = (h + 1) / 2, wc = (w + 1) / 2, c8 = c / 8;
+  const size_t total = (size_t)n * hc * wc * c8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % c8) * 8;
+    size_t t = i / c8;
+    const int q = (int)(t % wc);
+    t /= wc;
+    const int p = (int)(t % hc);
+    const int b = (int)(t / hc);
+    const size_t base = (((size_t)b * h + 2 * p) * w + 2 * q) * c + ch;
+    const bool has_r = 2 * p + 1 < h, has_c = 2 * q + 1 < w;
+    u32x4 o[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    if (p < ho && q < wo) {
+      const size_t win = ((size_t)b * ho + p) * wo + q;
+      const uint2 a8 = *reinterpret_cast<const uint2*>(argmax + win * c + ch);
+      const u32x4 yv = *reinterpret_cast<const u32x4*>(y + win * ldy + ch);
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + win * lddy + ch);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t sh = (e & 1) ? 0xffff0000u : 0x0000ffffu;
+        const uint32_t yb = (e & 1) ? (yv[e >> 1] & 0xffff0000u) : (yv[e >> 1] << 16);
+        uint32_t g = gv[e >> 1] & sh;                                   // the gradient's 16 bits, in place
+        if (relu_mask && !(__uint_as_float(yb) > 0.f)) g = 0u;
+        const uint32_t arg = ((e < 4 ? a8.x : a8.y) >> (8 * (e & 3))) & 0xffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (arg == (uint32_t)k) o[k][e >> 1] |= g;
+      }
+    }
+    *reinterpret_cast<u32x4*>(dx + base) = o[0];
+    if (has_c) *reinterpret_cast<u32x4*>(dx + base + c) = o[1];
+    if (has_r) *reinterpret_cast<u32x4*>(dx + base + (size_t)w * c) = o[2];
+    if (has_r && has_c) *reinterpret_cast<u32x4*>(dx + base + (size_t)w * c + c) = o[3];
+  }
+}
 }  // namespace a3d
 
 using namespace a3d;
@@ -825,6 +867,21 @@ int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argma
                      argmax, static_cast<const __bf16*>(y), static_cast<const __bf16*>(dy), dx, n, h, w, c, h / 2, w / 2, ldy,
                      lddy, relu_mask);
   return check_launch("maxpool_bwd_idx_bf16");
+}
+
+int a3d_maxpool2x2_bwd_idx_bf16s(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,
+                                 int lddy, void* dx, int relu_mask, void* stream) {
+  A3D_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && c > 0 && argmax && y && dy && dx && ldy >= c && lddy >= c,
+                "maxpool_bwd_idx_bf16s: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx);
+  A3D_CHECK_ARG(c % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (al & 15) == 0 && (reinterpret_cast<uintptr_t>(argmax) & 7) == 0,
+                "maxpool_bwd_idx_bf16s: channels and pixel strides in whole 16-byte pieces");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / 8);
+  clear_stale_error();
+  hipLaunchKernelGGL(maxpool_bwd_idx_bf16s_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     argmax, static_cast<const __bf16*>(y), static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), n, h, w, c,
+                     h / 2, w / 2, ldy, lddy, relu_mask);
+  return check_launch("maxpool_bwd_idx_bf16s");
 }
 
 int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, const float* y, int ldy, const float* dy,

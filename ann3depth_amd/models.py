@@ -188,6 +188,8 @@ class MSDNReplica:
         # conv + ReLU + max pool in one kernel inside step(): the pre-pool activations c0, c1, f1 are never written
         # (the network being trained keeps one byte per pool window instead, see forward())
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
+        # bf16 storage: conv2d_1's pool in the LDS-DMA kernel's epilogue (argmax bytes + a bf16 MaxPoolGrad by index)
+        self.pool1_fused = self.bf16s and os.environ.get('A3D_BF16S_POOL1', '1') != '0'
         self.side = None
         if self.overlap and dev.type == 'cuda':
             # below the main stream's queue priority: a CU slot that frees up goes to the HBM-bound kernel first
@@ -603,7 +605,7 @@ class MSDNReplica:
         src = {'c0': (self.c0, self.p0, self.a0, 1), 'c1': (self.c1, self.p1, self.a1, 1),
                'f1': (self.f1, self.cat, self.af1, 2)}[which]
         full, pooled, arg, phase = src
-        if self.pooled_fwd != phase and not (self.bf16s and which == 'f1'):
+        if self.pooled_fwd != phase and not (self.bf16s and which == 'f1') and not (self.pool1_fused and which == 'c1'):
             return full
         if full is None:          # 'bf16s': the tensor does not exist at all
             full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'f1': (110, 148, 63)}[which], device=self.device)
@@ -618,8 +620,7 @@ class MSDNReplica:
         return out
 
     def _conv_pool(self, name, x, y_pooled, argmax=None):
-        w, b = self._kb(name)
-        ops.conv2d_pool_fwd(self._desc(name, 'fwd'), x, w, b, y_pooled, 'relu', argmax)
+        ops.conv2d_pool_fwd(self._desc(name, 'fwd'), x, self._w(name), self._v(name + '/bias'), y_pooled, 'relu', argmax)
 
     def forward(self, images, depths, keep_mask, join=True, phase=None):
         """join=False leaves the fine network's forward in flight on the side stream (step() joins later).
@@ -648,8 +649,11 @@ class MSDNReplica:
         elif self.bf16s:
             self._conv('coarse/conv/conv2d_0', self.x, self.c0)
             self._pool(self.c0, self.p0)
-            self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
-            self._pool(self.c1, self.p1)
+            if self.pool1_fused:        # conv + ReLU + pool in the LDS-DMA kernel's epilogue: c1 (33 MB at B = 64) is never written
+                self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1)
+            else:
+                self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
+                self._pool(self.c1, self.p1)
         else:
             self._conv('coarse/conv/conv2d_0', self.x, self.c0)
             self._pool(self.c0, self.p0)
@@ -757,7 +761,7 @@ class MSDNReplica:
         if after_conv2 is not None:
             after_conv2()          # gradients of conv2d_2..4 (the tail of the CoarseConv buffer) are complete
         self._bwd_data(n, self.dc2, self.dp1)
-        if self.pooled_fwd == 1:
+        if self.pooled_fwd == 1 or self.pool1_fused:
             ops.maxpool2x2_bwd_idx(self.a1, self.p1, self.dp1, self.dc1, relu_mask=True)
         else:
             self._pool_bwd(self.c1, self.dp1, self.dc1)

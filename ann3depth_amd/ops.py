@@ -109,6 +109,12 @@ def maxpool2x2_bwd_idx(argmax, y_pooled, dy, dx, relu_mask=True):
     """MaxPoolGrad (+ ReluGrad) from the argmax positions and pooled values of conv2d_pool_fwd; dx [n,h,w,c] dense,
     y_pooled / dy: last dim = pixel stride (>= c)."""
     n, h, w, c = dx.shape
+    if y_pooled.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16:      # bf16 storage throughout (conv2d_1 of config 5)
+        assert dy.dtype == torch.bfloat16
+        check(_lib.load().a3d_maxpool2x2_bwd_idx_bf16s(n, h, w, c, _ptr(argmax), _ptr(y_pooled), y_pooled.shape[-1], _ptr(dy),
+                                                       dy.shape[-1], _ptr(dx), int(relu_mask), _stream()),
+              'a3d_maxpool2x2_bwd_idx_bf16s')
+        return dx
     if y_pooled.dtype == torch.bfloat16:         # bf16 storage: pooled values and dy bf16, dx float32
         assert dy.dtype == torch.bfloat16 and dx.dtype == torch.float32
         check(_lib.load().a3d_maxpool2x2_bwd_idx_bf16(n, h, w, c, _ptr(argmax), _ptr(y_pooled), y_pooled.shape[-1], _ptr(dy),

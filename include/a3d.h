@@ -223,6 +223,10 @@ int a3d_maxpool2x2_bwd_bf16(int n, int h, int w, int c, const void* x, int ldx, 
 int a3d_copy_channel_bf16(size_t npix, const float* src, int ld_src, int c_src, void* dst, int ld_dst, int c_dst, void* stream);
 int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,
                                 int lddy, float* dx, int relu_mask, void* stream);
+/* ... and to a bf16 dx (dense [n,h,w,c]): the backward of a3d_conv2d_pool_fwd on bf16 x, w and y (config 5's conv2d_1:
+ * src/models.py:214-215), c, ldy, lddy multiples of 8 and 16-byte aligned tensors. */
+int a3d_maxpool2x2_bwd_idx_bf16s(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,
+                                 int lddy, void* dx, int relu_mask, void* stream);
 
 /* dense_bwd_filter and ApplyAdam of one dense layer in ONE pass, for the optimizer the reference actually builds:
  * AdamOptimizer(rate, 0.9, beta2 = 1) (src/models.py:309) has alpha = 0 and 1 - beta2 = 0, so ApplyAdam moves only the

@@ -859,6 +859,54 @@ def test_lds_dma_kernel_on_bf16_stored_operands(ops, n, h, w, c, k, ks, st, pad,
     assert rel_l2(db.cpu().numpy(), bref) < 1e-5
 
 
+@pytest.mark.parametrize('n,h,w,c,k,ks,pad,same_kernel', [
+    (26, 27, 37, 96, 256, 5, 'SAME', True),     # conv2d_1: odd height and width (the last row / column has no window), 256 x 256 tiles
+    (122, 14, 18, 64, 128, 3, 'SAME', True),    # 128 x 128 tiles, M = 122 * 7 * 9 * 4 rows: a tail tile
+    (100, 21, 30, 32, 64, 3, 'VALID', True),    # 64 columns: 256 x 64 tiles
+    (9, 21, 30, 32, 64, 3, 'VALID', False),     # few tiles: the unpooled conv is igemm_bf16's (another summation order), the
+                                                # pooled one has no other kernel than this one
+])
+def test_lds_dma_kernel_with_the_max_pool_in_its_epilogue(ops, n, h, w, c, k, ks, pad, same_kernel):
+    """Config 5's conv2d_1 (src/models.py:214-215): conv + ReLU + 2x2 max pool of bf16 x, w into a bf16 pooled map and argmax
+    bytes in ONE launch of the LDS-DMA kernel (a3d_conv2d_pool_fwd with all three storage bits).  The pooled values are bit
+    for bit those of the two launches (conv to a bf16 tensor, a3d_maxpool2x2_fwd_bf16); the argmax bytes name a position
+    that holds the window's maximum — the first one in scan order; and a3d_maxpool2x2_bwd_idx_bf16s routes a bf16 gradient
+    exactly as a3d_maxpool2x2_bwd_bf16 does from the unpooled activations."""
+    rng = np.random.default_rng(k + ks + n)
+    bf = torch.bfloat16
+    x = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).cuda().to(bf)
+    wt = torch.from_numpy((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)).cuda().to(bf)
+    b = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+    X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+    d = ops.with_storage(ops.conv_desc(n, h, w, c, k, ks, ks, 1, pad, precision='bf16'), X | W | Y)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda', dtype=bf)
+    ops.conv2d_fwd(d, x, wt, b, y, 'relu')
+    ph, pw = d.ho // 2, d.wo // 2
+    two = torch.empty((n, ph, pw, k), device='cuda', dtype=bf)
+    ops.maxpool2x2_fwd_bf16(y, two)
+    one = torch.full((n, ph, pw, k), float('nan'), device='cuda', dtype=bf)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x, wt, b, one, 'relu', arg)
+    assert int(arg.max()) <= 3
+    if not same_kernel:        # values within a bf16 rounding step of the two launches; routing checked on the kernel's own values below
+        assert rel_l2(one.float().cpu().numpy(), two.float().cpu().numpy()) < 4e-3
+        assert (one.view(torch.int16) != two.view(torch.int16)).float().mean() < 1e-3
+        return
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    yw = y[:, :2 * ph, :2 * pw, :].reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4).float()
+    vmax = yw.max(dim=-1, keepdim=True).values
+    first = (yw == vmax).float().argmax(dim=-1)                # the first maximal position, as MaxPoolGrad scans a window
+    assert torch.equal(arg.long(), first)
+    ops.conv2d_pool_fwd(d, x, wt, b, one.fill_(float('nan')), 'relu', None)          # without argmax: the same map
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    dy = torch.from_numpy(rng.standard_normal((n, ph, pw, k)).astype(np.float32)).cuda().to(bf)
+    dx_ref = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=bf)
+    ops.maxpool2x2_bwd_bf16(y, dy, dx_ref, relu_mask=True)
+    dx = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=bf)
+    ops.maxpool2x2_bwd_idx(arg, one, dy, dx, relu_mask=True)
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16))
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
