@@ -67,6 +67,7 @@ SIGNATURES = {
     'a3d_dense_fwd_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     'a3d_dense_bwd_data_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P]),
     'a3d_cast_bf16': (c_int, [c_size_t, _P, _P, c_int, _P]),
+    'a3d_cast_rows': (c_int, [c_size_t, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
     'a3d_pad_channels_bf16': (c_int, [c_size_t, c_int, _P, c_int, _P, _P]),
     'a3d_stream_create': (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p)]),
     'a3d_stream_destroy': (c_int, [_P]),

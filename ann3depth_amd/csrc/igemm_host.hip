@@ -1360,7 +1360,7 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
                      dz, w, dx, k, k);
   if (rc != A3D_OK) return rc;
   g.ring_ok = p.a16 && p.b16 && precision == A3D_PREC_BF16 && k % 8 == 0 && n % 8 == 0 && aligned16(dx) &&
-              (!mask || (aligned16(mask) && mask_act == A3D_ACT_RELU && scale == 1.f));
+              (!mask || (aligned16(mask) && mask_act == A3D_ACT_RELU));
   GemmPlan plan = plan_gemm(g, precision);
   A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_bwd_data: bf16 weights need vectorisable operands");
   A3D_CHECK_ARG(!(p.a16 || p.c16) || plan.ring, "dense_bwd_data: bf16 dz / dx are taken by the LDS-DMA kernel only (bf16 weights, k and n multiples of 8, ReLU mask)");

@@ -673,6 +673,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       for (int v = 0; v < 16; ++v) {
         if constexpr (M16) val[v] = acc16[2 * a + (v >> 3)][2 * b + ((v >> 2) & 1)][v & 3];
         else val[v] = acc[a][b][v];
+        if (MODE == MODE_BWD_D && !partial && p.mask) val[v] *= p.mask_scale;       // (dropout's gradient factor; the mask itself: 16-byte phase)
         if (MODE == MODE_FWD && !partial) {
           val[v] += bias[M16 ? (v >> 2) & 1 : 0];
           if (p.act == EPI_RELU) val[v] = fmaxf(val[v], 0.f);

@@ -599,6 +599,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_bf16_kernel(const uint8_t
     }
   }
 }
+// dst[r][c] = src[r][c] for c < cols (float32 or bf16 on either side, round to nearest even), dst[r][c] = 0 for
+// cols <= c < ld_dst: row pitches change (a padded bf16 copy of a matrix whose rows are not whole 16-byte pieces, and back)
+template <bool S16, bool D16>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const void* __restrict__ src, void* __restrict__ dst, size_t rows, int cols,
+                                                        int ld_src, int ld_dst) {
+  const size_t total = rows * (size_t)ld_dst;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / (size_t)ld_dst;
+    const int c = (int)(i - r * (size_t)ld_dst);
+    float v = 0.f;
+    if (c < cols) v = S16 ? (float)static_cast<const __bf16*>(src)[r * ld_src + c] : static_cast<const float*>(src)[r * ld_src + c];
+    if (D16) static_cast<__bf16*>(dst)[i] = (__bf16)v;
+    else static_cast<float*>(dst)[i] = v;
+  }
+}
 // The same with a bf16 dx (config 5: the conv stack's activation gradients are bf16 tensors), eight channels per thread:
 // 8 argmax bytes, 16 bytes of pooled values and of dy in, four 16-byte pieces of dx out.
 __global__ __launch_bounds__(256) void maxpool_bwd_idx_bf16s_kernel(const uint8_t* __restrict__ argmax,
@@ -867,6 +882,20 @@ int a3d_maxpool2x2_bwd_idx_bf16(int n, int h, int w, int c, const uint8_t* argma
                      argmax, static_cast<const __bf16*>(y), static_cast<const __bf16*>(dy), dx, n, h, w, c, h / 2, w / 2, ldy,
                      lddy, relu_mask);
   return check_launch("maxpool_bwd_idx_bf16");
+}
+
+int a3d_cast_rows(size_t rows, int cols, const void* src, int ld_src, int src_bf16, void* dst, int ld_dst, int dst_bf16,
+                  void* stream) {
+  A3D_CHECK_ARG(rows > 0 && cols > 0 && src && dst && ld_src >= cols && ld_dst >= cols, "cast_rows: bad arguments");
+  const size_t total = rows * (size_t)ld_dst;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  clear_stale_error();
+  const dim3 grid(grid_for(total)), block(256);
+  if (src_bf16 && dst_bf16) hipLaunchKernelGGL((cast_rows_kernel<true, true>), grid, block, 0, st, src, dst, rows, cols, ld_src, ld_dst);
+  else if (src_bf16) hipLaunchKernelGGL((cast_rows_kernel<true, false>), grid, block, 0, st, src, dst, rows, cols, ld_src, ld_dst);
+  else if (dst_bf16) hipLaunchKernelGGL((cast_rows_kernel<false, true>), grid, block, 0, st, src, dst, rows, cols, ld_src, ld_dst);
+  else hipLaunchKernelGGL((cast_rows_kernel<false, false>), grid, block, 0, st, src, dst, rows, cols, ld_src, ld_dst);
+  return check_launch("cast_rows");
 }
 
 int a3d_maxpool2x2_bwd_idx_bf16s(int n, int h, int w, int c, const uint8_t* argmax, const void* y, int ldy, const void* dy,

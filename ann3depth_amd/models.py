@@ -257,6 +257,16 @@ class MSDNReplica:
         if self.bf16s:
             self.c4_32 = buf(B, 6, 8, 256)                                          # the fp32 copy of c4 dense_0's filter gradient reads
             self.dz0_16 = torch.empty((B, 4096), device=dev, dtype=torch.bfloat16)  # dense_0's bwd-data takes dz0 as bf16
+            # dense_1 ([4096, 4070]: rows of 8140 bytes, not whole 16-byte pieces) on the LDS-DMA kernel too: a bf16 copy of
+            # its kernel with rows of 4072 elements (the two pad columns zero, the bias padded alike); x (= drop), dz and y cross
+            # to that layout and back by a3d_cast_rows (0.5 - 1 MB each).  Its master weights, gradient and ApplyAdam stay fp32.
+            self.dense1_bf16 = os.environ.get('A3D_BF16S_DENSE1', '1') != '0'
+            NP = (OUT_H * OUT_W + 7) // 8 * 8
+            self.w1pad = torch.zeros((4096, NP), device=dev, dtype=torch.bfloat16)
+            self.b1pad = torch.zeros((1, NP), device=dev)
+            self.drop16 = torch.empty((B, 4096), device=dev, dtype=torch.bfloat16)
+            self.y1pad = torch.empty((B, NP), device=dev)
+            self.dz1_16 = torch.empty((B, NP), device=dev, dtype=torch.bfloat16)
         # descriptors
         def D(*a):
             return ops.conv_desc(*a, precision=precision)
@@ -339,6 +349,9 @@ class MSDNReplica:
             ops.cast_bf16(self._v(n + '/kernel'), c)
         if self.bf16s:
             self.w4[:, :, :3, :] = self._v('fine/first/conv2d/kernel')
+            n = 'coarse/dense/dense_1'
+            ops.cast_rows(self._v(n + '/kernel'), self.w1pad)
+            ops.cast_rows(self._v(n + '/bias').view(1, -1), self.b1pad)
 
     def _weights_moved(self, *groups):
         """After an ApplyAdam that can change `var` (any optimizer but the reference's frozen beta2 = 1 one): the bf16
@@ -680,7 +693,13 @@ class MSDNReplica:
         else:
             ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
-        ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
+        if self.bf16s and self.dense1_bf16:
+            ops.cast_bf16(self.drop, self.drop16)
+            ops.dense_fwd_ex(self.drop16, self.w1pad, self.b1pad, self.y1pad, None, precision='bf16',
+                             storage=ops.STORE_W | ops.STORE_X)
+            ops.cast_rows(self.y1pad, self.coarse.view(B, -1))
+        else:
+            ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
         with self._beside():
             if lean_fine or self.bf16s:
                 ops.copy_channel(self.coarse, 0, self.cat, 63)                                # tf.concat([pool, coarse])
@@ -728,7 +747,12 @@ class MSDNReplica:
             after_dense1()         # dense_1's gradient (67 MB) is complete: first piece of the dense bucket
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
         # (train=False, src/models.py:230: tf.layers.dropout is the identity; only the ReluGrad remains)
-        ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
+        if self.bf16s and self.dense1_bf16:
+            ops.cast_rows(self.dz1, self.dz1_16)
+            ops.dense_bwd_data_ex(self.dz1_16, self.w1pad, self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0,
+                                  precision='bf16', storage=ops.STORE_W | ops.STORE_Y)
+        else:
+            ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
         n = 'coarse/dense/dense_0'
         if self.bf16s:              # the filter gradient takes c4 on the dense layers' fp32 side
             ops.cast_bf16(self.c4, self.c4_32)

@@ -326,6 +326,17 @@ def pad_channels_bf16(src, dst):
     return dst
 
 
+def cast_rows(src, dst, cols=None):
+    """dst[r, :cols] = src[r, :cols] (float32 / bfloat16 on either side), dst[r, cols:] = 0: 2-D tensors whose last
+    dimensions are their row pitches."""
+    rows = src.shape[0]
+    cols = cols if cols is not None else min(src.shape[1], dst.shape[1])
+    assert dst.shape[0] == rows and src.dim() == dst.dim() == 2 and src.is_contiguous() and dst.is_contiguous()
+    check(_lib.load().a3d_cast_rows(rows, cols, _ptr(src), src.shape[1], int(src.dtype == torch.bfloat16), _ptr(dst),
+                                    dst.shape[1], int(dst.dtype == torch.bfloat16), _stream()), 'a3d_cast_rows')
+    return dst
+
+
 def cast_bf16(src, dst):
     """float32 -> bfloat16 or back, by dst's dtype (round to nearest even)."""
     assert src.numel() == dst.numel() and {src.dtype, dst.dtype} == {torch.float32, torch.bfloat16}

@@ -203,6 +203,11 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
 /* float32 <-> bf16 (round to nearest even) of `count` elements: weight copies after ApplyAdam, and the two small tensors
  * that cross between the bf16 conv stack and the float32 dense layers (to_bf16 != 0: src float32 -> dst bf16). */
 int a3d_cast_bf16(size_t count, const void* src, void* dst, int to_bf16, void* stream);
+/* The same between matrices of different row pitches: dst[r][c] = src[r][c] for c < cols, zero for cols <= c < ld_dst
+ * (src_bf16 / dst_bf16: the element types).  The bf16 copy of tf.layers.dense's [4096, 4070] kernel (src/models.py:231)
+ * is kept with rows of 4072 elements — whole 16-byte pieces — and the layer's x, dz and y cross to it and back. */
+int a3d_cast_rows(size_t rows, int cols, const void* src, int ld_src, int src_bf16, void* dst, int ld_dst, int dst_bf16,
+                  void* stream);
 
 /* float32 [pixels][c_src] -> bf16 [pixels][4] with the missing channels zero (c_src <= 4): the network image as 8-byte
  * pixels.  a3d_conv2d_fwd with A3D_STORE_X_BF16, c = ldx = 4, no padding, an even stride and precision A3D_PREC_BF16

@@ -503,12 +503,18 @@ def test_bf16_storage_weight_copies_follow_the_masters(models, global_step):
         assert torch.equal(c, master.to(torch.bfloat16)), n                 # round-to-nearest-even, like a3d_cast_bf16
     assert moved >= (4 if global_step == 0 else 1)
     assert torch.equal(net.w4[:, :, :3, :], net.var('fine/first/conv2d/kernel')) and not net.w4[:, :, 3, :].any()
+    # dense_1's copy has rows of 4072 elements (whole 16-byte pieces): 4070 rounded weights and two zeros; its bias alike
+    k1, b1 = net.var('coarse/dense/dense_1/kernel'), net.var('coarse/dense/dense_1/bias')
+    assert net.w1pad.shape == (4096, 4072) and torch.equal(net.w1pad[:, :4070], k1.to(torch.bfloat16)) and not net.w1pad[:, 4070:].any()
+    assert torch.equal(net.b1pad[0, :4070], b1) and not net.b1pad[0, 4070:].any()
+    if global_step == 0:
+        assert not torch.equal(k1.cpu(), torch.from_numpy(params['coarse/dense/dense_1/kernel']))      # it did move
     # restore into a replica that was initialised with OTHER weights: copies follow, and the next step is the same step
     other = models.MSDNReplica(B, seed=1, beta2=0.999, precision='bf16s')
     other.load_state_dict(net.state_dict())
     for n, c in other.wcopy.items():
         assert torch.equal(c, net.wcopy[n]), n
-    assert torch.equal(other.w4, net.w4)
+    assert torch.equal(other.w4, net.w4) and torch.equal(other.w1pad, net.w1pad) and torch.equal(other.b1pad, net.b1pad)
     img, dep, keep = synth(B, 77, 96, 128)
     args = (torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda(), torch.from_numpy(keep).cuda())
     net.step(*args)

@@ -907,6 +907,24 @@ def test_lds_dma_kernel_with_the_max_pool_in_its_epilogue(ops, n, h, w, c, k, ks
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16))
 
 
+def test_cast_rows_between_row_pitches(ops):
+    """a3d_cast_rows: float32 / bf16 either way, the first `cols` columns of every row, pad columns of the destination zero."""
+    rng = np.random.default_rng(3)
+    a = torch.from_numpy(rng.standard_normal((37, 4070)).astype(np.float32)).cuda()
+    p = torch.full((37, 4072), float('nan'), device='cuda', dtype=torch.bfloat16)
+    ops.cast_rows(a, p)
+    assert torch.equal(p[:, :4070], a.to(torch.bfloat16)) and not p[:, 4070:].any()
+    back = torch.full((37, 4070), float('nan'), device='cuda')
+    ops.cast_rows(p, back)
+    assert torch.equal(back, a.to(torch.bfloat16).float())
+    f = torch.full((37, 4072), float('nan'), device='cuda')
+    ops.cast_rows(a, f)
+    assert torch.equal(f[:, :4070], a) and not f[:, 4070:].any()
+    q = torch.full((37, 100), float('nan'), device='cuda', dtype=torch.bfloat16)
+    ops.cast_rows(p, q, cols=90)
+    assert torch.equal(q[:, :90], p[:, :90]) and not q[:, 90:].any()
+
+
 def test_timing_brackets_every_launch_or_one_kernel(ops):
     """a3d_timing_enable / a3d_timing_select (include/a3d.h): bench.py learns the dominant kernel with every launch
     bracketed, then brackets only that kernel inside its timed region."""
