@@ -672,18 +672,32 @@ class MSDNReplica:
             self._pool(self.c0, self.p0)
             self._conv('coarse/conv/conv2d_1', self.p0, self.c1)
             self._pool(self.c1, self.p1)
+        def fine_first():
+            with self._beside():    # beside the two weight-streaming dense layers
+                if lean_fine:
+                    self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
+                elif self.bf16s and phase in (1, 3):        # conv + ReLU + pool in one launch: f1 is never written
+                    ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu')
+                elif self.bf16s:
+                    self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
+                else:
+                    self._conv('fine/first/conv2d', self.x, self.f1)
+        # where the side stream starts: ahead of conv2d_4's forward.  The fine forward is the longer chain of the stretch
+        # (bf16 storage: fine/first runs 0.27 ms beside the dense layers; started after conv2d_4 it left the main queue
+        # waiting 41 us at the join: 1.43 -> 1.39 ms; fp32: 26 us at the join, 2.93 -> 2.91 ms).  One layer earlier still is
+        # slower again (1.41 / 2.94 ms), two layers 1.44: MFMA-bound grids beside each other only trade CU slots.
+        early = int(os.environ.get('A3D_SIDE_EARLY', '1'))
+        if early == 3:
+            fine_first()
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
+        if early == 2:
+            fine_first()
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
+        if early == 1:
+            fine_first()
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
-        with self._beside():        # beside the two weight-streaming dense layers
-            if lean_fine:
-                self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
-            elif self.bf16s and phase in (1, 3):        # conv + ReLU + pool in one launch: f1 is never written
-                ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu')
-            elif self.bf16s:
-                self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
-            else:
-                self._conv('fine/first/conv2d', self.x, self.f1)
+        if early == 0:
+            fine_first()
         if not self._sharded_in_flight():
             self.settle()           # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
