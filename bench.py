@@ -213,13 +213,15 @@ def hbm_bytes_bf16_storage(B):
         + 3 * px(228, 304, 3, f4) + 3 * px(55, 74, 1, f4)          # x: written, read by conv2d_0 fwd, fine/first fwd (+ conv2d_0 bwd-filter: below); t: written, read by both losses
         + px(228, 304, 3, f4)                                      # x again: conv2d_0 bwd-filter
         + 2 * px(228, 304, 4, b2)                                  # fine/first on the bf16 pipe: x4 written + read (conv + pool fused: f1 never reaches HBM)
-        # forward activations, written once and read once by the next layer (bf16): p0, c1, p1, c2, c3, c4, cat; f2 fp32
-        + 2 * (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
-               + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4)
+        # forward activations, written once and read once by the next layer (bf16): p0, p1, c2, c3, c4, cat; f2 fp32.  c1 never
+        # reaches HBM since round 4 (conv2d_1's pool is in its kernel's epilogue): one argmax byte per pool window instead
+        + 2 * (px(27, 37, 96, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
+               + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4) + px(13, 18, 256, 1)
         + 2 * px(55, 74, 96, b2)                                   # c0 (bf16): written by conv2d_0, read by its pool
         # backward of coarse/*: each stored activation read again (bwd-filter A operand / ReLU mask), each activation
         # gradient written once and read by bwd-filter and bwd-data of the layer below (2 reads)
-        + (px(27, 37, 96, b2) + px(27, 37, 256, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
+        # (conv2d_1's pool gradient reads the argmax bytes and p1 instead of c1)
+        + (px(27, 37, 96, b2) + px(13, 18, 256, 1) + 2 * px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
         + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
         + px(55, 74, 96, b2) + 2 * px(55, 74, 96, b2)              # c0 read by the pool gradient; dc0 (bf16) written + read
         + 6 * 4096 * f4 + 6 * 4070 * f4                            # dense side tensors (drop, coarse, dz0, dz1, ...)
@@ -230,7 +232,7 @@ def hbm_bytes_bf16_storage(B):
     per_step = (
         2 * (conv_w - 34944) * b2 + 2 * 34944 * f4                 # conv kernels: bf16 copies in fwd and bwd-data (conv2d_0: fp32)
         + fine_w * f4                                              # fine network forward
-        + 2 * d0 * b2 + 2 * d1 * f4                                # dense_0 bf16 copy / dense_1 fp32, fwd and bwd-data
+        + 2 * d0 * b2 + 2 * d1 * b2                                # the dense layers' bf16 copies, fwd and bwd-data (dense_1: round 4)
         + conv_w * f4 * (1 + 3)                                    # conv dW written; ApplyAdam: g, m read, m written
         + (d0 + d1) * f4 * 2                                       # dense dW -> m slot in place: m read, m written
     )
