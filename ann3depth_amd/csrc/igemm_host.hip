@@ -908,7 +908,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   if (pool) {
     const int all16 = A3D_STORE_X_BF16 | A3D_STORE_W_BF16 | A3D_STORE_Y_BF16;
     A3D_CHECK_ARG(d->precision == A3D_PREC_F32 || bf16_image_form_ok(d, x) ||
-                      (d->precision == A3D_PREC_BF16 && (d->storage & all16) == all16),
+                      (d->precision == A3D_PREC_BF16 && ((d->storage & all16) == all16 || d->storage == A3D_STORE_Y_BF16)),
                   "conv2d_pool_fwd: fp32, the bf16 image form (4-channel bf16 image, a3d_pad_channels_bf16), or bf16 arithmetic on "
                   "bf16 x, w and y (LDS-DMA kernel)");
     A3D_CHECK_ARG(d->ho >= 2 && d->wo >= 2 && ld_out >= d->k, "conv2d_pool_fwd: output smaller than one pool window");

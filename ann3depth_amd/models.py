@@ -190,6 +190,7 @@ class MSDNReplica:
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
         # bf16 storage: conv2d_1's pool in the LDS-DMA kernel's epilogue (argmax bytes + a bf16 MaxPoolGrad by index)
         self.pool1_fused = self.bf16s and os.environ.get('A3D_BF16S_POOL1', '1') != '0'
+        self.pool0_fused = self.bf16s and os.environ.get('A3D_BF16S_POOL0', '1') != '0'
         self.side = None
         if self.overlap and dev.type == 'cuda':
             # below the main stream's queue priority: a CU slot that frees up goes to the HBM-bound kernel first
@@ -618,7 +619,7 @@ class MSDNReplica:
         src = {'c0': (self.c0, self.p0, self.a0, 1), 'c1': (self.c1, self.p1, self.a1, 1),
                'f1': (self.f1, self.cat, self.af1, 2)}[which]
         full, pooled, arg, phase = src
-        if self.pooled_fwd != phase and not (self.bf16s and which == 'f1') and not (self.pool1_fused and which == 'c1'):
+        if self.pooled_fwd != phase and not (self.bf16s and which == 'f1') and not (self.pool1_fused and which == 'c1') and not (self.pool0_fused and which == 'c0'):
             return full
         if full is None:          # 'bf16s': the tensor does not exist at all
             full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'f1': (110, 148, 63)}[which], device=self.device)
@@ -660,8 +661,11 @@ class MSDNReplica:
             self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0 if train else None)
             self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1 if train else None)
         elif self.bf16s:
-            self._conv('coarse/conv/conv2d_0', self.x, self.c0)
-            self._pool(self.c0, self.p0)
+            if self.pool0_fused:
+                self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0)
+            else:
+                self._conv('coarse/conv/conv2d_0', self.x, self.c0)
+                self._pool(self.c0, self.p0)
             if self.pool1_fused:        # conv + ReLU + pool in the LDS-DMA kernel's epilogue: c1 (33 MB at B = 64) is never written
                 self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1)
             else:
@@ -806,7 +810,7 @@ class MSDNReplica:
         n = 'coarse/conv/conv2d_1'
         dw(n, self.p0, self.dc1)
         self._bwd_data(n, self.dc1, self.dp0)
-        if self.pooled_fwd == 1:
+        if self.pooled_fwd == 1 or self.pool0_fused:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:
             self._pool_bwd(self.c0, self.dp0, self.dc0)

@@ -217,13 +217,13 @@ def hbm_bytes_bf16_storage(B):
         # reaches HBM since round 4 (conv2d_1's pool is in its kernel's epilogue): one argmax byte per pool window instead
         + 2 * (px(27, 37, 96, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
                + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4) + px(13, 18, 256, 1)
-        + 2 * px(55, 74, 96, b2)                                   # c0 (bf16): written by conv2d_0, read by its pool
+        + px(27, 37, 96, 1)                                        # conv2d_0's pool is in its kernel's epilogue too: argmax bytes, no c0
         # backward of coarse/*: each stored activation read again (bwd-filter A operand / ReLU mask), each activation
         # gradient written once and read by bwd-filter and bwd-data of the layer below (2 reads)
         # (conv2d_1's pool gradient reads the argmax bytes and p1 instead of c1)
         + (px(27, 37, 96, b2) + px(13, 18, 256, 1) + 2 * px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
         + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
-        + px(55, 74, 96, b2) + 2 * px(55, 74, 96, b2)              # c0 read by the pool gradient; dc0 (bf16) written + read
+        + px(27, 37, 96, 1) + px(27, 37, 96, b2) + 2 * px(55, 74, 96, b2)   # argmax bytes and p0 read by the pool gradient; dc0 (bf16) written + read
         + 6 * 4096 * f4 + 6 * 4070 * f4                            # dense side tensors (drop, coarse, dz0, dz1, ...)
     )
     conv_w = 34944 + 614656 + 885120 + 1327488 + 884992            # coarse/conv parameters
