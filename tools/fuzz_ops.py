@@ -153,6 +153,49 @@ def run_conv_pool(n, h, w, c, k, ks, st, pad):
     return max(float((pooled.double() - want).norm()), float((at_arg - want).norm())) / scale
 
 
+def run_conv_pool_bf16s(n, h, w, c, k, ks, st, pad):
+    """bf16 storage with the pool fused (config 5's conv2d_1: x, w, pooled y bf16, the LDS-DMA kernel): the pooled map against
+    torch float64 on the rounded operands to bf16 rounding; the recorded position must hold a value within that rounding of
+    the window's maximum; and the by-index MaxPoolGrad to a bf16 gradient must put exactly dy (or 0 under the ReLU mask) at
+    that position and zeros elsewhere.  stride 1 only, k a multiple of 16 (whole 16-byte pieces of argmax bytes)."""
+    bf = torch.bfloat16
+    k = max(16, k // 16 * 16)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, 1, pad, precision='bf16')
+    if d.ho < 2 or d.wo < 2:
+        return 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, h, w, c), device='cuda', generator=g).to(bf)
+    wt = (torch.randn((ks, ks, c, k), device='cuda', generator=g) / np.sqrt(ks * ks * c)).to(bf)
+    b = torch.randn((k,), device='cuda', generator=g) * 0.1
+    X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+    ph, pw = d.ho // 2, d.wo // 2
+    pooled = torch.full((n, ph, pw, k), float('nan'), device='cuda', dtype=bf)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(ops.with_storage(d, X | W | Y), x, wt, b, pooled, 'relu', arg)
+    if int(arg.max()) > 3 or not bool(torch.isfinite(pooled.float()).all()):
+        return 1.0
+    pt = max((d.ho - 1) + ks - h, 0) if pad == 'SAME' else 0
+    pl = max((d.wo - 1) + ks - w, 0) if pad == 'SAME' else 0
+    ref = F.conv2d(F.pad(x.double().permute(0, 3, 1, 2), (pl // 2, pl - pl // 2, pt // 2, pt - pt // 2)),
+                   wt.double().permute(3, 2, 0, 1).contiguous(), b.double(), stride=1).clamp_min(0).permute(0, 2, 3, 1)
+    win = ref[:, :2 * ph, :2 * pw].reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4)
+    want = win.max(-1).values
+    at_arg = win.gather(-1, arg.long().unsqueeze(-1)).squeeze(-1)
+    scale = max(float(want.norm()), 1e-30)
+    err = max(float((pooled.double() - want).norm()), float((at_arg - want).norm())) / scale
+    dy = torch.randn((n, ph, pw, k), device='cuda', generator=g).to(bf)
+    dx = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=bf)
+    ops.maxpool2x2_bwd_idx(arg, pooled, dy, dx, relu_mask=True)
+    routed = torch.where(pooled.float() > 0, dy.float(), torch.zeros_like(dy.float()))
+    exp = torch.zeros((n, ph, pw, k, 4), device='cuda')
+    exp.scatter_(-1, arg.long().unsqueeze(-1), routed.unsqueeze(-1))
+    full = torch.zeros((n, d.ho, d.wo, k), device='cuda')
+    full[:, :2 * ph, :2 * pw] = exp.reshape(n, ph, pw, k, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2 * ph, 2 * pw, k)
+    if not torch.equal(dx.float(), full):
+        return 1.0
+    return err
+
+
 def run_dense_adam():
     """a3d_dense_bwd_filter_adam_tf1 (the gradient never written; the reference's frozen optimizer) against
     a3d_dense_bwd_filter + a3d_adam_apply_tf1 over two steps: m, v, var bit for bit (same MFMA sum order, the same
@@ -254,7 +297,14 @@ while time.time() < t_end:
         e16, e32 = run_conv_bf16s(*case)
         err = max(e16 * TOL / TOL_BF16_OUT, e32 * TOL / TOL_BF16_DW)      # each judged against its own tolerance
         case = ('conv bf16s',) + case
-    elif u < 0.55:
+    elif u < 0.50:
+        for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK', 'A3D_FORCE_SK_SLICED'):
+            os.environ.pop(v, None)
+        forced = 'auto'
+        case = conv_case_bf16s()
+        err = run_conv_pool_bf16s(*case) * TOL / TOL_BF16_OUT
+        case = ('conv+pool bf16s',) + case
+    elif u < 0.58:
         os.environ.pop('A3D_FORCE_STREAMK', None)          # the fused pool takes whole K ranges only
         os.environ.pop('A3D_FORCE_SPLITK', None)
         case = conv_case()
