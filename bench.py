@@ -160,14 +160,14 @@ def roofline_from(recs, with_traffic=True):
             'calls': g['calls'], 'avg_launch_us': round(1e3 * g['ms'] / g['calls'], 2),
             'flops_per_launch': g['flops'] / g['calls']}
     if roof['traffic'] is not None:
-        # what the counters can and cannot say (profiles/r03_ic_evidence.txt): FETCH_SIZE / WRITE_SIZE count the L2s' fabric
+        # what the counters can and cannot say (profiles/r04_ic_evidence.txt): FETCH_SIZE / WRITE_SIZE count the L2s' fabric
         # requests, Infinity-Cache hits included, and gfx950 has no counter that separates those from HBM reads
         # (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on every launch)
         roof['traffic_fabric'] = roof['traffic']
         roof['traffic_hbm'] = None
         roof['traffic_source'] = pmc_traffic(name)[1]      # NOT measured by this run: the committed counter passes of this command
         roof['traffic_note'] = ('fabric-side bytes per launch from the committed PMC passes of this command (profiles/*_pmc_traffic.json), '
-                                'Infinity-Cache hits included; no gfx950 counter isolates HBM: see profiles/r03_ic_evidence.txt')
+                                'Infinity-Cache hits included; no gfx950 counter isolates HBM: see profiles/r04_ic_evidence.txt')
     return roof, table
 
 
