@@ -105,10 +105,12 @@ int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const
  * y_pooled[n, ho/2, wo/2, k] (pixel stride ld_pooled >= k) = 2x2 / stride-2 VALID max pool of act(conv + bias); the conv
  * output itself is never written.  argmax (may be NULL): [n, ho/2, wo/2, k] bytes, the position 0..3 (row-major in the
  * window) of the first maximum — all that MaxPoolGrad + ReluGrad need besides the pooled value, so training does not
- * need the conv output either (a3d_maxpool2x2_bwd_idx).  fp32 arithmetic and inputs (storage A3D_STORE_Y_BF16: the
- * pooled output is bf16), or the bf16 kernel's image form (a 4-channel bf16 image, see a3d_pad_channels_bf16: the values
- * compared are the ones a separate conv would have stored, rounded to its output type); same workspace as
- * a3d_conv2d_fwd. */
+ * need the conv output either (a3d_maxpool2x2_bwd_idx).  Accepted: fp32 arithmetic and inputs; float32 x and w with a
+ * bf16 pooled map (storage A3D_STORE_Y_BF16, fp32 or bf16 arithmetic: conv2d_0 of BASELINE config 5); the bf16 kernel's
+ * image form (a 4-channel bf16 image, see a3d_pad_channels_bf16); bf16 x, w AND y with bf16 arithmetic (all three storage
+ * bits; channels, pixel strides and ld_pooled multiples of 8, k a multiple of 16 when argmax is wanted: the LDS-DMA kernel,
+ * conv2d_1 of config 5).  Wherever the output tensor is bf16 the values compared are the ones a separate conv would have
+ * stored, i.e. rounded to bf16.  Same workspace as a3d_conv2d_fwd. */
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
                         int ld_pooled, uint8_t* argmax, int act, void* ws, size_t ws_bytes, void* stream);
 
