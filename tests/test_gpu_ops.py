@@ -907,6 +907,44 @@ def test_lds_dma_kernel_with_the_max_pool_in_its_epilogue(ops, n, h, w, c, k, ks
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize('n,h,w,k,ks,st', [(6, 100, 132, 96, 11, 4), (5, 61, 80, 63, 9, 2)])
+def test_few_channel_conv_with_bf16_pooled_map_from_a_float32_image(ops, n, h, w, k, ks, st):
+    """Config 5's conv2d_0 (src/models.py:211-213): float32 image and filter, bf16 arithmetic, conv + ReLU + 2x2 max pool in one
+    launch with a bf16 pooled map and argmax bytes (a3d_conv2d_pool_fwd, storage A3D_STORE_Y_BF16).  Against the two launches
+    (the same conv to a bf16 tensor, then a3d_maxpool2x2_fwd_bf16): equal to a bf16 rounding step (the unpooled conv may add
+    its K range in another order), the recorded position holds the window's maximum to that step, and the by-index
+    MaxPoolGrad to a bf16 gradient routes dy exactly where the bytes say."""
+    rng = np.random.default_rng(k + ks)
+    bf = torch.bfloat16
+    x = dev(rng.standard_normal((n, h, w, 3)).astype(np.float32))
+    wt = dev((rng.standard_normal((ks, ks, 3, k)) / np.sqrt(ks * ks * 3)).astype(np.float32))
+    b = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+    d = ops.with_storage(ops.conv_desc(n, h, w, 3, k, ks, ks, st, 'VALID', precision='bf16'), ops.STORE_Y)
+    y = torch.empty((n, d.ho, d.wo, k), device='cuda', dtype=bf)
+    ops.conv2d_fwd(d, x, wt, b, y, 'relu')
+    ph, pw = d.ho // 2, d.wo // 2
+    two = torch.empty((n, ph, pw, k), device='cuda', dtype=bf)
+    ops.maxpool2x2_fwd_bf16(y, two)
+    one = torch.full((n, ph, pw, k), float('nan'), device='cuda', dtype=bf)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x, wt, b, one, 'relu', arg)
+    assert int(arg.max()) <= 3 and bool(torch.isfinite(one.float()).all())
+    assert rel_l2(one.float().cpu().numpy(), two.float().cpu().numpy()) < 4e-3
+    yw = y[:, :2 * ph, :2 * pw, :].reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4).float()
+    at_arg = yw.gather(-1, arg.long().unsqueeze(-1)).squeeze(-1)
+    assert rel_l2(at_arg.cpu().numpy(), yw.max(-1).values.cpu().numpy()) < 4e-3
+    if k % 8 == 0:
+        dy = torch.from_numpy(rng.standard_normal((n, ph, pw, k)).astype(np.float32)).cuda().to(bf)
+        dx = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda', dtype=bf)
+        ops.maxpool2x2_bwd_idx(arg, one, dy, dx, relu_mask=True)
+        routed = torch.where(one.float() > 0, dy.float(), torch.zeros_like(dy.float()))
+        exp = torch.zeros((n, ph, pw, k, 4), device='cuda')
+        exp.scatter_(-1, arg.long().unsqueeze(-1), routed.unsqueeze(-1))
+        full = torch.zeros((n, d.ho, d.wo, k), device='cuda')
+        full[:, :2 * ph, :2 * pw] = exp.reshape(n, ph, pw, k, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2 * ph, 2 * pw, k)
+        assert torch.equal(dx.float(), full)
+
+
 def test_cast_rows_between_row_pitches(ops):
     """a3d_cast_rows: float32 / bf16 either way, the first `cols` columns of every row, pad columns of the destination zero."""
     rng = np.random.default_rng(3)
