@@ -19,6 +19,19 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak = fp32 vector peak
 METRIC = 'images/sec (640x480->55x74 MSDN train step)'
+# algorithmic fp32 FLOPs per image of one train step (2*M*N*K per GEMM-equivalent; forward of both networks +
+# the backward of the phase's variables) and the step's algorithmic HBM bytes per image at B = 32
+STEP_GFLOP_PER_IMAGE = {'coarse': 9.357, 'fine': 6.302}
+
+
+def step_roofline(phase, B, seconds_per_step):
+    """The whole step against the fp32 matrix-core bound (the fp32 step is FLOP-bound): coarse 1.904 ms, fine
+    1.282 ms at B = 32."""
+    gflop = STEP_GFLOP_PER_IMAGE[phase] * B
+    tf = gflop / seconds_per_step / 1e3
+    return {'bound': 'mfma', 'scope': f'{phase}-phase step, 2*M*N*K of every GEMM-equivalent (SURVEY 8d)',
+            'gflop_per_step': round(gflop, 1), 'achieved': round(tf, 1), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / PEAK_F32_MFMA_TFLOPS, 4), 'bound_ms': round(gflop / PEAK_F32_MFMA_TFLOPS, 3)}
 
 
 def synth_batch(B, rank, device):
@@ -327,6 +340,9 @@ def main():
                     help='conv arithmetic; the headline (and parity) mode is fp32')
     ap.add_argument('--also', default='bf16x3', help='comma list of extra precisions measured after the headline run')
     ap.add_argument('--no-fine', action='store_true', help='skip the additional fine-phase measurement')
+    ap.add_argument('--phase', default='coarse', choices=['coarse', 'fine'],
+                    help='which phase the main timed (and profiled) run executes; the driver-facing line is coarse. '
+                         'fine = global_step 2 000 000 // B (src/models.py:302-305): a profiling aid, prints a fine-phase line')
     ap.add_argument('--no-dp-rank', action='store_true', help='N = 1: skip timing the step a data-parallel rank would run')
     ap.add_argument('--dp-world', type=int, default=8, help='world size assumed by the N = 1 dp_rank measurement')
     ap.add_argument('--model', default='msdn', choices=['msdn', 'dcnf'],
@@ -354,7 +370,8 @@ def main():
     masks = keep_masks(B, 8, rank, device)
 
     # headline: coarse-phase train step (what `make train` executes from global_step 0; the heaviest real phase)
-    dt, (recs, warm_recs) = run_phase(net, img, dep, masks, args.steps, args.warmup, 0, lib, world, timed_kernels=True)
+    gs0 = 0 if args.phase == 'coarse' else models.SAMPLES_COARSE // B
+    dt, (recs, warm_recs) = run_phase(net, img, dep, masks, args.steps, args.warmup, gs0, lib, world, timed_kernels=True)
     value = world * B * args.steps / dt
     roof, _ = roofline_from(recs)                                     # the dominant kernel, event-timed in the timed region
     _, table = roofline_from(warm_recs, with_traffic=False)           # every kernel: event-timed during the warm-up steps
@@ -366,10 +383,12 @@ def main():
                 'frac': round(nbytes / (dt / args.steps) / 8e12, 4), 'traffic': None,
                 'bytes_per_step': nbytes, 'bytes_per_image': round((nbytes) / B)}
     extra = {}
-    if not args.no_fine:
+    if not args.no_fine and args.phase == 'coarse':
         dtf, _ = run_phase(net, img, dep, masks, args.steps, min(args.warmup, 2), models.SAMPLES_COARSE // B, lib,
                            world, timed_kernels=False)
         extra['fine_phase'] = {'value': round(world * B * args.steps / dtf, 1), 'ms_per_step': round(1e3 * dtf / args.steps, 3)}
+        if args.precision == 'fp32':
+            extra['fine_phase']['roofline'] = step_roofline('fine', B, dtf / args.steps)
     for prec in [p for p in args.also.split(',') if p and p != args.precision]:
         alt = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=prec, keep_dense_grads=False)
         dta, _ = run_phase(alt, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
@@ -402,12 +421,15 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'bf16s': 'bf16'}.get(args.precision, args.precision),
             'data': 'synthetic',
-            'config': {'workload': f'MSDN coarse+fine, batch {B} per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, '
+            'config': {'workload': f'MSDN coarse+fine, batch {B} per GPU, 640x480 stored -> 228x304 net -> 55x74 depth, ' + (
                                    'coarse-phase train step (global_step 0): both forwards + both losses, backward of '
-                                   'coarse/*, 2x ApplyAdam(beta2=1)',
+                                   'coarse/*, 2x ApplyAdam(beta2=1)' if args.phase == 'coarse' else
+                                   f'FINE-phase train step (global_step {gs0}): both forwards + both losses, backward of '
+                                   'fine/*, 2x ApplyAdam(beta2=1) -- a profiling line, not the headline'),
                        'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}' + (' (RCCL all-reduce of 283 MB grads/step)' if world > 1 else '')},
             'roofline': roof,
+            'step_roofline': step_roofline(args.phase, B, dt / args.steps) if args.precision == 'fp32' else None,
             'igemm_kernels': table,
             'igemm_kernels_note': 'HIP-event durations of every GEMM launch, taken during the warm-up steps; inside the timed '
                                   'region only the roofline kernel is bracketed, in every fourth step (an event pair per '
