@@ -76,6 +76,10 @@ int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const f
                  hipStream_t st);
 int stencil1_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
                         hipStream_t st);
+bool stencil1_bwd_both_applicable(const a3d_conv_desc* d);
+size_t stencil1_bwd_both_ws_bytes(const a3d_conv_desc* d);
+int stencil1_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, const float* w, float* dw, float* db,
+                      void* dx, int lddx, int dx_bf16, int relu_mask, unsigned* state, void* ws, hipStream_t st);
 
 // ---- few-channel forward convolution straight from L2 (conv3.hip) ----
 bool conv3_applicable(const a3d_conv_desc* d, const void* x);

@@ -1197,6 +1197,30 @@ static bool bwd_f_ring_ok(const a3d_conv_desc* d) {
          d->ldy % 8 == 0 && (double)d->n * d->h * d->w * d->ldx * 2.0 < 2147483647.0 && colsum_bf16_ok(d->k) && d->ldy == d->k;
 }
 
+int a3d_conv2d_bwd_both_supported(const a3d_conv_desc* d) {
+  return check_desc(d) == A3D_OK && !d->storage && stencil1_bwd_both_applicable(d);
+}
+
+size_t a3d_conv2d_bwd_both_ws_bytes(const a3d_conv_desc* d) {
+  return a3d_conv2d_bwd_both_supported(d) ? stencil1_bwd_both_ws_bytes(d) : 0;
+}
+
+int a3d_conv2d_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, const float* w, float* dw, float* db,
+                        void* dx, int lddx, int dx_bf16, int relu_mask, uint32_t* state, void* ws, size_t ws_bytes,
+                        void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(x && dz && w && dw && dx && state, "conv2d_bwd_both: null tensor");
+  A3D_CHECK_ARG(a3d_conv2d_bwd_both_supported(d),
+                "conv2d_bwd_both: one output channel, 5x5, stride 1, an even channel count <= 64, float32 tensors, x below 1 GiB");
+  A3D_CHECK_ARG(lddx >= d->c && lddx % 2 == 0, "conv2d_bwd_both: lddx must be even and >= c");
+  A3D_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dx) & (dx_bf16 ? 3 : 7)) == 0 && (reinterpret_cast<uintptr_t>(ws) & 3) == 0,
+                "conv2d_bwd_both: x, w and dx must be aligned to a channel pair");
+  if (stencil1_bwd_both_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_both: workspace too small");
+  return stencil1_bwd_both(d, x, dz, w, dw, db, dx, lddx, dx_bf16, relu_mask, state, ws, static_cast<hipStream_t>(stream));
+}
+
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);

@@ -165,6 +165,233 @@ __global__ __launch_bounds__(256) void stencil1_bwdf_reduce_kernel(const float* 
   }
 }
 
+
+// ================================================================================================================
+// Round 5: the layer's BACKWARD on packed fp32 FMAs (v_pk_fma_f32), half a wave per pixel.
+// A lane owns TWO adjacent channels (one 8-byte piece), 32 lanes cover the 64 channels of a pixel, and every
+// multiply-add is a packed one over the channel pair.  Needs an even channel count and 8-byte aligned pixels.
+// (A forward of the same shape — 32 outputs per half-wave, the partial sums reduced by a halving exchange — was built
+// and measured at the time of the lane = channel kernel above, 21.5 vs 21.5 us at B = 32: neither is bound by its vector
+// instructions, both pull each pixel through the L1 three times.)
+// ================================================================================================================
+typedef float pk2 __attribute__((ext_vector_type(2)));
+
+// acc += a * g with ONE scalar g for both halves: g is the low / the high dword of an aligned register pair (as a 16-byte LDS
+// read leaves it) and the instruction's op_sel bits broadcast it — spelled in asm because the compiler builds the splat
+// with two v_mov per multiply-add otherwise (243 moves beside 200 packed FMAs in stencil1_bwd_kernel's loop).
+__device__ __forceinline__ void pkfma_lo(pk2& acc, pk2 a, pk2 gpair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(gpair));
+}
+__device__ __forceinline__ void pkfma_hi(pk2& acc, pk2 a, pk2 gpair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(gpair));
+}
+
+// Backward, both gradients in ONE pass over x: for an input pixel q and tap t the SAME output
+// gradient g = dz[q - t + pad] enters  dw[t][c] += x[q][c] * g  and  dx[q][c] += w[t][c] * g, so a lane that holds x[q][c..c+1]
+// does both with the g it fetched once (50 packed FMAs per pixel and channel pair), writes dx (masked by x > 0: the
+// ReluGrad of the layer below, whose output x is) and keeps dw in registers; x is read once, dx written once.
+//   block = (image, band of RB input rows); dz of the band's rows +- the filter reach sits zero-padded in LDS;
+//   half a wave walks runs of 4 consecutive pixels (the 5 x 8 window of dz it needs: ten 16-byte LDS reads);
+//   dw / db: halves -> waves (LDS) -> one slab per block -> groups of blocks -> total, in index order at every level, the
+//   last-arriving block of a group / the last group doing the adding (tickets in `state`, which every call leaves zero).
+struct Stencil1BwdParams {
+  const float* x; const float* dz; const float* w; void* dx; float* slabs; float* gslabs; float* dw; float* db;
+  unsigned* state;
+  int n, h, w_in, c, ldx, ho, wo, pad_t, pad_l, ldy, lddx;
+  int bands, runs_per_row, dwid, group, ngroups, mask, xvec4;
+};
+
+template <int KS, int RB, bool DX16>
+__global__ __launch_bounds__(256, 2) void stencil1_bwd_kernel(const Stencil1BwdParams p) {
+  constexpr int TW = KS * KS * 64;                   // a slab: TW filter-gradient sums, then db, padded to whole 16-byte pieces
+  constexpr int SLAB4 = TW / 4 + 1;
+  constexpr int DROWS = RB + KS - 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* D = smem;                                   // [DROWS][dwid]
+  float* X = smem + DROWS * p.dwid;                  // [RB][w_in][c]: the band of x; later the four waves' filter-gradient sums
+  float* red = X;
+  __shared__ float dbred[4];
+  __shared__ unsigned last;
+  const int lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31, wv = threadIdx.x >> 6;
+  const int img = blockIdx.x / p.bands, iy0 = (blockIdx.x - img * p.bands) * RB;
+  const bool live = 2 * cl < p.c;
+  // ---- the band of x -> LDS: every thread's loads in flight at once (rows past the image: the buffer's end, i.e. zeros)
+  {
+    const int rows = min(RB, p.h - iy0);
+    const size_t first = ((size_t)img * p.h + iy0) * p.w_in * p.ldx;
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.x + first, ((unsigned long long)(rows * p.w_in - 1) * p.ldx + p.c) * 4ull);
+    if (p.xvec4) {                                   // c, ldx multiples of 4, 16-byte aligned pixels
+      const int c4 = p.c >> 2, total = RB * p.w_in * c4;
+      constexpr int U = 8;
+      for (int e0 = threadIdx.x; e0 < total; e0 += 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + u * 256, px = e / c4, q = e - px * c4;
+          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rb, e < total ? (px * p.ldx + 4 * q) * 4 : (int)kOOB, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + u * 256;
+          if (e < total) *reinterpret_cast<u32x4*>(X + 4 * e) = v[u];
+        }
+      }
+    } else {
+      const int c2 = p.c >> 1, total = RB * p.w_in * c2;
+      for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e / c2, q = e - px * c2;
+        *reinterpret_cast<u32x2*>(X + 2 * e) = __builtin_amdgcn_raw_buffer_load_b64(rb, (px * p.ldx + 2 * q) * 4, 0, 0);
+      }
+    }
+  }
+  // ---- dz window of the band -> LDS (zeros outside the output), and this block's share of BiasAddGrad: the output rows
+  //      iy0 .. iy0+RB-1 (every output row belongs to exactly one band: ho <= h)
+  float dbp = 0.f;
+  for (int i = threadIdx.x; i < DROWS * p.dwid; i += 256) {
+    const int a = i / p.dwid, bcol = i - a * p.dwid;
+    const int oy = iy0 + p.pad_t - (KS - 1) + a, ox = bcol - (KS - 1) + p.pad_l;
+    float g = 0.f;
+    if ((unsigned)oy < (unsigned)p.ho && (unsigned)ox < (unsigned)p.wo) {
+      g = p.dz[(((size_t)img * p.ho + oy) * p.wo + ox) * p.ldy];
+      if (oy >= iy0 && oy < iy0 + RB) dbp += g;
+    }
+    D[i] = g;
+  }
+  dbp = wave_sum64(dbp);
+  if (lane == 0) dbred[wv] = dbp;
+  pk2 wreg[KS * KS], acc[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) {
+    wreg[t] = live ? *reinterpret_cast<const pk2*>(p.w + t * p.c + 2 * cl) : pk2{0.f, 0.f};
+    acc[t] = pk2{0.f, 0.f};
+  }
+  __syncthreads();
+  const int units = RB * p.runs_per_row;             // (row of the band, run of 4 pixels)
+  const int hwb = wv * 2 + half;
+  const int iters = (units + 7) / 8;                 // the same trip count for every half-wave of the block
+  for (int k = 0; k < iters; ++k) {
+    const int u = min(k * 8 + hwb, units - 1);       // (a half-wave past the end repeats the last run with x = 0)
+    const bool uok = k * 8 + hwb < units;
+    const int j = u / p.runs_per_row, run = u - j * p.runs_per_row;
+    const int iy = iy0 + j;
+    pk2 v[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int ix = min(4 * run + pp, p.w_in - 1);
+      const pk2 t = *reinterpret_cast<const pk2*>(X + (j * p.w_in + ix) * p.c + (live ? 2 * cl : 0));
+      const bool ok = uok && live && 4 * run + pp < p.w_in;
+      v[pp] = pk2{ok ? t[0] : 0.f, ok ? t[1] : 0.f};
+    }
+    pk2 G[KS][4];                                      // G[r][m] = dz window columns 2m, 2m+1 of filter row r
+#pragma unroll
+    for (int r = 0; r < KS; ++r) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(D + (j + (KS - 1) - r) * p.dwid + 4 * run);
+      const f32x4 g0 = src[0], g1 = src[1];
+      G[r][0] = pk2{g0[0], g0[1]}; G[r][1] = pk2{g0[2], g0[3]};
+      G[r][2] = pk2{g1[0], g1[1]}; G[r][3] = pk2{g1[2], g1[3]};
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      pk2 d = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < KS; ++r)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int col = pp + (KS - 1) - s;           // window column of this pixel's tap
+          if (col & 1) {
+            pkfma_hi(acc[r * KS + s], v[pp], G[r][col >> 1]);
+            pkfma_hi(d, wreg[r * KS + s], G[r][col >> 1]);
+          } else {
+            pkfma_lo(acc[r * KS + s], v[pp], G[r][col >> 1]);
+            pkfma_lo(d, wreg[r * KS + s], G[r][col >> 1]);
+          }
+        }
+      const int ix = 4 * run + pp;
+      if (live && uok && iy < p.h && ix < p.w_in) {
+        if (p.mask) {
+          d[0] = v[pp][0] > 0.f ? d[0] : 0.f;
+          d[1] = v[pp][1] > 0.f ? d[1] : 0.f;
+        }
+        const size_t o = (((size_t)img * p.h + iy) * p.w_in + ix) * p.lddx + 2 * cl;
+        if constexpr (DX16) {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<bf16x2*>(static_cast<__bf16*>(p.dx) + o) = bf16x2{(__bf16)d[0], (__bf16)d[1]};
+        } else {
+          *reinterpret_cast<pk2*>(static_cast<float*>(p.dx) + o) = d;
+        }
+      }
+    }
+  }
+  __syncthreads();                                     // the band of x is dead: its LDS takes the waves' sums
+  // ---- dw: the two halves of a wave, then the four waves, then the block's slab
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) {
+    const float a0 = acc[t][0] + __shfl_xor(acc[t][0], 32, 64);
+    const float a1 = acc[t][1] + __shfl_xor(acc[t][1], 32, 64);
+    if (half == 0) *reinterpret_cast<pk2*>(red + (wv * KS * KS + t) * 64 + 2 * cl) = pk2{a0, a1};
+  }
+  __syncthreads();
+  // slabs cross CUs (and XCDs) as 16-byte write-through stores, drained before the block's ticket, and are read back with
+  // sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: the last-arriver form)
+  const int nblocks = gridDim.x;
+  const size_t slab_bytes = (size_t)SLAB4 * 16;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slabs, (unsigned long long)nblocks * slab_bytes);
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gslabs, (unsigned long long)p.ngroups * slab_bytes);
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    f32x4 s;
+    if (i4 < TW / 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(red + 4 * i4), b = *reinterpret_cast<const f32x4*>(red + TW + 4 * i4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(red + 2 * TW + 4 * i4), d = *reinterpret_cast<const f32x4*>(red + 3 * TW + 4 * i4);
+      s = (a + b) + (c + d);
+    } else {
+      s = f32x4{(dbred[0] + dbred[1]) + (dbred[2] + dbred[3]), 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rs, (int)(blockIdx.x * slab_bytes + i4 * 16), 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int grp = blockIdx.x / p.group;
+  const int gfirst = grp * p.group, gcount = min(p.group, nblocks - gfirst);
+  if (threadIdx.x == 0) last = atomicInc(&p.state[1 + grp], (unsigned)gcount - 1u) == (unsigned)gcount - 1u;
+  __syncthreads();
+  if (!last) return;
+  auto sum_slabs = [&](const __amdgpu_buffer_rsrc_t r, int firstslab, int count, int i4) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int b0 = 0; b0 < count; b0 += U) {            // eight loads in flight, added in slab order
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, b0 + u < count ? (int)((firstslab + b0 + u) * slab_bytes + i4 * 16) : (int)kOOB, 0, 16);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (b0 + u < count) s += __builtin_bit_cast(f32x4, v[u]);
+    }
+    return s;
+  };
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    const f32x4 s = sum_slabs(rs, gfirst, gcount, i4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rg, (int)(grp * slab_bytes + i4 * 16), 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicInc(&p.state[0], (unsigned)p.ngroups - 1u) == (unsigned)p.ngroups - 1u;
+  __syncthreads();
+  if (!last) return;
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    const f32x4 s = sum_slabs(rg, 0, p.ngroups, i4);
+    if (i4 == TW / 4) {
+      if (p.db) p.db[0] = s[0];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * i4 + e, t = i / 64, ch = i % 64;
+        if (ch < p.c) p.dw[t * p.c + ch] = s[e];
+      }
+    }
+  }
+}
+
 static const int kStencilBlocks = 1024;
 static const int kStencilGroup = 32;
 
@@ -195,6 +422,59 @@ int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const f
   clear_stale_error();
   hipLaunchKernelGGL(stencil1_fwd_kernel<5>, dim3(blocks), dim3(256), 0, st, p);
   return check_launch("stencil1_fwd");
+}
+
+// ---- both gradients in one pass (stencil1_bwd_kernel) ----
+static constexpr int kBwdRB = 4;
+static void bwd_geometry(const a3d_conv_desc* d, int& bands, int& blocks, int& group, int& ngroups) {
+  bands = (d->h + kBwdRB - 1) / kBwdRB;
+  blocks = d->n * bands;
+  group = 32;
+  if ((blocks + group - 1) / group > 63) group = (blocks + 62) / 63;
+  ngroups = (blocks + group - 1) / group;
+}
+
+// dz window of the band + the band of x (later: four waves' sums), two blocks per CU
+static size_t bwd_lds_bytes(const a3d_conv_desc* d) {
+  const int dwid = 4 * ((d->w + 3) / 4) + 4;
+  return (size_t)((kBwdRB + 4) * dwid + std::max(4 * 25 * 64, kBwdRB * d->w * d->c)) * 4;
+}
+
+bool stencil1_bwd_both_applicable(const a3d_conv_desc* d) {
+  return stencil1_applicable(d) && d->c % 2 == 0 && d->ldx % 2 == 0 && d->pad_t >= 0 && d->pad_t < 5 && d->pad_l >= 0 &&
+         d->pad_l < 5 && d->ho <= d->h && d->wo <= d->w && bwd_lds_bytes(d) <= 79 * 1024 &&
+         (unsigned long long)d->n * d->h * d->w * d->ldx * 4ull <= 0x40000000ull;
+}
+
+size_t stencil1_bwd_both_ws_bytes(const a3d_conv_desc* d) {
+  int bands, blocks, group, ngroups;
+  bwd_geometry(d, bands, blocks, group, ngroups);
+  return (size_t)(blocks + ngroups) * (25 * 64 + 4) * 4 + 16;
+}
+
+int stencil1_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, const float* w, float* dw, float* db,
+                      void* dx, int lddx, int dx_bf16, int relu_mask, unsigned* state, void* ws, hipStream_t st) {
+  Stencil1BwdParams p{};
+  p.x = x; p.dz = dz; p.w = w; p.dx = dx; p.dw = dw; p.db = db; p.state = state;
+  p.n = d->n; p.h = d->h; p.w_in = d->w; p.c = d->c; p.ldx = d->ldx; p.ho = d->ho; p.wo = d->wo;
+  p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ldy = d->ldy; p.lddx = lddx; p.mask = relu_mask;
+  int blocks;
+  bwd_geometry(d, p.bands, blocks, p.group, p.ngroups);
+  p.runs_per_row = (d->w + 3) / 4;
+  p.dwid = 4 * p.runs_per_row + 4;
+  p.slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
+  p.gslabs = p.slabs + (size_t)blocks * (25 * 64 + 4);
+  p.xvec4 = d->c % 4 == 0 && d->ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const size_t lds = bwd_lds_bytes(d);
+  // above 64 KiB of dynamic LDS: the attribute is per device and cheap, set on every call
+  if (dx_bf16) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil1_bwd_kernel<5, kBwdRB, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil1_bwd_kernel<5, kBwdRB, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  clear_stale_error();
+  if (dx_bf16) hipLaunchKernelGGL((stencil1_bwd_kernel<5, kBwdRB, true>), dim3(blocks), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((stencil1_bwd_kernel<5, kBwdRB, false>), dim3(blocks), dim3(256), lds, st, p);
+  return check_launch("stencil1_bwd_both");
 }
 
 int stencil1_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,

@@ -166,6 +166,7 @@ class MSDNReplica:
         self._share_names = {0: (), 1: ('fine/first/conv2d', 'fine/second/conv2d'), 2: ('fine/first/conv2d',),
                              3: ('fine/second/conv2d',)}[share]
         self._shared_desc = {}
+        self._alone = ()          # fine-network GEMMs of the current forward that nothing runs beside (fine phase: fine/second)
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         # data-parallel replicas under the reference's frozen optimizer: the dense bucket is reduce-scattered and each
         # rank keeps the Adam `m` slot of its own slices only (dp.py); gather_state() reassembles it
@@ -253,7 +254,8 @@ class MSDNReplica:
         self.dc4 = abuf(B, 6, 8, 256); self.dc3 = abuf(B, 13, 18, 384); self.dc2 = abuf(B, 13, 18, 384)
         self.dp1 = abuf(B, 13, 18, 256); self.dc1 = abuf(B, 27, 37, 256)
         self.dp0 = abuf(B, 27, 37, 96); self.dc0 = abuf(B, 55, 74, 96)
-        self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = buf(B, OUT_H, OUT_W, 64)
+        # fine/third's backward writes df2 in the type fine/second's backward reads it: bf16 under 'bf16s' (round 5)
+        self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = abuf(B, OUT_H, OUT_W, 64)
         self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
         if self.bf16s:
             self.c4_32 = buf(B, 6, 8, 256)                                          # the fp32 copy of c4 dense_0's filter gradient reads
@@ -302,7 +304,9 @@ class MSDNReplica:
                 self.d[n] = ops.with_storage(self.d[n], 0)
                 self.d[n].precision = ops.PREC['fp32']
                 self.store[n] = {'fwd': Y, 'bwd_d': 0, 'bwd_f': 0}
-            self.store['fine/second/conv2d'] = {'fwd': X | W, 'bwd_d': W | X, 'bwd_f': X}     # f2 / df2 stay fp32
+            # f2 stays fp32 (fine/third is a single-output-channel stencil on fp32); df2 comes back from that layer's fused
+            # backward as bf16, so fine/second's bwd-data and bwd-filter read two bf16 operands (the LDS-DMA kernel)
+            self.store['fine/second/conv2d'] = {'fwd': X | W, 'bwd_d': W | X | Y, 'bwd_f': X | Y}
             # ... except where fine/first has no backward (coarse phase, and once nothing trains any more): there its forward
             # runs on the bf16 pipe from a 4-channel bf16 copy of the image (8-byte pixels: window runs 16 bytes apart),
             # 0.41 -> 0.10 ms at B = 64, conv + ReLU + max pool in one launch (f1 is never written there either)
@@ -329,7 +333,7 @@ class MSDNReplica:
         """The layer's conv descriptor for 'fwd' | 'bwd_d' | 'bwd_f', with that call's storage bits."""
         d = self.d[name]
         bits = self.store.get(name, {}).get(which, 0)
-        if which == 'fwd' and name in self._share_names:
+        if which == 'fwd' and name in self._share_names and name not in self._alone:
             # a fine-network GEMM on the side stream beside the dense layers' weight streams: leave those room on every CU
             key = (name, bits)
             if key not in self._shared_desc:
@@ -649,6 +653,9 @@ class MSDNReplica:
             ops.resize_bilinear_tf1(depths, self.t)
         B = self.B
         self.dropout_on = keep_mask is not None            # None: the plugin was called with train=False
+        # fine phase: the main queue has nothing left to run beside fine/second (the coarse backward does not exist there and
+        # the fine backward waits for this forward), so the launch takes the whole CU instead of leaving room (A3D_HINT_SHARE_CU)
+        self._alone = ('fine/second/conv2d',) if phase == 2 else ()
         if self.bf16s and phase in (1, 3) and not (self.fuse_pool and phase in (1, 2, 3)):
             # the fine network's 4-channel bf16 image, on the main stream: the side stream's chain (fine/first .. loss) is
             # the longer one at the join, the main stream idles there
@@ -822,8 +829,14 @@ class MSDNReplica:
         self._join()                                                          # the fine forward ran on the side stream
         ops.silog_loss_bwd(self.fine, self.t, self.ws_f, self.dfine)
         n = 'fine/third'
-        self._bwd_filter(n, self.f2, self.dfine)
-        self._bwd_data(n, self.dfine, self.df2, relu_mask=self.f2)
+        if ops.conv2d_bwd_both_supported(self.d[n]):
+            # filter, bias and input gradient (+ fine/second's ReluGrad) in one pass over f2
+            ops.conv2d_bwd_both(self.d[n], self.f2, self.dfine, self._v(n + '/kernel'), self._g(n + '/kernel'),
+                                self._g(n + '/bias'), self.df2, relu_mask=True)
+        else:
+            assert not self.bf16s, 'bf16 storage: df2 is a bf16 tensor only the fused backward writes'
+            self._bwd_filter(n, self.f2, self.dfine)
+            self._bwd_data(n, self.dfine, self.df2, relu_mask=self.f2)
         n = 'fine/second/conv2d'
         self._bwd_filter(n, self.cat, self.df2)
         self._bwd_data(n, self.df2, self.dcat)

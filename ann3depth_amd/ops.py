@@ -152,6 +152,29 @@ def conv2d_bwd_filter(d, x, dz, dw, db=None):
     return dw, db
 
 
+_BOTH_STATE = {}
+
+
+def conv2d_bwd_both_supported(d):
+    return bool(_lib.load().a3d_conv2d_bwd_both_supported(ctypes.byref(d)))
+
+
+def conv2d_bwd_both(d, x, dz, w, dw, db, dx, relu_mask=True):
+    """Filter gradient, bias gradient and input gradient (times x > 0 if relu_mask) of a single-output-channel conv in one
+    pass over x (a3d_conv2d_bwd_both); dx may be a bfloat16 tensor.  The launch's arrival counters live in a small zeroed
+    buffer per stream (every call leaves it zero)."""
+    lib = _lib.load()
+    key = (torch.cuda.current_stream().cuda_stream, x.device)
+    state = _BOTH_STATE.get(key)
+    if state is None:
+        state = _BOTH_STATE[key] = torch.zeros(64, dtype=torch.int32, device=x.device)
+    ws, n = _ws().get(lib.a3d_conv2d_bwd_both_ws_bytes(ctypes.byref(d)), x.device)
+    check(lib.a3d_conv2d_bwd_both(ctypes.byref(d), _ptr(x), _ptr(dz), _ptr(w), _ptr(dw), _ptr(db), _ptr(dx), dx.shape[-1],
+                                  int(dx.dtype == torch.bfloat16), int(bool(relu_mask)), _ptr(state), ws, n, _stream()),
+          'a3d_conv2d_bwd_both')
+    return dw, db, dx
+
+
 def dense_fwd(x, w, bias, y, act=None, drop_keep=None):
     m, k = x.shape
     n = w.shape[1]

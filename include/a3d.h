@@ -126,6 +126,21 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* Conv2DBackpropFilter + BiasAddGrad + Conv2DBackpropInput (+ the ReluGrad of the layer below) of a convolution with ONE
+ * output channel, in one pass over x — fine/third (src/models.py:250-251; its gradients are asked for at :333-338 through
+ * compute_gradients over the fine variables, the input gradient by the layer below): the same dz[q - tap + pad] enters
+ * dw[tap][c] += x[q][c] * dz and dx[q][c] += w[tap][c] * dz, so x is read once (for the filter gradient AND as the ReLU mask
+ * of dx when relu_mask != 0: dx *= (x > 0)) and dx written once, float32 or (dx_bf16 != 0) bf16, pixel stride lddx.
+ * Supported (a3d_conv2d_bwd_both_supported): k = 1, 5x5, stride 1, an even c <= 64, even ldx, float32 x / dz / w, x below
+ * 1 GiB; otherwise call a3d_conv2d_bwd_filter and a3d_conv2d_bwd_data.  dw and db are summed in a fixed order (the same
+ * bits on every run).  `state`: 64 uint32 owned by the caller, zero before the first call; every call leaves them zero
+ * (arrival counters of the launch's blocks; one buffer per stream that may run this call concurrently). */
+int a3d_conv2d_bwd_both_supported(const a3d_conv_desc* d);
+size_t a3d_conv2d_bwd_both_ws_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, const float* w, float* dw, float* db,
+                        void* dx, int lddx, int dx_bf16, int relu_mask, uint32_t* state, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* tf.layers.dense (src/models.py:80-82,228,231): y[m,n] = act(x[m,:] @ w[:,n] + b[n]).
  * If drop_keep != NULL (uint8 [m,n]) the tf.layers.dropout(rate=.5, training=True) of src/models.py:230 is fused:
  * y *= 2 * keep. */

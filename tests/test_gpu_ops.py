@@ -101,6 +101,54 @@ def test_conv2d_fwd_bwd(ops, n, h, w, c, k, ks, st, pad):
     assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < RTOL_F32
 
 
+BOTH_CASES = [
+    # n, h, w, c, padding, ldx, lddx          (single-output-channel 5x5 convs: fine/third, src/models.py:250-251)
+    (2, 21, 30, 64, 'SAME', 64, 64),
+    (3, 55, 74, 64, 'SAME', 64, 64),         # fine/third at full spatial size: 74 = 18 runs of 4 + 2, 55 = 13 bands of 4 + 3
+    (2, 9, 13, 40, 'VALID', 40, 40),         # fewer channels than lanes, no padding: output smaller than the input
+    (5, 7, 6, 64, 'SAME', 64, 72),           # fewer rows than two bands' reach; dx with a wider pixel stride
+    (70, 5, 9, 24, 'SAME', 32, 24),          # more than 63 groups' worth of blocks at the default group size; strided x
+]
+
+
+@pytest.mark.parametrize('dx16', [False, True])
+@pytest.mark.parametrize('n,h,w,c,pad,ldx,lddx', BOTH_CASES)
+def test_conv2d_bwd_both_single_output_channel(ops, n, h, w, c, pad, ldx, lddx, dx16):
+    """a3d_conv2d_bwd_both: Conv2DBackpropFilter + BiasAddGrad + Conv2DBackpropInput + ReluGrad of a Cout = 1 conv in one pass
+    over x, against the float64 oracle; dx as float32 or bf16 (config 5 hands it to fine/second's backward in that form);
+    run twice on one state buffer (the arrival counters must come back to zero) and bit-identical both times."""
+    rng = np.random.default_rng(700 + n * h * w + c)
+    xbuf = rng.standard_normal((n, h, w, ldx)).astype(np.float32)
+    x = xbuf[..., :c]
+    wt = (rng.standard_normal((5, 5, c, 1)) / np.sqrt(25 * c)).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, 1, 5, 5, 1, pad, ldx=ldx)
+    assert ops.conv2d_bwd_both_supported(d)
+    dz = rng.standard_normal((n, d.ho, d.wo, 1)).astype(np.float32)
+    x64, w64, dz64 = x.astype(np.float64), wt.astype(np.float64), dz.astype(np.float64)
+    dw_ref, db_ref = T.conv2d_bwd_filter(x64, dz64, wt.shape, 1, pad)
+    dx_ref = T.conv2d_bwd_data(dz64, w64, x.shape, 1, pad)
+    xd, wd, dzd = dev(xbuf), dev(wt), dev(dz)
+    for mask in (True, False):
+        outs = []
+        for _ in range(2):
+            dw = torch.full_like(wd, float('nan'))
+            db = torch.full((1,), float('nan'), device='cuda')
+            dx = torch.full((n, h, w, lddx), 7.0, device='cuda', dtype=torch.bfloat16 if dx16 else torch.float32)
+            ops.conv2d_bwd_both(d, xd, dzd, wd, dw, db, dx, relu_mask=mask)
+            torch.cuda.synchronize()
+            outs.append((dw.cpu().numpy(), db.cpu().numpy(), dx.float().cpu().numpy()))
+        for a, b in zip(outs[0], outs[1]):
+            np.testing.assert_array_equal(a, b)
+        dw_g, db_g, dx_g = outs[0]
+        assert rel_l2(dw_g, dw_ref) < RTOL_F32
+        assert rel_l2(db_g, db_ref) < RTOL_F32
+        want = dx_ref * (x > 0) if mask else dx_ref
+        assert rel_l2(dx_g[..., :c], want) < (4e-3 if dx16 else RTOL_F32)
+        assert (dx_g[..., c:] == 7.0).all()
+    # a descriptor the fused kernel does not take is refused, not mis-run
+    assert not ops.conv2d_bwd_both_supported(ops.conv_desc(n, h, w, c, 2, 5, 5, 1, pad, ldx=ldx))
+
+
 BF16_CASES = [c for c in CONV_CASES if c[3] % 4 == 0 and c[4] % 4 == 0 and c[4] > 1]
 
 
