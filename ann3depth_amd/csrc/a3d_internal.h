@@ -25,6 +25,11 @@ inline int check_launch(const char* what) {
   return A3D_OK;
 }
 
+// Environment switches (capi.cc).  tune_int: A/B and sweep switches — the environment is consulted ONLY in a process started
+// with A3D_TUNING=1 (the tools under tools/ set it); anywhere else the default is returned and nothing reads the environment.
+bool tuning();
+int tune_int(const char* name, int dflt);
+
 // ---- implicit-GEMM front end (igemm_host.hip) ----
 struct GemmPlan {
   int prec;          // A3D_PREC_*: 0 = fp32 kernel (cfg valid), else bf16 kernel (bf16_bn valid)
@@ -80,6 +85,12 @@ bool stencil1_bwd_both_applicable(const a3d_conv_desc* d);
 size_t stencil1_bwd_both_ws_bytes(const a3d_conv_desc* d);
 int stencil1_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, const float* w, float* dw, float* db,
                       void* dx, int lddx, int dx_bf16, int relu_mask, unsigned* state, void* ws, hipStream_t st);
+
+// ---- few-channel filter gradient from LDS-staged input rows, optionally with the max pool's gradient fused (fewch.hip) ----
+bool fewch_bwdf_applicable(const a3d_conv_desc* d, bool pooled);
+size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled);
+int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void* dz, int ldz, const void* pooled_act,
+                     const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st);
 
 // ---- few-channel forward convolution straight from L2 (conv3.hip) ----
 bool conv3_applicable(const a3d_conv_desc* d, const void* x);

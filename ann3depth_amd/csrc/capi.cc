@@ -1,6 +1,7 @@
 // capi.cc — error reporting and version of liba3d.so.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "a3d_internal.h"
@@ -15,6 +16,17 @@ int set_error(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+bool tuning() {
+  static const bool v = [] { const char* e = getenv("A3D_TUNING"); return e && *e && atoi(e) != 0; }();
+  return v;
+}
+
+int tune_int(const char* name, int dflt) {
+  if (!tuning()) return dflt;
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
 }
 
 }  // namespace a3d

@@ -1,0 +1,280 @@
+// fewch.hip — Conv2DBackpropFilter (+ BiasAddGrad) of the few-channel layers from LDS-staged input rows: conv2d_0
+// (src/models.py:211: 11x11 stride 4 on a 3-channel image), fine/first (:241: 9x9 stride 2) and DCNF's first conv
+// (:64: 11x11 stride 1).  dw[(r,s,c)][k] = sum over pixels x[oy*st + r][ox*st + s][c] * dz[oy][ox][k] is a GEMM with
+// M = R*S*C (243 / 363), N = k (63 / 64 / 96) and the PIXELS as its contraction axis; the generic kernel gathers its A
+// operand (im2col(x) transposed) with 8-byte window runs, a row-table lookup and a bound test per piece — 4 vector and 3
+// scalar instructions per MFMA, matrix pipe half idle (profiles/r04_pmc_mfma_busy.json).  Here:
+//   * a block owns 128 rows of M (four waves x one 32-row tile x all of N) and a contiguous range of output rows;
+//   * per output row the few input rows its filter rows touch (<= 6 x W*C floats) and the row of dz go to LDS once, as
+//     16-byte pieces; lane (m, half) of v_mfma_f32_32x32x2_f32 then reads its A element for the pixel pair (2kp, 2kp+1) at
+//     `lane constant + kp * 2*stride*C` — ONE ds_read_b32 and one add per MFMA group, no decode, no bound test (VALID
+//     convolutions: every tap of every output pixel lies inside the image);
+//   * BiasAddGrad rides in the GEMM: row M of the padded tile reads a constant 1.0, so dw[M][k] = sum dz[.][k];
+//   * the pool in front of these layers' gradients is fused into the staging of dz (SRC_POOLED): the row of dz is built
+//     from the POOLED gradient, the argmax byte and the sign of the pooled activation (MaxPoolGrad + ReluGrad,
+//     src/models.py:213,243,65), so the full-resolution gradient (131 MB for fine/first at B = 32, 1.6 GB for DCNF) is
+//     never written or read;
+//   * the pixel axis is split over blocks; partial tiles go to slabs and one reduction adds them in split order (the
+//     same bits on every run).
+#include <algorithm>
+
+#include "a3d_internal.h"
+#include "igemm.h"
+
+namespace a3d {
+
+enum { FEW_SRC_DZ = 0, FEW_SRC_POOLED = 1, FEW_SRC_POOLED_BF16 = 2 };
+constexpr int kFewRows = 6;          // input rows one 128-row group of M can touch (128 / (S*C) + 2 for S*C >= 27)
+
+struct FewchParams {
+  const float* x;          // [n, h, w, c], pixels densely packed
+  const void* dz;          // FEW_SRC_DZ: [n, ho, wo, ldz] float32; pooled: the pooled gradient [n, ho/2, wo/2, ldz]
+  const void* pooled;      // pooled sources: the pooled activation (ReluGrad: > 0), same layout as dz; null = no mask
+  const uint8_t* argmax;   // pooled sources: [n, ho/2, wo/2, ld_arg] window positions 0..3
+  float* slabs;            // [splits][Mp][NP]
+  int n, h, w, c, R, S, stride, ho, wo, N, M, Mp, NP;
+  int ldz, ld_arg;
+  int rows_per_img, rows_total, splits, mgroups;
+  int xpitch, rowlen, kpairs, wo_pad;
+  int xvec4, dvec4;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TN, int SRC>
+__global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                   // [kFewRows][xpitch]
+  float* dzs = xs + kFewRows * p.xpitch;              // [wo_pad][NP]
+  float* consts = dzs + p.wo_pad * p.NP;              // 1.0, 0.0
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int split = blockIdx.x / p.mgroups, mg = blockIdx.x - split * p.mgroups;
+  const int SC = p.S * p.c;
+  const int rlo = (mg * 128) / SC;
+  const int rhi = min(p.M - 1, mg * 128 + 127) / SC;
+  const int nr = rhi - rlo + 1;
+  // ---- this lane's A element: row m of the tile, pixel parity lh
+  const int m = mg * 128 + wv * 32 + li;
+  int a_off, a_step;
+  if (m < p.M) {
+    const int r = m / SC, j = m - r * SC;
+    a_off = (r - rlo) * p.xpitch + j + lh * p.stride * p.c;
+    a_step = 2 * p.stride * p.c;
+  } else {
+    a_off = (int)(consts - xs) + (m == p.M ? 0 : 1);  // the bias row reads 1.0, the rest of the padding 0.0
+    a_step = 0;
+  }
+  // zero what the staging never writes: the tails of the input rows (read against dz = 0 when wo is odd) and the columns
+  // N..NP / the pad pixel of the dz row
+  for (int i = tid; i < kFewRows * p.xpitch; i += 256) xs[i] = 0.f;
+  for (int i = tid; i < p.wo_pad * p.NP; i += 256) dzs[i] = 0.f;
+  if (tid == 0) { consts[0] = 1.f; consts[1] = 0.f; }
+  f32x16 acc[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+  const int row_lo = (int)((long)split * p.rows_total / p.splits), row_hi = (int)((long)(split + 1) * p.rows_total / p.splits);
+  for (int row = row_lo; row < row_hi; ++row) {
+    const int img = row / p.rows_per_img, oy = row - img * p.rows_per_img;
+    __syncthreads();                                  // the previous row's MFMAs have read their operands
+    // ---- input rows oy*stride + rlo .. + nr-1 -> xs
+    {
+      const float* src = p.x + ((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen;
+      if (p.xvec4) {
+        const int r4 = p.rowlen >> 2, total = nr * r4;
+        for (int e = tid; e < total; e += 256) {
+          const int rr = e / r4, q = e - rr * r4;
+          *reinterpret_cast<f32x4*>(xs + rr * p.xpitch + 4 * q) = *reinterpret_cast<const f32x4*>(src + (size_t)rr * p.rowlen + 4 * q);
+        }
+      } else {
+        const int total = nr * p.rowlen;
+        for (int e = tid; e < total; e += 256) {
+          const int rr = e / p.rowlen, q = e - rr * p.rowlen;
+          xs[rr * p.xpitch + q] = src[(size_t)rr * p.rowlen + q];
+        }
+      }
+    }
+    // ---- the row of dz -> dzs[pixel][NP]
+    if constexpr (SRC == FEW_SRC_DZ) {
+      const float* src = static_cast<const float*>(p.dz) + ((size_t)img * p.ho + oy) * p.wo * p.ldz;
+      if (p.dvec4) {
+        const int n4 = p.N >> 2, total = p.wo * n4;
+        for (int e = tid; e < total; e += 256) {
+          const int px = e / n4, q = e - px * n4;
+          *reinterpret_cast<f32x4*>(dzs + px * p.NP + 4 * q) = *reinterpret_cast<const f32x4*>(src + (size_t)px * p.ldz + 4 * q);
+        }
+      } else {
+        const int total = p.wo * p.N;
+        for (int e = tid; e < total; e += 256) {
+          const int px = e / p.N, q = e - px * p.N;
+          dzs[px * p.NP + q] = src[(size_t)px * p.ldz + q];
+        }
+      }
+    } else {
+      // MaxPoolGrad + ReluGrad while staging: window (oy/2, px) hands its gradient to position argmax, if the maximum was > 0
+      const int pw = p.wo >> 1, ph = p.ho >> 1;
+      const size_t prow = ((size_t)img * ph + (oy >> 1)) * pw;
+      const int want = (oy & 1) * 2;
+      const int total = pw * p.N;
+      for (int e = tid; e < total; e += 256) {
+        const int px = e / p.N, q = e - px * p.N;
+        const size_t o = (prow + px) * p.ldz + q;
+        float g, act = 1.f;
+        if constexpr (SRC == FEW_SRC_POOLED_BF16) {
+          g = (float)static_cast<const __bf16*>(p.dz)[o];
+          if (p.pooled) act = (float)static_cast<const __bf16*>(p.pooled)[o];
+        } else {
+          g = static_cast<const float*>(p.dz)[o];
+          if (p.pooled) act = static_cast<const float*>(p.pooled)[o];
+        }
+        const int a = p.argmax[(prow + px) * p.ld_arg + q];
+        g = act > 0.f ? g : 0.f;
+        dzs[(2 * px) * p.NP + q] = a == want ? g : 0.f;
+        dzs[(2 * px + 1) * p.NP + q] = a == want + 1 ? g : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- 2 pixels per MFMA: A = x at the lane's tap for pixel 2kp + lh, B = dz[2kp + lh][column li]
+    const float* ap = xs + a_off;
+    const float* bp = dzs + lh * p.NP + li;
+    int kp = 0;
+    for (; kp + 4 <= p.kpairs; kp += 4) {
+      float a[4], b[4][TN];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = ap[u * a_step];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[u][t] = bp[u * 2 * p.NP + t * 32];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+      ap += 4 * a_step;
+      bp += 8 * p.NP;
+    }
+    for (; kp < p.kpairs; ++kp) {
+      const float a = ap[0];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[t * 32], acc[t], 0, 0, 0);
+      ap += a_step;
+      bp += 2 * p.NP;
+    }
+  }
+  // ---- the block's partial tile -> its slab (register 4g+i of a lane: row 8g + 4*lh + i, column li)
+  float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * p.NP;
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slab[(size_t)(8 * g + 4 * lh + i) * p.NP + t * 32 + li] = acc[t][4 * g + i];
+}
+
+// dw[m][n] (m < M), db[n] (row M) = sum over splits, in split order
+__global__ __launch_bounds__(256) void fewch_reduce_kernel(const float* __restrict__ slabs, int splits, int Mp, int NP, int M, int N,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (M + 1) * N) return;
+  const int m = idx / N, n = idx - m * N;
+  const float* s = slabs + (size_t)m * NP + n;
+  const size_t pitch = (size_t)Mp * NP;
+  float a0 = 0.f;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {                   // eight loads in flight, added in split order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(k + u) * pitch];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a0 += v[u];
+  }
+  for (; k < splits; ++k) a0 += s[(size_t)k * pitch];
+  if (m < M) dw[(size_t)m * N + n] = a0;
+  else if (db) db[n] = a0;
+}
+
+// ---- host side ----
+struct FewchShape {
+  int M, Mp, mgroups, TN, NP, rows_per_img, rows_total, splits, xpitch, wo_pad, kpairs;
+  size_t lds;
+};
+
+static FewchShape fewch_shape(const a3d_conv_desc* d, bool pooled) {
+  FewchShape s;
+  s.M = d->r * d->s * d->c;
+  s.mgroups = (s.M + 1 + 127) / 128;                  // + the bias row
+  s.Mp = s.mgroups * 128;
+  s.TN = (d->k + 31) / 32;
+  s.NP = s.TN * 32;
+  s.rows_per_img = pooled ? (d->ho / 2) * 2 : d->ho;  // (a last odd row has no pool window: its gradient is zero)
+  s.rows_total = d->n * s.rows_per_img;
+  s.wo_pad = (d->wo + 1) / 2 * 2;
+  s.kpairs = s.wo_pad / 2;
+  const int reach = (s.wo_pad - 1) * d->stride * d->c + d->s * d->c;
+  s.xpitch = (std::max(d->w * d->c, reach) + 3) / 4 * 4;
+  // two resident blocks per CU; a block needs a few rows to amortise its slab (Mp x NP floats)
+  s.splits = std::max(1, std::min(s.rows_total / 4, 512 / s.mgroups));
+  s.lds = (size_t)(kFewRows * s.xpitch + s.wo_pad * s.NP + 4) * 4;
+  return s;
+}
+
+bool fewch_bwdf_applicable(const a3d_conv_desc* d, bool pooled) {
+  if (d->precision != A3D_PREC_F32 || d->c > 4 || d->pad_t || d->pad_l || d->ldx != d->c) return false;
+  if (d->k < 33 || d->k > 96) return false;
+  if (d->s * d->c < 27) return false;                 // kFewRows input rows per 128 rows of M
+  if ((d->ho - 1) * d->stride + d->r > d->h || (d->wo - 1) * d->stride + d->s > d->w) return false;   // VALID geometry
+  if (pooled && (d->ho < 2 || d->wo < 2)) return false;
+  const FewchShape s = fewch_shape(d, pooled);
+  if (s.rows_total < 1 || s.lds > 78 * 1024) return false;
+  return true;
+}
+
+size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled) {
+  const FewchShape s = fewch_shape(d, pooled);
+  return (size_t)s.splits * s.Mp * s.NP * 4 + 16;
+}
+
+template <int TN>
+static void fewch_launch(int src, const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
+  // above 64 KiB of dynamic LDS is possible: the attribute is per device and cheap, set on every call
+  if (src == FEW_SRC_DZ) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_DZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_DZ>), dim3(blocks), dim3(256), lds, st, p);
+  } else if (src == FEW_SRC_POOLED) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_POOLED>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_POOLED>), dim3(blocks), dim3(256), lds, st, p);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_POOLED_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_POOLED_BF16>), dim3(blocks), dim3(256), lds, st, p);
+  }
+}
+
+// src: FEW_SRC_*; dz / ldz: the gradient tensor (or the pooled gradient) and its pixel stride
+int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void* dz, int ldz, const void* pooled_act,
+                     const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st) {
+  const bool pooled = src != FEW_SRC_DZ;
+  const FewchShape s = fewch_shape(d, pooled);
+  FewchParams p{};
+  p.x = x; p.dz = dz; p.pooled = pooled_act; p.argmax = argmax;
+  p.slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 15) & ~(uintptr_t)15);
+  p.n = d->n; p.h = d->h; p.w = d->w; p.c = d->c; p.R = d->r; p.S = d->s; p.stride = d->stride; p.ho = d->ho; p.wo = d->wo;
+  p.N = d->k; p.M = s.M; p.Mp = s.Mp; p.NP = s.NP; p.ldz = ldz; p.ld_arg = ld_arg;
+  p.rows_per_img = s.rows_per_img; p.rows_total = s.rows_total; p.splits = s.splits; p.mgroups = s.mgroups;
+  p.xpitch = s.xpitch; p.rowlen = d->w * d->c; p.kpairs = s.kpairs; p.wo_pad = s.wo_pad;
+  p.xvec4 = p.rowlen % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  p.dvec4 = !pooled && d->k % 4 == 0 && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0;
+  const int blocks = s.splits * s.mgroups;
+  clear_stale_error();
+  if (s.TN == 3) fewch_launch<3>(src, p, blocks, s.lds, st);
+  else fewch_launch<2>(src, p, blocks, s.lds, st);
+  int rc = check_launch("fewch_bwd_filter");
+  if (rc != A3D_OK) return rc;
+  const int outs = (s.M + 1) * d->k;
+  clear_stale_error();
+  hipLaunchKernelGGL(fewch_reduce_kernel, dim3((outs + 255) / 256), dim3(256), 0, st, static_cast<const float*>(p.slabs), s.splits,
+                     s.Mp, s.NP, s.M, d->k, dw, db);
+  return check_launch("fewch_reduce");
+}
+
+}  // namespace a3d

@@ -63,8 +63,7 @@ static int env_int(const char* name, int dflt) {
 // The A3D_FORCE_* / A3D_NO_* / A3D_BF16_BN switches of the sweep and fuzz tools are consulted on every launch ONLY in
 // a process started with A3D_TUNING=1 (the tools set it); otherwise nothing below reads the environment after its first
 // call, and plans are cached per problem (plan_gemm).
-static bool tuning() { static const bool v = env_int("A3D_TUNING", 0) != 0; return v; }
-static int tune_int(const char* name, int dflt) { return tuning() ? env_int(name, dflt) : dflt; }
+// (tuning() / tune_int(): a3d_internal.h, capi.cc)
 static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
 // K-sliced stream-K is built and fuzzed but OFF by default: it removes the bwd-filter launches' fabric over-fetch and
 // costs 0.7 % of the step; A3D_SK_SLICED=1 turns it on
@@ -1221,9 +1220,35 @@ int a3d_conv2d_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz,
   return stencil1_bwd_both(d, x, dz, w, dw, db, dx, lddx, dx_bf16, relu_mask, state, ws, static_cast<hipStream_t>(stream));
 }
 
+// the few-channel layers' filter gradient from LDS-staged input rows (fewch.hip); A3D_FEWCH=0 (tuning processes) keeps the
+// window-run form of the generic kernel for A/B runs
+static bool fewch_wanted(const a3d_conv_desc* d, bool pooled) {
+  return !d->storage && fewch_bwdf_applicable(d, pooled) && tune_int("A3D_FEWCH", 1) != 0;
+}
+
+size_t a3d_conv2d_bwd_filter_pooled_ws_bytes(const a3d_conv_desc* d) {
+  if (check_desc(d) != A3D_OK || d->storage || !fewch_bwdf_applicable(d, true)) return 0;
+  return fewch_bwdf_ws_bytes(d, true);
+}
+
+int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const void* dpool, int ld_dpool, const void* pooled,
+                                 const uint8_t* argmax, int ld_argmax, int pooled_bf16, float* dw, float* db, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(x && dpool && argmax && dw, "conv2d_bwd_filter_pooled: null tensor");
+  A3D_CHECK_ARG(!d->storage && fewch_bwdf_applicable(d, true),
+                "conv2d_bwd_filter_pooled: an unpadded fp32 conv of <= 4 densely packed input channels and 33..96 filters");
+  A3D_CHECK_ARG(ld_dpool >= d->k && ld_argmax >= d->k, "conv2d_bwd_filter_pooled: pixel strides below the filter count");
+  if (fewch_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
+  return fewch_bwd_filter(d, x, pooled_bf16 ? 2 : 1, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws,
+                          static_cast<hipStream_t>(stream));
+}
+
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
+  if (fewch_wanted(d, false)) return fewch_bwdf_ws_bytes(d, false);
   GemmProblem g0 = bwd_f_problem(d);
   g0.ring_ok = bwd_f_ring_ok(d);
   GemmPlan plan = plan_gemm(g0, d->precision);
@@ -1248,6 +1273,10 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
     A3D_CHECK_ARG(!d->storage, "conv2d_bwd_filter: single-output-channel convs take float32 tensors");
     if (stencil1_bwdf_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return stencil1_bwd_filter(d, x, dz, dw, db, ws, static_cast<hipStream_t>(stream));
+  }
+  if (fewch_wanted(d, false)) {
+    if (fewch_bwdf_ws_bytes(d, false) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
+    return fewch_bwd_filter(d, x, 0, dz, d->ldy, nullptr, nullptr, 0, dw, db, ws, static_cast<hipStream_t>(stream));
   }
   GemmProblem g = bwd_f_problem(d);
   if (!aligned16(x)) g.avec = 1;

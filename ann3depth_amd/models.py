@@ -256,7 +256,7 @@ class MSDNReplica:
         self.dp0 = abuf(B, 27, 37, 96); self.dc0 = abuf(B, 55, 74, 96)
         # fine/third's backward writes df2 in the type fine/second's backward reads it: bf16 under 'bf16s' (round 5)
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = abuf(B, OUT_H, OUT_W, 64)
-        self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = buf(B, 110, 148, 63)
+        self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = None      # df1 (131 MB at B = 32): allocated only if the unfused path runs
         if self.bf16s:
             self.c4_32 = buf(B, 6, 8, 256)                                          # the fp32 copy of c4 dense_0's filter gradient reads
             self.dz0_16 = torch.empty((B, 4096), device=dev, dtype=torch.bfloat16)  # dense_0's bwd-data takes dz0 as bf16
@@ -283,6 +283,17 @@ class MSDNReplica:
             'fine/second/conv2d': D(B, OUT_H, OUT_W, 64, 64, 5, 5, 1, 'SAME'),
             'fine/third': D(B, OUT_H, OUT_W, 64, 1, 5, 5, 1, 'SAME'),
         }
+        # conv -> ReLU -> pool blocks on the 3-channel image: filter gradient straight from the POOLED map's gradient (MaxPoolGrad
+        # by index + ReluGrad while the kernel stages its operand): dc0 / df1 (50 / 131 MB at B = 32) are never written or read.
+        # fp32 arithmetic on the fp32 image in every precision mode.  A3D_FEWCH_POOLED=0: the separate launches.
+        self.d_few = {}
+        if os.environ.get('A3D_FEWCH_POOLED', '1') != '0' and dev.type == 'cuda':
+            for n, dd in (('coarse/conv/conv2d_0', ops.conv_desc(B, NET_H, NET_W, 3, 96, 11, 11, 4, 'VALID')),
+                          ('fine/first/conv2d', ops.conv_desc(B, NET_H, NET_W, 3, 63, 9, 9, 2, 'VALID'))):
+                if ops.conv2d_bwd_filter_pooled_supported(dd):
+                    self.d_few[n] = dd
+        if self.bf16s and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
+            self.d_few.pop('coarse/conv/conv2d_0', None)      # config 5: conv2d_0's filter gradient stays on the bf16 matrix cores
         # bf16 storage: per layer, which tensors of the forward / bwd-data / bwd-filter call are bf16 (ops.STORE_*), and
         # the bf16 copies of the kernels (refreshed whenever the fp32 masters change)
         self.store = {}
@@ -817,11 +828,15 @@ class MSDNReplica:
         n = 'coarse/conv/conv2d_1'
         dw(n, self.p0, self.dc1)
         self._bwd_data(n, self.dc1, self.dp0)
+        n = 'coarse/conv/conv2d_0'
+        if (self.pooled_fwd == 1 or self.pool0_fused) and n in self.d_few:
+            ops.conv2d_bwd_filter_pooled(self.d_few[n], self.x, self.dp0, self.p0, self.a0, self._g(n + '/kernel'),
+                                         self._g(n + '/bias'))
+            return
         if self.pooled_fwd == 1 or self.pool0_fused:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:
             self._pool_bwd(self.c0, self.dp0, self.dc0)
-        n = 'coarse/conv/conv2d_0'
         dw(n, self.x, self.dc0)
 
     # ---- backward of loss_fine wrt fine/* : src/models.py:333-338 ----
@@ -840,11 +855,17 @@ class MSDNReplica:
         n = 'fine/second/conv2d'
         self._bwd_filter(n, self.cat, self.df2)
         self._bwd_data(n, self.df2, self.dcat)
+        n = 'fine/first/conv2d'
+        if (self.pooled_fwd == 2 or self.bf16s) and n in self.d_few:          # reads channels 0..62 of dcat / cat
+            ops.conv2d_bwd_filter_pooled(self.d_few[n], self.x, self.dcat, self.cat, self.af1, self._g(n + '/kernel'),
+                                         self._g(n + '/bias'))
+            return
+        if self.df1 is None:
+            self.df1 = torch.empty((self.B, 110, 148, 63), device=self.device)
         if self.pooled_fwd == 2 or self.bf16s:                                 # both read channels 0..62 of dcat
             ops.maxpool2x2_bwd_idx(self.af1, self.cat, self.dcat, self.df1, relu_mask=True)
         else:
             self._pool_bwd(self.f1, self.dcat, self.df1, c=63)
-        n = 'fine/first/conv2d'
         self._bwd_filter(n, self.x, self.df1)
 
     # ---- one session.run(train_op) ----
@@ -969,6 +990,7 @@ class DCNFUnary:
         # written, one argmax byte per pool window serves the backward (see MSDNReplica.forward)
         self.fuse_pool = precision == 'fp32' and os.environ.get('A3D_NO_FUSED_POOL', '0') != '1'
         self.argmax, self.conv_hw = {}, {}
+        self.few_pooled = False
         self.act['x'] = buf(P, DCNF_PATCH, DCNF_PATCH, 3)
         h = DCNF_PATCH
         for n, ci, co, k in DCNF_CONVS:
@@ -985,6 +1007,8 @@ class DCNFUnary:
         for n, i, o, _ in DCNF_DENSES:
             self.act[n] = buf(P, o)
         self.z = self.act['dense_2']
+        self.few_pooled = (self.fuse_pool and dev.type == 'cuda' and os.environ.get('A3D_FEWCH_POOLED', '1') != '0'
+                           and ops.conv2d_bwd_filter_pooled_supported(self.desc['conv2d']))
 
     def var(self, name):
         return self.group.view(self.group.var, DCNF_PREFIX + name)
@@ -1053,6 +1077,13 @@ class DCNFUnary:
         inputs = {'conv2d': 'x', 'conv2d_1': 'conv2d/pool', 'conv2d_2': 'conv2d_1/pool', 'conv2d_3': 'conv2d_2',
                   'conv2d_4': 'conv2d_3'}
         for n, _, _, _ in reversed(DCNF_CONVS):
+            if n == 'conv2d' and self.fuse_pool and self.few_pooled:
+                # the first conv's filter gradient straight from the pooled map's gradient: its 768 x 90 x 90 x 64 pre-pool
+                # gradient (1.6 GB at batch 16) is never written
+                pool = a[n + '/pool']
+                ops.conv2d_bwd_filter_pooled(self.desc[n], a['x'], d.view(pool.shape), pool, self.argmax[n],
+                                             self.grad(n + '/kernel'), self.grad(n + '/bias'))
+                continue
             if n in DCNF_POOL_AFTER and self.fuse_pool:
                 hw, co = self.conv_hw[n], a[n + '/pool'].shape[-1]
                 if n not in self.dact:

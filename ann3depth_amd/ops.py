@@ -152,6 +152,22 @@ def conv2d_bwd_filter(d, x, dz, dw, db=None):
     return dw, db
 
 
+def conv2d_bwd_filter_pooled_supported(d):
+    return _lib.load().a3d_conv2d_bwd_filter_pooled_ws_bytes(ctypes.byref(d)) > 0
+
+
+def conv2d_bwd_filter_pooled(d, x, dpool, pooled, argmax, dw, db=None):
+    """Filter and bias gradient of a conv -> ReLU -> 2x2 max pool block from the gradient of the POOLED map: MaxPoolGrad (by the
+    recorded window positions) and ReluGrad (pooled > 0; pooled=None: none) happen while the kernel stages its operand."""
+    lib = _lib.load()
+    ws, n = _ws().get(lib.a3d_conv2d_bwd_filter_pooled_ws_bytes(ctypes.byref(d)), x.device)
+    assert pooled is None or (pooled.dtype == dpool.dtype and pooled.shape[-1] == dpool.shape[-1])
+    check(lib.a3d_conv2d_bwd_filter_pooled(ctypes.byref(d), _ptr(x), _ptr(dpool), dpool.shape[-1], _ptr(pooled), _ptr(argmax),
+                                           argmax.shape[-1], int(dpool.dtype == torch.bfloat16), _ptr(dw), _ptr(db), ws, n,
+                                           _stream()), 'a3d_conv2d_bwd_filter_pooled')
+    return dw, db
+
+
 _BOTH_STATE = {}
 
 

@@ -126,6 +126,19 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* MaxPoolGrad + ReluGrad + Conv2DBackpropFilter + BiasAddGrad of a conv -> ReLU -> 2x2 max pool block in one launch
+ * (src/models.py:211-213 conv2d_0, :241-243 fine/first, :64-65 DCNF's first conv; the gradients asked for at :314,:198):
+ * the gradient of the conv's pre-activation output is never materialised.  dpool / pooled: gradient wrt the POOLED map and
+ * the pooled activation itself [n, ho/2, wo/2, .] with pixel stride ld_dpool (float32, or bf16 when pooled_bf16 != 0);
+ * pooled == NULL: no ReluGrad.  argmax: the window positions a3d_conv2d_pool_fwd recorded, pixel stride ld_argmax.  A window
+ * hands its gradient to the position of its maximum if that maximum is > 0, exactly as a3d_maxpool2x2_bwd_idx followed by
+ * a3d_conv2d_bwd_filter.  Accepted: fp32 arithmetic, float32 x with <= 4 densely packed channels (ldx == c), no padding,
+ * 33..96 filters (a3d_conv2d_bwd_filter_pooled_ws_bytes returns 0 otherwise).  Sums are taken in a fixed order. */
+size_t a3d_conv2d_bwd_filter_pooled_ws_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const void* dpool, int ld_dpool, const void* pooled,
+                                 const uint8_t* argmax, int ld_argmax, int pooled_bf16, float* dw, float* db, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 /* Conv2DBackpropFilter + BiasAddGrad + Conv2DBackpropInput (+ the ReluGrad of the layer below) of a convolution with ONE
  * output channel, in one pass over x — fine/third (src/models.py:250-251; its gradients are asked for at :333-338 through
  * compute_gradients over the fine variables, the input gradient by the layer below): the same dz[q - tap + pad] enters

@@ -101,6 +101,55 @@ def test_conv2d_fwd_bwd(ops, n, h, w, c, k, ks, st, pad):
     assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < RTOL_F32
 
 
+POOLED_BWDF_CASES = [
+    # n, h, w, c, k, ksize, stride, ld (pixel stride of the pooled tensors), argmax stride
+    (2, 35, 48, 3, 96, 11, 4, 96, 96),       # conv2d_0 kind: 7 x 10 conv outputs, the odd last row has no pool window
+    (2, 40, 52, 3, 63, 9, 2, 64, 63),        # fine/first kind: 63 filters inside the 64-channel concat buffer
+    (3, 30, 35, 3, 64, 11, 1, 64, 64),       # DCNF's first conv kind (stride 1), 20 x 25 outputs
+    (1, 228, 304, 3, 96, 11, 4, 96, 96),     # conv2d_0 itself, one image
+]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,ld,lda', POOLED_BWDF_CASES)
+def test_conv2d_bwd_filter_with_the_pool_gradient_fused(ops, n, h, w, c, k, ks, st, ld, lda, dtype):
+    """a3d_conv2d_bwd_filter_pooled (MaxPoolGrad by index + ReluGrad + Conv2DBackpropFilter + BiasAddGrad in one launch) against
+    the float64 oracle on the gradient the separate path materialises: dz[window position argmax] = dpool * (pooled > 0)."""
+    rng = np.random.default_rng(900 + h * w + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, 'VALID')
+    assert ops.conv2d_bwd_filter_pooled_supported(d)
+    ph, pw = d.ho // 2, d.wo // 2
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    pooled = rng.standard_normal((n, ph, pw, ld)).astype(np.float32)          # about half of the maxima <= 0: ReluGrad is live
+    dpool = rng.standard_normal((n, ph, pw, ld)).astype(np.float32)
+    arg = rng.integers(0, 4, (n, ph, pw, lda)).astype(np.uint8)
+    pooled_d, dpool_d = dev(pooled).to(tdt), dev(dpool).to(tdt)
+    pooled_r, dpool_r = pooled_d.float().cpu().numpy(), dpool_d.float().cpu().numpy()
+    dz = np.zeros((n, d.ho, d.wo, k), np.float64)
+    g = np.where(pooled_r[..., :k] > 0, dpool_r[..., :k], 0.0)
+    for pos in range(4):
+        dz[:, pos >> 1:2 * ph:2, pos & 1:2 * pw:2, :] = np.where(arg[..., :k] == pos, g, 0.0)
+    dw_ref, db_ref = T.conv2d_bwd_filter(x.astype(np.float64), dz, (ks, ks, c, k), st, 'VALID')
+    xd = dev(x)
+    dw = torch.full((ks, ks, c, k), float('nan'), device='cuda')
+    db = torch.full((k,), float('nan'), device='cuda')
+    ops.conv2d_bwd_filter_pooled(d, xd, dpool_d, pooled_d, torch.from_numpy(arg).cuda(), dw, db)
+    assert rel_l2(dw.cpu().numpy(), dw_ref) < RTOL_F32
+    assert rel_l2(db.cpu().numpy(), db_ref) < RTOL_F32
+    # the same launch twice gives the same bits (fixed summation order)
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_bwd_filter_pooled(d, xd, dpool_d, pooled_d, torch.from_numpy(arg).cuda(), dw2, None)
+    np.testing.assert_array_equal(dw.cpu().numpy(), dw2.cpu().numpy())
+    # and it equals the two launches it replaces to rounding (float32 sources only: the separate kernel takes no bf16 here)
+    if dtype == 'f32' and ld == k and lda == k:
+        dzd = torch.empty((n, d.ho, d.wo, k), device='cuda')
+        ops.maxpool2x2_bwd_idx(torch.from_numpy(arg).cuda(), pooled_d, dpool_d, dzd, relu_mask=True)
+        dw3 = torch.empty_like(dw)
+        ops.conv2d_bwd_filter(d, xd, dzd, dw3, None)
+        assert rel_l2(dw3.cpu().numpy(), dw.cpu().numpy()) < 1e-5
+
+
 BOTH_CASES = [
     # n, h, w, c, padding, ldx, lddx          (single-output-channel 5x5 convs: fine/third, src/models.py:250-251)
     (2, 21, 30, 64, 'SAME', 64, 64),
