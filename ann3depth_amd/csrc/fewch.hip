@@ -41,8 +41,13 @@ struct FewchParams {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int TN, int SRC>
+constexpr int kPX = 6;               // 16-byte pieces of input rows per thread and output row (6 rows x 228 pieces / 256 threads)
+constexpr int kPDPlain = 10;         // ... of the dz row (148 pixels x 16 pieces)
+constexpr int kPDPooled = 5;         // 4-channel groups of the pooled row (74 windows x 16 groups), three registers each
+
+template <int TN, int SRC, bool VEC>
 __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p) {
+  constexpr int kPD = SRC == FEW_SRC_DZ ? kPDPlain : kPDPooled;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                                   // [kFewRows][xpitch]
   float* dzs = xs + kFewRows * p.xpitch;              // [wo_pad][NP]
@@ -74,90 +79,175 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   for (int b = 0; b < TN; ++b)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
-  const int row_lo = (int)((long)split * p.rows_total / p.splits), row_hi = (int)((long)(split + 1) * p.rows_total / p.splits);
-  for (int row = row_lo; row < row_hi; ++row) {
-    const int img = row / p.rows_per_img, oy = row - img * p.rows_per_img;
-    __syncthreads();                                  // the previous row's MFMAs have read their operands
-    // ---- input rows oy*stride + rlo .. + nr-1 -> xs
-    {
-      const float* src = p.x + ((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen;
-      if (p.xvec4) {
-        const int r4 = p.rowlen >> 2, total = nr * r4;
-        for (int e = tid; e < total; e += 256) {
-          const int rr = e / r4, q = e - rr * r4;
-          *reinterpret_cast<f32x4*>(xs + rr * p.xpitch + 4 * q) = *reinterpret_cast<const f32x4*>(src + (size_t)rr * p.rowlen + 4 * q);
-        }
-      } else {
-        const int total = nr * p.rowlen;
-        for (int e = tid; e < total; e += 256) {
-          const int rr = e / p.rowlen, q = e - rr * p.rowlen;
-          xs[rr * p.xpitch + q] = src[(size_t)rr * p.rowlen + q];
-        }
-      }
-    }
-    // ---- the row of dz -> dzs[pixel][NP]
-    if constexpr (SRC == FEW_SRC_DZ) {
-      const float* src = static_cast<const float*>(p.dz) + ((size_t)img * p.ho + oy) * p.wo * p.ldz;
-      if (p.dvec4) {
-        const int n4 = p.N >> 2, total = p.wo * n4;
-        for (int e = tid; e < total; e += 256) {
-          const int px = e / n4, q = e - px * n4;
-          *reinterpret_cast<f32x4*>(dzs + px * p.NP + 4 * q) = *reinterpret_cast<const f32x4*>(src + (size_t)px * p.ldz + 4 * q);
-        }
-      } else {
-        const int total = p.wo * p.N;
-        for (int e = tid; e < total; e += 256) {
-          const int px = e / p.N, q = e - px * p.N;
-          dzs[px * p.NP + q] = src[(size_t)px * p.ldz + q];
-        }
-      }
+
+  // ---- staging in two halves: fetch() puts a row's operands into registers (issued behind the first MFMAs of the previous
+  //      row), commit() writes them to LDS behind the barrier that ends those MFMAs.  Every load is a raw buffer load at
+  //      `row base + per-thread constant`; a piece the thread does not have carries the out-of-range offset (zeros, no branch).
+  const int r4 = p.rowlen >> 2;
+  const int xtotal = nr * r4;                          // 16-byte pieces of the input rows
+  const int n4 = (p.N + 3) >> 2;
+  const int pw = p.wo >> 1, ph = p.ho >> 1;
+  const int dtotal = SRC == FEW_SRC_DZ ? p.wo * n4 : pw * n4;
+  constexpr int ESZ = SRC == FEW_SRC_POOLED_BF16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, (unsigned long long)p.n * p.h * p.rowlen * 4ull);
+  const unsigned long long dz_elems = SRC == FEW_SRC_DZ ? (unsigned long long)p.n * p.ho * p.wo * p.ldz
+                                                         : (unsigned long long)p.n * ph * pw * p.ldz;
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(static_cast<const float*>(p.dz), dz_elems * ESZ);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(static_cast<const float*>(p.pooled ? p.pooled : p.dz), dz_elems * ESZ);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const float*>(p.argmax),
+                                              SRC == FEW_SRC_DZ ? 0ull : (unsigned long long)p.n * ph * pw * p.ld_arg);
+  int xdst[kPX];
+  uint32_t xoff[kPX];
+#pragma unroll
+  for (int i = 0; i < kPX; ++i) {
+    const int e = tid + i * 256, rr = e / r4, q = e - rr * r4;
+    xdst[i] = e < xtotal ? rr * p.xpitch + 4 * q : -1;
+    xoff[i] = e < xtotal ? (uint32_t)((rr * p.rowlen + 4 * q) * 4) : kOOB;
+  }
+  int ddst[kPD];                                       // LDS float index of the piece (pooled: of its even pixel), -1: none
+  uint32_t doff[kPD], aoff[kPD], dlive[kPD];           // byte offsets into dz (or dpool / pooled) and argmax; channels of the piece below N
+#pragma unroll
+  for (int i = 0; i < kPD; ++i) {
+    const int e = tid + i * 256, px = e / n4, q = 4 * (e - px * n4);
+    const bool ok = e < dtotal;
+    ddst[i] = ok ? (SRC == FEW_SRC_DZ ? px : 2 * px) * p.NP + q : -1;
+    doff[i] = ok ? (uint32_t)((px * p.ldz + q) * ESZ) : kOOB;
+    aoff[i] = ok ? (uint32_t)(px * p.ld_arg + q) : kOOB;
+    dlive[i] = (uint32_t)max(0, min(4, p.N - q));
+  }
+  f32x4 xv[kPX], dv[kPD], av[kPD];
+  uint32_t argv[kPD];
+  auto load4 = [&](const __amdgpu_buffer_rsrc_t r, uint32_t off) -> f32x4 {
+    if constexpr (SRC == FEW_SRC_POOLED_BF16) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const bf16x4 g = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+      return f32x4{(float)g[0], (float)g[1], (float)g[2], (float)g[3]};
     } else {
-      // MaxPoolGrad + ReluGrad while staging: window (oy/2, px) hands its gradient to position argmax, if the maximum was > 0
-      const int pw = p.wo >> 1, ph = p.ho >> 1;
-      const size_t prow = ((size_t)img * ph + (oy >> 1)) * pw;
-      const int want = (oy & 1) * 2;
-      const int total = pw * p.N;
-      for (int e = tid; e < total; e += 256) {
-        const int px = e / p.N, q = e - px * p.N;
-        const size_t o = (prow + px) * p.ldz + q;
-        float g, act = 1.f;
-        if constexpr (SRC == FEW_SRC_POOLED_BF16) {
-          g = (float)static_cast<const __bf16*>(p.dz)[o];
-          if (p.pooled) act = (float)static_cast<const __bf16*>(p.pooled)[o];
-        } else {
-          g = static_cast<const float*>(p.dz)[o];
-          if (p.pooled) act = static_cast<const float*>(p.pooled)[o];
-        }
-        const int a = p.argmax[(prow + px) * p.ld_arg + q];
-        g = act > 0.f ? g : 0.f;
-        dzs[(2 * px) * p.NP + q] = a == want ? g : 0.f;
-        dzs[(2 * px + 1) * p.NP + q] = a == want + 1 ? g : 0.f;
-      }
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
     }
+  };
+  auto fetch = [&](int row) {
+    const int img = row / p.rows_per_img, oy = row - img * p.rows_per_img;
+    const uint32_t xbase = (uint32_t)((((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen) * 4);
+#pragma unroll
+    for (int i = 0; i < kPX; ++i)
+      if (i * 256 < xtotal) xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xbase + xoff[i]), 0, 0));
+    if constexpr (SRC == FEW_SRC_DZ) {
+      const uint32_t dbase = (uint32_t)((((size_t)img * p.ho + oy) * p.wo * p.ldz) * 4);
+#pragma unroll
+      for (int i = 0; i < kPD; ++i)
+        if (i * 256 < dtotal) {
+          if constexpr (VEC) {
+            dv[i] = load4(rd, dbase + doff[i]);
+          } else {                                     // pixel strides / filter counts off the 16-byte grid: element by element
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              dv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (uint32_t)e < dlive[i] ? (int)(dbase + doff[i] + 4 * e) : (int)kOOB, 0, 0));
+          }
+        }
+    } else {
+      const size_t prow = ((size_t)img * ph + (oy >> 1)) * pw;
+      const uint32_t dbase = (uint32_t)(prow * p.ldz * ESZ), abase = (uint32_t)(prow * p.ld_arg);
+#pragma unroll
+      for (int i = 0; i < kPD; ++i)
+        if (i * 256 < dtotal) {
+          dv[i] = load4(rd, dbase + doff[i]);
+          if (p.pooled) av[i] = load4(rp, dbase + doff[i]);
+          if constexpr (VEC) {                         // (here: argmax rows of whole, aligned 4-byte groups)
+            argv[i] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(abase + aoff[i]), 0, 0);
+          } else {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              w |= (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(ra, (uint32_t)e < dlive[i] ? (int)(abase + aoff[i] + e) : (int)kOOB, 0, 0) << (8 * e);
+            argv[i] = w;
+          }
+        }
+    }
+  };
+  auto commit = [&](int row) {
+#pragma unroll
+    for (int i = 0; i < kPX; ++i)
+      if (i * 256 < xtotal && xdst[i] >= 0) *reinterpret_cast<f32x4*>(xs + xdst[i]) = xv[i];
+    if constexpr (SRC == FEW_SRC_DZ) {
+#pragma unroll
+      for (int i = 0; i < kPD; ++i)
+        if (i * 256 < dtotal && ddst[i] >= 0) *reinterpret_cast<f32x4*>(dzs + ddst[i]) = dv[i];
+    } else {
+      // MaxPoolGrad + ReluGrad: window (oy/2, px) hands its gradient to position argmax, if the maximum was > 0
+      const int oy = row % p.rows_per_img;
+      const uint32_t want = (uint32_t)(oy & 1) * 2u;
+#pragma unroll
+      for (int i = 0; i < kPD; ++i)
+        if (i * 256 < dtotal && ddst[i] >= 0) {
+          f32x4 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool live = (uint32_t)e < dlive[i] && (!p.pooled || av[i][e] > 0.f);
+            const float g = live ? dv[i][e] : 0.f;
+            const uint32_t a = (argv[i] >> (8 * e)) & 0xffu;
+            lo[e] = a == want ? g : 0.f;
+            hi[e] = a == want + 1u ? g : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dzs + ddst[i]) = lo;
+          *reinterpret_cast<f32x4*>(dzs + ddst[i] + p.NP) = hi;
+        }
+    }
+  };
+
+  const int row_lo = (int)((long)split * p.rows_total / p.splits), row_hi = (int)((long)(split + 1) * p.rows_total / p.splits);
+  if (row_lo < row_hi) fetch(row_lo);
+  for (int row = row_lo; row < row_hi; ++row) {
+    __syncthreads();                                  // the previous row's MFMAs have read their operands
+    commit(row);
     __syncthreads();
-    // ---- 2 pixels per MFMA: A = x at the lane's tap for pixel 2kp + lh, B = dz[2kp + lh][column li]
+    // ---- 2 pixels per MFMA: A = x at the lane's tap for pixel 2kp + lh, B = dz[2kp + lh][column li]; groups of four
+    //      pixel pairs, the next group's operands read from LDS while this group's MFMAs run; the NEXT row's global loads
+    //      are issued behind the first group's MFMAs
     const float* ap = xs + a_off;
     const float* bp = dzs + lh * p.NP + li;
-    int kp = 0;
-    for (; kp + 4 <= p.kpairs; kp += 4) {
-      float a[4], b[4][TN];
+    const int groups = p.kpairs >> 2;
+    const bool more = row + 1 < row_hi;
+    float a[2][4], b[2][4][TN];
+    auto read = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        a[u] = ap[u * a_step];
+        a[buf][u] = ap[u * a_step];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) b[u][t] = bp[u * 2 * p.NP + t * 32];
+        for (int t = 0; t < TN; ++t) b[buf][u][t] = bp[u * 2 * p.NP + t * 32];
       }
+      ap += 4 * a_step;
+      bp += 8 * p.NP;
+    };
+    auto mul = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
-      ap += 4 * a_step;
-      bp += 8 * p.NP;
+        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][u], b[buf][u][t], acc[t], 0, 0, 0);
+    };
+    int g = 0;
+    if (groups >= 2) {
+      read(0);
+      read(1);
+      mul(0);
+      if (more) fetch(row + 1);
+      if (groups > 2) read(0);
+      mul(1);
+      for (g = 2; g + 2 <= groups; g += 2) {
+        read(1);
+        mul(0);
+        if (g + 2 < groups) read(0);
+        mul(1);
+      }
+      if (g < groups) mul(0);
+      g = groups;
+    } else if (more) {
+      fetch(row + 1);
     }
-    for (; kp < p.kpairs; ++kp) {
-      const float a = ap[0];
+    for (int kp = g * 4; kp < p.kpairs; ++kp) {
+      const float av1 = ap[0];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[t * 32], acc[t], 0, 0, 0);
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bp[t * 32], acc[t], 0, 0, 0);
       ap += a_step;
       bp += 2 * p.NP;
     }
@@ -214,7 +304,7 @@ static FewchShape fewch_shape(const a3d_conv_desc* d, bool pooled) {
   const int reach = (s.wo_pad - 1) * d->stride * d->c + d->s * d->c;
   s.xpitch = (std::max(d->w * d->c, reach) + 3) / 4 * 4;
   // two resident blocks per CU; a block needs a few rows to amortise its slab (Mp x NP floats)
-  s.splits = std::max(1, std::min(s.rows_total / 4, 512 / s.mgroups));
+  s.splits = std::max(1, std::min(s.rows_total / 4, tune_int("A3D_FEWCH_BLOCKS", 512) / s.mgroups));
   s.lds = (size_t)(kFewRows * s.xpitch + s.wo_pad * s.NP + 4) * 4;
   return s;
 }
@@ -225,8 +315,12 @@ bool fewch_bwdf_applicable(const a3d_conv_desc* d, bool pooled) {
   if (d->s * d->c < 27) return false;                 // kFewRows input rows per 128 rows of M
   if ((d->ho - 1) * d->stride + d->r > d->h || (d->wo - 1) * d->stride + d->s > d->w) return false;   // VALID geometry
   if (pooled && (d->ho < 2 || d->wo < 2)) return false;
+  if ((d->w * d->c) % 4 != 0) return false;           // input rows as whole 16-byte pieces
   const FewchShape s = fewch_shape(d, pooled);
   if (s.rows_total < 1 || s.lds > 78 * 1024) return false;
+  // the per-thread staging registers: kPX pieces of input rows, kPD pieces of the dz row (or 4-channel groups of the pooled row)
+  if (kFewRows * (d->w * d->c / 4) > kPX * 256) return false;
+  if ((pooled ? d->wo / 2 : d->wo) * ((d->k + 3) / 4) > (pooled ? kPDPooled : kPDPlain) * 256) return false;
   return true;
 }
 
@@ -235,19 +329,18 @@ size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled) {
   return (size_t)s.splits * s.Mp * s.NP * 4 + 16;
 }
 
+template <int TN, int SRC, bool VEC>
+static void fewch_launch3(const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
+  // above 64 KiB of dynamic LDS is possible: the attribute is per device and cheap, set on every call
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, SRC, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            80 * 1024);
+  hipLaunchKernelGGL((fewch_bwdf_kernel<TN, SRC, VEC>), dim3(blocks), dim3(256), lds, st, p);
+}
 template <int TN>
 static void fewch_launch(int src, const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
-  // above 64 KiB of dynamic LDS is possible: the attribute is per device and cheap, set on every call
-  if (src == FEW_SRC_DZ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_DZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_DZ>), dim3(blocks), dim3(256), lds, st, p);
-  } else if (src == FEW_SRC_POOLED) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_POOLED>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_POOLED>), dim3(blocks), dim3(256), lds, st, p);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, FEW_SRC_POOLED_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipLaunchKernelGGL((fewch_bwdf_kernel<TN, FEW_SRC_POOLED_BF16>), dim3(blocks), dim3(256), lds, st, p);
-  }
+  if (src == FEW_SRC_DZ) p.dvec4 ? fewch_launch3<TN, FEW_SRC_DZ, true>(p, blocks, lds, st) : fewch_launch3<TN, FEW_SRC_DZ, false>(p, blocks, lds, st);
+  else if (src == FEW_SRC_POOLED) p.dvec4 ? fewch_launch3<TN, FEW_SRC_POOLED, true>(p, blocks, lds, st) : fewch_launch3<TN, FEW_SRC_POOLED, false>(p, blocks, lds, st);
+  else p.dvec4 ? fewch_launch3<TN, FEW_SRC_POOLED_BF16, true>(p, blocks, lds, st) : fewch_launch3<TN, FEW_SRC_POOLED_BF16, false>(p, blocks, lds, st);
 }
 
 // src: FEW_SRC_*; dz / ldz: the gradient tensor (or the pooled gradient) and its pixel stride
@@ -263,7 +356,9 @@ int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void
   p.rows_per_img = s.rows_per_img; p.rows_total = s.rows_total; p.splits = s.splits; p.mgroups = s.mgroups;
   p.xpitch = s.xpitch; p.rowlen = d->w * d->c; p.kpairs = s.kpairs; p.wo_pad = s.wo_pad;
   p.xvec4 = p.rowlen % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-  p.dvec4 = !pooled && d->k % 4 == 0 && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0;
+  // whole aligned 16-byte pieces of dz (plain source) / 4-byte groups of argmax bytes (pooled sources)
+  p.dvec4 = pooled ? (d->k % 4 == 0 && ld_arg % 4 == 0 && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0)
+                   : (d->k % 4 == 0 && ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
   const int blocks = s.splits * s.mgroups;
   clear_stale_error();
   if (s.TN == 3) fewch_launch<3>(src, p, blocks, s.lds, st);

@@ -1240,6 +1240,9 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
   A3D_CHECK_ARG(!d->storage && fewch_bwdf_applicable(d, true),
                 "conv2d_bwd_filter_pooled: an unpadded fp32 conv of <= 4 densely packed input channels and 33..96 filters");
   A3D_CHECK_ARG(ld_dpool >= d->k && ld_argmax >= d->k, "conv2d_bwd_filter_pooled: pixel strides below the filter count");
+  A3D_CHECK_ARG(ld_dpool % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(dpool) & (pooled_bf16 ? 7 : 15)) == 0 &&
+                    (reinterpret_cast<uintptr_t>(pooled) & (pooled_bf16 ? 7 : 15)) == 0,
+                "conv2d_bwd_filter_pooled: x, dpool and pooled in whole aligned 4-channel groups (ld_dpool % 4 == 0)");
   if (fewch_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
   return fewch_bwd_filter(d, x, pooled_bf16 ? 2 : 1, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws,
                           static_cast<hipStream_t>(stream));
@@ -1274,7 +1277,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
     if (stencil1_bwdf_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return stencil1_bwd_filter(d, x, dz, dw, db, ws, static_cast<hipStream_t>(stream));
   }
-  if (fewch_wanted(d, false)) {
+  if (fewch_wanted(d, false) && aligned16(x)) {
     if (fewch_bwdf_ws_bytes(d, false) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return fewch_bwd_filter(d, x, 0, dz, d->ldy, nullptr, nullptr, 0, dw, db, ws, static_cast<hipStream_t>(stream));
   }

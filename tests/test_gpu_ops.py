@@ -54,6 +54,7 @@ CONV_CASES = [
     (24, 26, 30, 5, 7, 5, 2, 'SAME'),        # ... and with scalar operands (Cin, Cout not multiples of 4), 5x5 taps
     # few-channel forward straight from L2 (conv3.hip): run starts 12 / 4 / 32 bytes apart, K tails, Cout off the tile width
     (2, 30, 35, 3, 64, 11, 1, 'VALID'),      # DCNF's first conv kind (stride 1: runs start 12 bytes apart)
+    (2, 30, 36, 3, 64, 11, 1, 'VALID'),      # ... with rows of whole 16-byte pieces: the filter gradient from LDS-staged rows (fewch.hip)
     (3, 23, 29, 1, 40, 5, 1, 'VALID'),       # one channel: runs start 4 bytes apart, run of 5 -> 8 floats
     (2, 20, 27, 4, 70, 3, 2, 'VALID'),       # four channels, 70 filters (three column tiles, 26 of 96 columns idle)
     (65, 15, 15, 2, 33, 7, 4, 'VALID'),      # 65 images of 3 x 3 outputs: row tiles crossing images, M tail
@@ -105,7 +106,7 @@ POOLED_BWDF_CASES = [
     # n, h, w, c, k, ksize, stride, ld (pixel stride of the pooled tensors), argmax stride
     (2, 35, 48, 3, 96, 11, 4, 96, 96),       # conv2d_0 kind: 7 x 10 conv outputs, the odd last row has no pool window
     (2, 40, 52, 3, 63, 9, 2, 64, 63),        # fine/first kind: 63 filters inside the 64-channel concat buffer
-    (3, 30, 35, 3, 64, 11, 1, 64, 64),       # DCNF's first conv kind (stride 1), 20 x 25 outputs
+    (3, 30, 36, 3, 64, 11, 1, 64, 64),       # DCNF's first conv kind (stride 1), 20 x 26 outputs
     (1, 228, 304, 3, 96, 11, 4, 96, 96),     # conv2d_0 itself, one image
 ]
 
