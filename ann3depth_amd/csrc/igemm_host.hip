@@ -1226,6 +1226,25 @@ static bool fewch_wanted(const a3d_conv_desc* d, bool pooled) {
   return !d->storage && fewch_bwdf_applicable(d, pooled) && tune_int("A3D_FEWCH", 1) != 0;
 }
 
+// the launch as the timing list sees it (a3d_timing_*): lds_dma 4 = fewch_bwdf_kernel, ms includes the slab reduction
+static int fewch_timed(const a3d_conv_desc* d, const float* x, int src, const void* dz, int ldz, const void* pooled_act,
+                       const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st) {
+  TimingSlot slot{};
+  {
+    a3d_timing_record& r = slot.rec;
+    r.mode = MODE_BWD_F; r.prec = A3D_PREC_F32; r.bm = 128; r.bn = (d->k + 31) / 32 * 32; r.waves_m = 4; r.nwaves = 4; r.bk = 2;
+    r.avec = 1; r.bvec = 1; r.splitk = 1; r.lds_dma = 4;
+    r.m = d->r * d->s * d->c; r.n = d->k; r.k = d->n * d->ho * d->wo; r.ms = 0.f;
+    r.flops = 2.0 * r.m * r.n * r.k;
+  }
+  const bool timed = timing_wanted(slot.rec);
+  int rc;
+  if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+  rc = fewch_bwd_filter(d, x, src, dz, ldz, pooled_act, argmax, ld_arg, dw, db, ws, st);
+  if (timed) timing_end(slot, st);
+  return rc;
+}
+
 size_t a3d_conv2d_bwd_filter_pooled_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK || d->storage || !fewch_bwdf_applicable(d, true)) return 0;
   return fewch_bwdf_ws_bytes(d, true);
@@ -1244,8 +1263,8 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
                     (reinterpret_cast<uintptr_t>(pooled) & (pooled_bf16 ? 7 : 15)) == 0,
                 "conv2d_bwd_filter_pooled: x, dpool and pooled in whole aligned 4-channel groups (ld_dpool % 4 == 0)");
   if (fewch_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
-  return fewch_bwd_filter(d, x, pooled_bf16 ? 2 : 1, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws,
-                          static_cast<hipStream_t>(stream));
+  return fewch_timed(d, x, pooled_bf16 ? 2 : 1, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws,
+                     static_cast<hipStream_t>(stream));
 }
 
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
@@ -1279,7 +1298,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   }
   if (fewch_wanted(d, false) && aligned16(x)) {
     if (fewch_bwdf_ws_bytes(d, false) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
-    return fewch_bwd_filter(d, x, 0, dz, d->ldy, nullptr, nullptr, 0, dw, db, ws, static_cast<hipStream_t>(stream));
+    return fewch_timed(d, x, 0, dz, d->ldy, nullptr, nullptr, 0, dw, db, ws, static_cast<hipStream_t>(stream));
   }
   GemmProblem g = bwd_f_problem(d);
   if (!aligned16(x)) g.avec = 1;

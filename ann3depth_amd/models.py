@@ -141,6 +141,7 @@ class MSDNReplica:
         # layers' filters, fine/second's output (fine/third is a single-output-channel stencil on fp32), and the
         # tensors of the dense layers' small side (x, y, dz, dx: a few MB; dense_0's 201 MB of weights are read as bf16).
         self.bf16s = precision == 'bf16s'
+        self.fine_first_bf16 = False
         if self.bf16s:
             precision = 'bf16'
         self.precision = precision
@@ -321,6 +322,9 @@ class MSDNReplica:
             # ... except where fine/first has no backward (coarse phase, and once nothing trains any more): there its forward
             # runs on the bf16 pipe from a 4-channel bf16 copy of the image (8-byte pixels: window runs 16 bytes apart),
             # 0.41 -> 0.10 ms at B = 64, conv + ReLU + max pool in one launch (f1 is never written there either)
+            # round 5: also where it trains (fine phase) — config 5's arithmetic is bf16 throughout, the fp32 few-channel kernel
+            # took 0.38 ms of that phase's 1.73 at B = 64.  A3D_BF16S_FINE1=0: the fp32 conv + pool there, as before.
+            self.fine_first_bf16 = os.environ.get('A3D_BF16S_FINE1', '1') != '0'
             self.x4 = torch.empty((B, NET_H, NET_W, 4), device=dev, dtype=torch.bfloat16)
             self.w4 = torch.zeros((9, 9, 4, 63), device=dev)
             self.d4 = ops.with_storage(ops.conv_desc(B, NET_H, NET_W, 4, 63, 9, 9, 2, 'VALID', ldy=64, precision='bf16'),
@@ -667,7 +671,7 @@ class MSDNReplica:
         # fine phase: the main queue has nothing left to run beside fine/second (the coarse backward does not exist there and
         # the fine backward waits for this forward), so the launch takes the whole CU instead of leaving room (A3D_HINT_SHARE_CU)
         self._alone = ('fine/second/conv2d',) if phase == 2 else ()
-        if self.bf16s and phase in (1, 3) and not (self.fuse_pool and phase in (1, 2, 3)):
+        if self.bf16s and (phase in (1, 3) or self.fine_first_bf16) and not (self.fuse_pool and phase in (1, 2, 3)):
             # the fine network's 4-channel bf16 image, on the main stream: the side stream's chain (fine/first .. loss) is
             # the longer one at the join, the main stream idles there
             ops.pad_channels_bf16(self.x, self.x4)
@@ -700,6 +704,8 @@ class MSDNReplica:
                     self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
                 elif self.bf16s and phase in (1, 3):        # conv + ReLU + pool in one launch: f1 is never written
                     ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu')
+                elif self.bf16s and self.fine_first_bf16:   # the same launch where the layer trains: it also records the window positions
+                    ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu', self.af1)
                 elif self.bf16s:
                     self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
                 else:

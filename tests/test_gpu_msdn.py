@@ -440,7 +440,7 @@ def test_msdn_fused_dense_adam_equals_kept_gradients(models):
     assert not models.MSDNReplica(B, params=params, beta2=0.999, keep_dense_grads=False)._fused_dense_adam()
 
 
-BF16S_DEPTH_TOL = 5e-2     # bf16 operands AND bf16-stored activations (8 significant bits each, ~10 layers deep)
+import bf16s_tol      # noqa: E402  (tests/bf16s_tol.py: per-tensor-class tolerances of precision 'bf16s', 1.5 x the observed error)
 
 
 def test_msdn_bf16_storage_at_config5_batch(models):
@@ -448,7 +448,9 @@ def test_msdn_bf16_storage_at_config5_batch(models):
     fp32 masters, accumulators, gradients and Adam slots (precision 'bf16s').  Stated tolerance: depth maps within 5e-2
     rel-L2 of the fp32 oracle (the plain-bf16 mode's own bound, tests above; the oracle runs on 4 of the 64 images —
     samples are independent), within 2e-2 of the fp32-storage bf16 mode (what storing activations as bf16 adds), and every
-    filter / bias gradient within 6e-2 of the oracle's fp32 backward of the stored activations, both trained phases."""
+    filter / bias gradient within 6e-2 of the oracle's fp32 backward of the stored activations, both trained phases.
+    Round 5: the blanket 5e-2 / 6e-2 are replaced by per-tensor-class bounds of 1.5 x what the error
+    actually is (tests/bf16s_tol.py; the values are printed: run with -s)."""
     B = 64
     img, dep, keep = synth(B, 6464)
     params = O.init_params(3000)
@@ -460,8 +462,10 @@ def test_msdn_bf16_storage_at_config5_batch(models):
     assert net.wcopy['coarse/dense/dense_0'].dtype == torch.bfloat16 and net.groups['CoarseDense'].var.dtype == torch.float32
     sl = [0, 1, 62, 63]
     a = O.forward(params, img[sl], dep[sl], keep[sl])
-    assert rel(net.coarse[sl].cpu().numpy(), a['coarse']) < BF16S_DEPTH_TOL
-    assert rel(net.fine[sl].cpu().numpy(), a['fine']) < BF16S_DEPTH_TOL
+    seen = {}
+    for k in ('coarse', 'fine'):
+        seen['depth/' + k] = e = rel(getattr(net, k)[sl].cpu().numpy(), a[k])
+        assert e < bf16s_tol.DEPTH[k], (k, e)
     assert np.isfinite(float(out['coarse_loss'])) and np.isfinite(float(out['fine_loss']))
     ref = models.MSDNReplica(B, params=params, precision='bf16')
     ref.step(*args)
@@ -473,15 +477,24 @@ def test_msdn_bf16_storage_at_config5_batch(models):
     a_gpu = gpu_activations(net)
     a_gpu['keep_mask'] = keep
     for n, gref in O.backward_coarse(params, a_gpu).items():
-        assert rel(net.grad(n).cpu().numpy(), gref) < 6e-2, n
-    # the fine phase runs too (fine/second's filter gradient takes a bf16 activation against an fp32 gradient)
-    net2 = models.MSDNReplica(8, params=params, precision='bf16s', global_step=2000000 // 8)
-    a8 = [t[:8] for t in args]
-    net2.step(*a8)
+        seen['grad/' + n] = e = rel(net.grad(n).cpu().numpy(), gref)
+        assert e < bf16s_tol.grad_tol(n), (n, e)
+    del net, ref
+    # the fine phase at the same batch (round 5: fine/first's forward on the bf16 image form records the window positions, its
+    # filter gradient comes straight from the pooled map's gradient, fine/second's backward reads a bf16 df2)
+    net2 = models.MSDNReplica(B, params=params, precision='bf16s', global_step=2000000 // B)
+    net2.step(*args)
     torch.cuda.synchronize()
+    a2 = O.forward(params, img[sl], dep[sl], keep[sl])
+    seen['depth/fine (fine phase)'] = e = rel(net2.fine[sl].cpu().numpy(), a2['fine'])
+    assert e < bf16s_tol.DEPTH['fine'], e
     a_gpu = gpu_activations(net2)
     for n, gref in O.backward_fine(params, a_gpu).items():
-        assert rel(net2.grad(n).cpu().numpy(), gref) < 6e-2, n
+        seen['grad/' + n] = e = rel(net2.grad(n).cpu().numpy(), gref)
+        assert e < bf16s_tol.grad_tol(n), (n, e)
+    print('\nprecision bf16s, B = 64, rel-L2 against the fp32 oracle:')
+    for k, v in seen.items():
+        print(f'  {k:45s} {v:.3e}')
 
 
 @pytest.mark.parametrize('global_step', [0, 2000000 // 2])

@@ -1005,6 +1005,52 @@ def test_lds_dma_kernel_with_the_max_pool_in_its_epilogue(ops, n, h, w, c, k, ks
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize('kind,n', [('conv2d_1', 8), ('conv2d_0', 4)])
+def test_pooled_epilogues_of_config5_against_the_oracle(ops, kind, n):
+    """config 5's first two layers (conv2d_0: float32 image, bf16 pooled map; conv2d_1 at its own
+    geometry: bf16 x / w / pooled map in the LDS-DMA kernel's epilogue) meet the ORACLE at layer tolerance, not only through
+    the network test: pooled map vs maxpool2x2(relu(conv2d(x, w) + b)) in float64 on the operands as stored (x, w rounded to
+    bf16 where they are bf16 tensors) at 4e-3 (one bf16 rounding of the output), and the argmax bytes vs the oracle's first
+    maximum wherever the window's two largest values differ by more than a bf16 rounding step of the larger."""
+    rng = np.random.default_rng(len(kind) + n)
+    bf = torch.bfloat16
+    if kind == 'conv2d_1':
+        h, w, c, k, ks, st, pad = 27, 37, 96, 256, 5, 1, 'SAME'
+        store = ops.STORE_X | ops.STORE_W | ops.STORE_Y
+        x = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).cuda().to(bf)
+        wt = torch.from_numpy((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)).cuda().to(bf)
+    else:
+        h, w, c, k, ks, st, pad = 228, 304, 3, 96, 11, 4, 'VALID'
+        store = ops.STORE_Y
+        x = dev(rng.random((n, h, w, c)).astype(np.float32))
+        wt = dev((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32))
+    b = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+    d = ops.with_storage(ops.conv_desc(n, h, w, c, k, ks, ks, st, pad, precision='bf16'), store)
+    ph, pw = d.ho // 2, d.wo // 2
+    one = torch.full((n, ph, pw, k), float('nan'), device='cuda', dtype=bf)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x, wt, b, one, 'relu', arg)
+    torch.cuda.synchronize()
+    # the oracle on what the kernel multiplies: bf16 operands (conv2d_0 rounds its float32 image and filter to bf16 on the way in)
+    xr = x.to(bf).double().cpu().numpy()
+    wr = wt.to(bf).double().cpu().numpy()
+    y = T.conv2d_fwd(xr, wr, b.double().cpu().numpy(), st, pad, relu=True)
+    yw = y[:, :2 * ph, :2 * pw, :].reshape(n, ph, 2, pw, 2, k).transpose(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4)
+    pooled = yw.max(-1)
+    got = one.float().cpu().numpy()
+    assert rel_l2(got, pooled) < 4e-3
+    first = (yw == pooled[..., None]).argmax(-1)
+    srt = np.sort(yw, axis=-1)
+    clear = (srt[..., 3] - srt[..., 2]) > np.abs(srt[..., 3]) * 2.0 ** -7          # the runner-up is more than a bf16 step away
+    assert clear.mean() > 0.5
+    a = arg.cpu().numpy()
+    assert int(a.max()) <= 3
+    assert (a[clear] == first[clear]).all()
+    # and everywhere the recorded position holds the window's maximum to a bf16 rounding step
+    at = np.take_along_axis(yw, a[..., None].astype(np.int64), -1)[..., 0]
+    assert rel_l2(at, pooled) < 4e-3
+
+
 @pytest.mark.parametrize('n,h,w,k,ks,st', [(6, 100, 132, 96, 11, 4), (5, 61, 80, 63, 9, 2)])
 def test_few_channel_conv_with_bf16_pooled_map_from_a_float32_image(ops, n, h, w, k, ks, st):
     """Config 5's conv2d_0 (src/models.py:211-213): float32 image and filter, bf16 arithmetic, conv + ReLU + 2x2 max pool in one
