@@ -234,7 +234,7 @@ static Conv3Shape conv3_shape(const a3d_conv_desc* d) {
 }
 
 bool conv3_applicable(const a3d_conv_desc* d, const void* x) {
-  static const bool off = getenv("A3D_NO_CONV3") && atoi(getenv("A3D_NO_CONV3")) != 0;
+  static const bool off = tune_int("A3D_NO_CONV3", 0) != 0;      // A/B aid (tuning processes only)
   if (off) return false;
   if (d->precision != A3D_PREC_F32 || d->c > 4 || d->pad_t || d->pad_l || d->ldx != d->c) return false;
   if (d->storage & ~A3D_STORE_Y_BF16) return false;

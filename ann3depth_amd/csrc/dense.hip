@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
 }
 
 static int pick_span(int extent, int groups, int quantum) {
-  static const int target = getenv("A3D_DENSE_BLOCKS") ? atoi(getenv("A3D_DENSE_BLOCKS")) : 512;      // tuning aid
+  const int target = 512;                              // two resident blocks per CU
   const int want = std::max(1, target / std::max(1, groups));
   int span = (extent + want - 1) / want;
   span = std::max(quantum, (span + quantum - 1) / quantum * quantum);
@@ -788,22 +788,19 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1_ex(int m, int k, int n, const float
                 "dense_bwd_filter_adam: only the reference's frozen optimizer (beta2 == 1); otherwise call "
                 "a3d_dense_bwd_filter and a3d_adam_apply_tf1");
   clear_stale_error();
-  static const int cw = getenv("A3D_DW_CW") ? atoi(getenv("A3D_DW_CW")) : 0;      // tuning aid
   const uintptr_t slots = reinterpret_cast<uintptr_t>(m_w) | reinterpret_cast<uintptr_t>(dz);
   const dim3 rows_grid((n + 511) / 512, (k + 31) / 32);
   // stream form: two blocks per CU, each walking down its share of the row groups; 512 columns per block for batches of
   // at most 32 rows, 256 for up to 64
-  static const bool no_stream = getenv("A3D_NO_DENSE_STREAM") && atoi(getenv("A3D_NO_DENSE_STREAM"));   // tuning aid
-  static const int gpb_env = getenv("A3D_DW_GPB") ? atoi(getenv("A3D_DW_GPB")) : 0;                       // tuning aid
-  // A3D_DW_SLIM (read once; default on): the slim form for batches of at most 32 rows — measured in the step, beside the
-  // fine network's hinted GEMMs
-  static const int slim_env = getenv("A3D_DW_SLIM") ? atoi(getenv("A3D_DW_SLIM")) : 1;      // 2: layers of at most 2^25 weights only
-  const bool slim = slim_env != 0 && m <= 32 && n % 2 == 0 && (slim_env != 2 || (long)k * n <= (1L << 25));
+  static const bool no_stream = tune_int("A3D_NO_DENSE_STREAM", 0) != 0;   // A/B aid (tuning processes only)
+  // the slim form (124 registers, four blocks per CU) for batches of at most 32 rows: measured in the step, beside the fine
+  // network's hinted GEMMs
+  const bool slim = m <= 32 && n % 2 == 0;
   const bool bf_cols = precision == A3D_PREC_BF16 && m > 32;      // the bf16 form: 512 columns per block at any batch
   const int bcols = slim ? 256 : ((m <= 32 || bf_cols) ? 512 : 256), colblocks = (n + bcols - 1) / bcols;
-  const int gpb = gpb_env > 0 ? gpb_env : std::max(1, ((k + 31) / 32 * colblocks + (slim ? 1023 : 511)) / (slim ? 1024 : 512));
+  const int gpb = std::max(1, ((k + 31) / 32 * colblocks + (slim ? 1023 : 511)) / (slim ? 1024 : 512));
   const dim3 stream_grid(colblocks, ((k + 31) / 32 + gpb - 1) / gpb);
-  const bool stream_ok = m <= 64 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream && cw != 4 && cw != 2;
+  const bool stream_ok = m <= 64 && k % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !no_stream;
   const hipStream_t hst = static_cast<hipStream_t>(stream);
 #define A3D_DW_STREAM(CWV, MBV, ...)                                                                                     \
   hipLaunchKernelGGL((dense_dw_adam_stream_kernel<CWV, MBV, ##__VA_ARGS__>), stream_grid, dim3(256), 0, hst, x, dz, var_w, m_w, v_w, var_b, \
@@ -817,18 +814,14 @@ extern "C" int a3d_dense_bwd_filter_adam_tf1_ex(int m, int k, int n, const float
   else if (stream_ok && m <= 32 && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 1);
   else if (stream_ok && n % 2 == 0 && (slots & 7) == 0) A3D_DW_STREAM(2, 2);
 #undef A3D_DW_STREAM
-  else if (cw != 4 && cw != 2 && n % 4 == 0 && (slots & 15) == 0)
+  else if (n % 4 == 0 && (slots & 15) == 0)
     hipLaunchKernelGGL(dense_dw_adam_rows_kernel<4>, rows_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz, var_w,
                        m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale);
-  else if (cw != 4 && cw != 2 && n % 2 == 0 && (slots & 7) == 0)
+  else if (n % 2 == 0 && (slots & 7) == 0)
     hipLaunchKernelGGL(dense_dw_adam_rows_kernel<2>, rows_grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dz, var_w,
                        m_w, v_w, var_b, m_b, v_b, m, k, n, 1.f - beta1, grad_scale);
-  else if (cw != 2)
-    hipLaunchKernelGGL((dense_dw_kernel<true, 4>), dim3((n + 127) / 128, (k + 127) / 128), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, dz, nullptr, nullptr, var_w, m_w, v_w, var_b, m_b, v_b, m, k, n,
-                       1.f - beta1, grad_scale);
   else
-    hipLaunchKernelGGL((dense_dw_kernel<true, 2>), dim3((n + 63) / 64, (k + 127) / 128), dim3(256), 0,
+    hipLaunchKernelGGL((dense_dw_kernel<true, 4>), dim3((n + 127) / 128, (k + 127) / 128), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, dz, nullptr, nullptr, var_w, m_w, v_w, var_b, m_b, v_b, m, k, n,
                        1.f - beta1, grad_scale);
   return check_launch("dense_dw_adam");

@@ -54,20 +54,17 @@ static const size_t kStampBytes = (size_t)8 << 20;
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Tuning aid (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-// A/B switches of the staging fast paths (tools/bench_layers.py); read once
+// Tuning aids (tools/sweep_igemm.py): A3D_FORCE_CFG / A3D_FORCE_SPLITK pin the tile config / split-K factor.  Every switch
+// below goes through tune_int(): none of them is read in a process that was not started with A3D_TUNING=1.
+// A/B switches of the staging fast paths (tools/bench_layers.py); read once per tuning process
 // The A3D_FORCE_* / A3D_NO_* / A3D_BF16_BN switches of the sweep and fuzz tools are consulted on every launch ONLY in
 // a process started with A3D_TUNING=1 (the tools set it); otherwise nothing below reads the environment after its first
 // call, and plans are cached per problem (plan_gemm).
 // (tuning() / tune_int(): a3d_internal.h, capi.cc)
-static bool env_flag_no_uni() { static const bool v = env_int("A3D_NO_UNI", 0) != 0; return v; }
+static bool env_flag_no_uni() { static const bool v = tune_int("A3D_NO_UNI", 0) != 0; return v; }
 // K-sliced stream-K is built and fuzzed but OFF by default: it removes the bwd-filter launches' fabric over-fetch and
 // costs 0.7 % of the step; A3D_SK_SLICED=1 turns it on
-static bool env_flag_no_sliced() { static const bool v = env_int("A3D_SK_SLICED", 0) == 0; return v; }
+static bool env_flag_no_sliced() { static const bool v = tune_int("A3D_SK_SLICED", 0) == 0; return v; }
 // K-sliced stream-K (SkSpace): a block's share must fit inside one slice of one tile's K range (at most two partial
 // tiles per block = its two slab slots) and a tile may not have more contributors than the fixup lists (96).
 static bool sk_sliced_ok(int mode, long tiles, int nk, int grid, long* meet_out) {
@@ -80,8 +77,8 @@ static bool sk_sliced_ok(int mode, long tiles, int nk, int grid, long* meet_out)
   if (meet_out) *meet_out = meet;
   return true;
 }
-static bool env_flag_no_streamk() { static const bool v = env_int("A3D_NO_STREAMK", 0) != 0; return v; }
-static bool env_flag_no_kperm() { static const bool v = env_int("A3D_NO_KPERM", 0) != 0; return v; }
+static bool env_flag_no_streamk() { static const bool v = tune_int("A3D_NO_STREAMK", 0) != 0; return v; }
+static bool env_flag_no_kperm() { static const bool v = tune_int("A3D_NO_KPERM", 0) != 0; return v; }
 
 // ---- opt-in launch timing (a3d_timing_*) ----
 struct TimingSlot {
@@ -125,7 +122,7 @@ static const int kFirstGldsCfg = 9;
 // (128 rows, two blocks per CU, where 256-row tiles would leave a third of the chip idle); never split (a launch that small
 // stays on igemm_bf16's split-K).  A3D_RING=0 turns the kernel off, A3D_RING_CFG pins a tile (tuning processes).
 static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
-  static const bool off = env_int("A3D_RING", 1) == 0;
+  static const bool off = tune_int("A3D_RING", 1) == 0;
   if (!g.ring_ok || (g.plain && g.mode != MODE_FWD)) return false;      // (plain = the forward with the 2x2 max pool fused: never split)
   if (g.mode != MODE_BWD_F && g.M <= 64 && g.N >= 1024 && g.K >= 1024) {      // (not under A3D_RING: bf16 x / dz have no other kernel)
     // a dense layer of a small batch: a weight stream.  64-row tiles of 128 columns, K split until ~512 blocks (three per
@@ -142,10 +139,10 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
     pl.ws_bytes = pl.splitk > 1 ? (size_t)pl.splitk * g.M * g.N * 4 : 0;
     return true;
   }
-  if (off) return false;
+  if (off && !g.plain) return false;              // (a pooled forward on bf16 inputs has no other kernel: ADVICE r4)
   if (g.mode == MODE_BWD_F) {
     // filter gradient: few tiles (M = r s Cin rows) over a long pixel axis — 256-row tiles, split-K until every CU has one block
-    static const bool off_f = env_int("A3D_RING_BWDF", 1) == 0;
+    static const bool off_f = tune_int("A3D_RING_BWDF", 1) == 0;
     if (off_f || g.M < 512 || g.N < 64 || g.K < 64 * 64) return false;      // (short pixel axes stay with igemm_bf16's finer tiles)
     int cfg = g.N <= 64 ? 1 : (g.N % 256 == 0 ? 2 : 0);
     const int forced = tune_int("A3D_RING_CFG", -1);
@@ -483,7 +480,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const ReducePar
 int launch_splitk_reduce(const ReduceParams& r, hipStream_t st) {
   const size_t total = (size_t)r.M * r.N;
   clear_stale_error();
-  static const bool no_wide = env_int("A3D_NO_WIDE_REDUCE", 0) != 0;      // A/B aid
+  static const bool no_wide = tune_int("A3D_NO_WIDE_REDUCE", 0) != 0;      // A/B aid
   if (!no_wide && r.vec4 && r.splitk >= 16 && total / 4 <= (size_t)1 << 16) {
     const unsigned blocks_c = (unsigned)((total / 4 + 15) / 16), blocks_b = r.dbias_out ? (unsigned)((r.N + 15) / 16) : 0u;
     hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(blocks_c + blocks_b), dim3(256), 0, st, r, blocks_c);
@@ -527,7 +524,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   g_stamp_grid = grid;
 #endif
   p.dbg = tune_int("A3D_DBG", 0);
-  static const bool plan_log = env_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
+  static const bool plan_log = tune_int("A3D_PLAN_LOG", 0) != 0;       // tuning aid: one line per launch on stderr
   if (plan_log)
     fprintf(stderr, "a3d plan: mode %d M %d N %d K %d -> %s %d (%dx%d) splitk %d streamk %d%s grid %u\n", mode, p.M, p.N, p.K,
             plan.ring ? "ring" : "cfg", plan.ring ? plan.ring - 1 : plan.cfg, plan.ring ? kRingCfgs[plan.ring - 1].bm : kCfgs[plan.cfg].bm,
@@ -1272,10 +1269,13 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
   if (fewch_wanted(d, false)) return fewch_bwdf_ws_bytes(d, false);
   GemmProblem g0 = bwd_f_problem(d);
-  g0.ring_ok = bwd_f_ring_ok(d);
-  GemmPlan plan = plan_gemm(g0, d->precision);
-  size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);
-  if (plan.ring) need = plan.ws_bytes + colsum_bf16_ws_bytes(d->k);
+  GemmPlan plan = plan_gemm(g0, d->precision);       // the plan without the LDS-DMA kernel: a launch may fall back to it (a dw
+  size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);      // off the 16-byte grid: ADVICE r4)
+  if (bwd_f_ring_ok(d)) {
+    g0.ring_ok = 1;
+    GemmPlan pr = plan_gemm(g0, d->precision);
+    if (pr.ring) need = std::max(need, pr.ws_bytes + colsum_bf16_ws_bytes(d->k));
+  }
   RunForm rf;
   if (run_form_ok(d, nullptr, &rf, true)) {
     GemmProblem g = bwd_f_problem(d);

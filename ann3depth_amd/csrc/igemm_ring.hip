@@ -9,10 +9,10 @@ namespace a3d {
 // index, BM, BN, WAVES_M  (keep in step with kRingCfgs in igemm_host.hip)
 #define A3D_RING_CFGS(X) X(0, 256, 128, 4) X(1, 256, 64, 8) X(2, 256, 256, 4) X(3, 128, 128, 4) X(5, 512, 64, 8) X(6, 64, 128, 2)
 
-// A3D_RING_M16 (tuning aid, read once): 0 = every launch on v_mfma_f32_32x32x16_bf16, 1 = on 16x16x32 wherever that form
+// A3D_RING_M16 (tuning processes, read once): 0 = every launch on v_mfma_f32_32x32x16_bf16, 1 = on 16x16x32 wherever that form
 // exists (wave tiles of at least 32 x 64), unset = the shipped choice per tile (ring_m16_default)
 static int ring_m16_env() {
-  static const int v = getenv("A3D_RING_M16") ? atoi(getenv("A3D_RING_M16")) : -1;
+  static const int v = tune_int("A3D_RING_M16", -1);
   return v;
 }
 
@@ -20,12 +20,15 @@ template <int MODE, int BM, int BN, int WAVES_M, bool C16, bool M16>
 static int launch_ring_one(IgemmParams& p, unsigned grid, hipStream_t st) {
   using Cfg = RingCfg<MODE, BM, BN, WAVES_M>;
   auto kern = igemm_ring_kernel<MODE, BM, BN, WAVES_M, C16, M16>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the raised LDS limit is a per-DEVICE attribute of the kernel: one flag per device (a benign race at worst sets it twice)
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cfg::LDS_BYTES);
     if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   clear_stale_error();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p);

@@ -234,8 +234,10 @@ class MSDNReplica:
         # activations
         self.x = buf(B, NET_H, NET_W, 3)
         self.t = buf(B, OUT_H, OUT_W, 1)
-        self.c0 = abuf(B, 55, 74, 96); self.p0 = abuf(B, 27, 37, 96)
-        self.c1 = abuf(B, 27, 37, 256); self.p1 = abuf(B, 13, 18, 256)
+        # c0 / c1 exist only where a forward writes them: never under 'bf16s' with its pools in the conv epilogues (83 MB at B = 64)
+        self.c0 = None if self.pool0_fused else abuf(B, 55, 74, 96)
+        self.c1 = None if self.pool1_fused else abuf(B, 27, 37, 256)
+        self.p0 = abuf(B, 27, 37, 96); self.p1 = abuf(B, 13, 18, 256)
         self.c2 = abuf(B, 13, 18, 384); self.c3 = abuf(B, 13, 18, 384); self.c4 = abuf(B, 6, 8, 256)
         self.drop = buf(B, 4096)
         self.coarse = buf(B, OUT_H, OUT_W, 1)
@@ -264,7 +266,12 @@ class MSDNReplica:
             # dense_1 ([4096, 4070]: rows of 8140 bytes, not whole 16-byte pieces) on the LDS-DMA kernel too: a bf16 copy of
             # its kernel with rows of 4072 elements (the two pad columns zero, the bias padded alike); x (= drop), dz and y cross
             # to that layout and back by a3d_cast_rows (0.5 - 1 MB each).  Its master weights, gradient and ApplyAdam stay fp32.
-            self.dense1_bf16 = os.environ.get('A3D_BF16S_DENSE1', '1') != '0'
+            # bf16 x / dz into the dense layers: the LDS-DMA kernel takes them as a weight stream of at most 64 rows (ring_plan,
+            # igemm_host.hip); a larger batch keeps the dense layers' small side fp32 (B = 65..383 had no kernel)
+            self.dense_bf16_x = B <= 64
+            self.dense1_bf16 = os.environ.get('A3D_BF16S_DENSE1', '1') != '0' and self.dense_bf16_x
+            if not self.dense_bf16_x:
+                self.dc4_32 = buf(B, 6, 8, 256)
             NP = (OUT_H * OUT_W + 7) // 8 * 8
             self.w1pad = torch.zeros((4096, NP), device=dev, dtype=torch.bfloat16)
             self.b1pad = torch.zeros((1, NP), device=dev)
@@ -641,7 +648,8 @@ class MSDNReplica:
         if self.pooled_fwd != phase and not (self.bf16s and which == 'f1') and not (self.pool1_fused and which == 'c1') and not (self.pool0_fused and which == 'c0'):
             return full
         if full is None:          # 'bf16s': the tensor does not exist at all
-            full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'f1': (110, 148, 63)}[which], device=self.device)
+            full = torch.empty((pooled.shape[0],) + {'c0': (55, 74, 96), 'c1': (27, 37, 256), 'f1': (110, 148, 63)}[which],
+                               device=self.device)
         pooled = pooled.float()
         c = arg.shape[-1]
         out = torch.zeros_like(full)
@@ -714,24 +722,20 @@ class MSDNReplica:
         # (bf16 storage: fine/first runs 0.27 ms beside the dense layers; started after conv2d_4 it left the main queue
         # waiting 41 us at the join: 1.43 -> 1.39 ms; fp32: 26 us at the join, 2.93 -> 2.91 ms).  One layer earlier still is
         # slower again (1.41 / 2.94 ms), two layers 1.44: MFMA-bound grids beside each other only trade CU slots.
-        early = int(os.environ.get('A3D_SIDE_EARLY', '1'))
-        if early == 3:
-            fine_first()
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
-        if early == 2:
-            fine_first()
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
-        if early == 1:
-            fine_first()
+        fine_first()
         self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
-        if early == 0:
-            fine_first()
         if not self._sharded_in_flight():
             self.settle()           # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
-        if self.bf16s:              # dense_0 streams its 100 MB bf16 weight copy against c4 as it stands (bf16): LDS-DMA kernel
+        if self.bf16s and self.dense_bf16_x:   # dense_0 streams its 100 MB bf16 weight copy against c4 as it stands (bf16): LDS-DMA kernel
             ops.dense_fwd_ex(self.c4.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
                              drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W | ops.STORE_X)
+        elif self.bf16s:            # more than 64 rows: the LDS-DMA kernel's weight-stream tiles do not apply; fp32 x, bf16 weight copy
+            ops.cast_bf16(self.c4, self.c4_32)
+            ops.dense_fwd_ex(self.c4_32.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
+                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W)
         else:
             ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
@@ -796,14 +800,18 @@ class MSDNReplica:
         else:
             ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
         n = 'coarse/dense/dense_0'
-        if self.bf16s:              # the filter gradient takes c4 on the dense layers' fp32 side
-            ops.cast_bf16(self.c4, self.c4_32)
+        if self.bf16s and self.dense_bf16_x:   # the filter gradient takes c4 on the dense layers' fp32 side
+            ops.cast_bf16(self.c4, self.c4_32)      # (B > 64: the forward already made this copy)
         flat = (self.c4_32 if self.bf16s else self.c4).view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
-        if self.bf16s:              # dz0 -> bf16 (1 MB); dc4 leaves as bf16, masked by the bf16 c4: no fp32 detour
+        if self.bf16s and self.dense_bf16_x:   # dz0 -> bf16 (1 MB); dc4 leaves as bf16, masked by the bf16 c4: no fp32 detour
             ops.cast_bf16(self.dz0, self.dz0_16)
             ops.dense_bwd_data_ex(self.dz0_16, self.wcopy[n], self.dc4.view(B, -1), mask=self.c4.view(B, -1), scale=1.0,
                                   precision='bf16', storage=ops.STORE_W | ops.STORE_X | ops.STORE_Y)
+        elif self.bf16s:            # B > 64: fp32 dz0 and mask against the bf16 weight copy, dc4 through an fp32 buffer
+            ops.dense_bwd_data_ex(self.dz0, self.wcopy[n], self.dc4_32.view(B, -1), mask=flat, scale=1.0, precision='bf16',
+                                  storage=ops.STORE_W)
+            ops.cast_bf16(self.dc4_32, self.dc4)
         else:
             ops.dense_bwd_data(self.dz0, self._v(n + '/kernel'), self.dc4.view(B, -1), mask=flat, scale=1.0)
         if after_dense is not None:

@@ -12,9 +12,9 @@
  *   - Process-wide state, all of it host-side: the thread-local error message; a cache of launch plans keyed by
  *     problem shape (mutex-guarded, never invalidated: a plan depends on nothing else); the launch-timing list of
  *     a3d_timing_enable / a3d_timing_collect, which is ONE list for every stream and thread — enable it from one
- *     place, and not during graph capture (it records hipEvents); and the environment switches, read once per process
- *     (A3D_NO_STREAMK, A3D_NO_UNI, A3D_NO_KPERM, A3D_PLAN_LOG, A3D_TUNING; with A3D_TUNING=1 the sweep tools'
- *     A3D_FORCE_* switches are read on every launch instead).
+ *     place, and not during graph capture (it records hipEvents).  The environment: A3D_TUNING is read once; every other
+ *     switch (A/B and sweep aids: INTEGRATION.md section 5) is read ONLY in a process started with A3D_TUNING=1 — without
+ *     it the library never calls getenv and a plan depends on the problem alone.
  *   - `ws` is caller-provided scratch of at least the size the matching *_ws_bytes() query returns.
  *   - Return value: 0 (A3D_OK) or a negative A3D_E* code; a3d_last_error() gives a thread-local message.
  *     Nothing throws across the ABI and nothing calls exit().

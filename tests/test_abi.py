@@ -173,3 +173,24 @@ def test_planner_handles_every_layer_shape_on_the_host():
     for m, k, n in [(32, 12288, 4096), (32, 4096, 4070), (64, 12288, 4096), (768, 12544, 128), (768, 128, 16), (768, 16, 1)]:
         for fn in (lib.a3d_dense_fwd_ws_bytes, lib.a3d_dense_bwd_data_ws_bytes, lib.a3d_dense_bwd_filter_ws_bytes):
             assert 0 <= fn(m, k, n) <= 200 << 20
+
+
+def test_the_library_reads_its_environment_only_behind_the_tuning_gate():
+    """VERDICT r4 item 7 / SURVEY 8b ("keeps no global state"): in the shipped liba3d.so, getenv is called from a3d::tuning()
+    (A3D_TUNING itself, once) and a3d::tune_int() (which returns its default without touching the environment unless the
+    process was started with A3D_TUNING=1) and from nowhere else; and no source file but capi.cc spells getenv."""
+    dis = subprocess.run(['objdump', '-d', '-C', '--no-show-raw-insn', '-j', '.text', _lib.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    fn, callers = None, set()
+    for line in dis.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(.*)>:$', line)
+        if m:
+            fn = m.group(1)
+        elif 'getenv@plt' in line or re.search(r'call.*<getenv', line):
+            callers.add(fn)
+    assert callers, 'no getenv call found at all: did the disassembly work?'
+    assert all(c.startswith('a3d::tuning()') or c.startswith('a3d::tune_int(') for c in callers), callers
+    csrc = os.path.join(ROOT, 'ann3depth_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.cc', '.h')) and name != 'capi.cc':
+            assert 'getenv' not in open(os.path.join(csrc, name)).read(), name

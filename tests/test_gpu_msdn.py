@@ -497,6 +497,31 @@ def test_msdn_bf16_storage_at_config5_batch(models):
         print(f'  {k:45s} {v:.3e}')
 
 
+def test_bf16_storage_above_64_rows_per_batch(models):
+    """precision 'bf16s' at a batch of 65..383 — the dense layers' bf16 x / dz form is the LDS-DMA kernel's
+    64-row weight stream only; above that the replica keeps the dense layers' small side float32 (weight copies bf16).  B = 96,
+    both trained phases, at the mode's tolerances."""
+    B = 96
+    img, dep, keep = synth(B, 9696, 240, 320)
+    params = O.init_params(3000)
+    args = [torch.from_numpy(a).cuda() for a in (img, dep, keep)]
+    sl = [0, 47, 95]
+    a = O.forward(params, img[sl], dep[sl], keep[sl])
+    for gs in (0, 2000000 // B):
+        net = models.MSDNReplica(B, params=params, precision='bf16s', global_step=gs)
+        assert not net.dense_bf16_x and net.keep_dense_grads
+        out = net.step(*args)
+        torch.cuda.synchronize()
+        assert out['phase'] == (1 if gs == 0 else 2)
+        for k in ('coarse', 'fine'):
+            assert rel(getattr(net, k)[sl].cpu().numpy(), a[k]) < bf16s_tol.DEPTH[k], k
+        a_gpu = gpu_activations(net)
+        a_gpu['keep_mask'] = keep
+        for n, gref in (O.backward_coarse if gs == 0 else O.backward_fine)(params, a_gpu).items():
+            assert rel(net.grad(n).cpu().numpy(), gref) < bf16s_tol.grad_tol(n), n
+        del net
+
+
 @pytest.mark.parametrize('global_step', [0, 2000000 // 2])
 def test_bf16_storage_weight_copies_follow_the_masters(models, global_step):
     """under precision 'bf16s' every conv / dense_0 kernel has a bf16 copy beside its fp32 master.  With
