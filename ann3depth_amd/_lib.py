@@ -44,6 +44,8 @@ SIGNATURES = {
     'a3d_conv2d_bwd_data': (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
     'a3d_conv2d_bwd_filter_ws_bytes': (c_size_t, [_D]),
     'a3d_conv2d_bwd_filter': (c_int, [_D, _P, _P, _P, _P, _P, c_size_t, _P]),
+    'a3d_conv2d_fwd_prepared_filter_bytes': (c_size_t, [_D]),
+    'a3d_conv2d_fwd_prepare_filter': (c_int, [_D, _P, _P, c_size_t, _P]),
     'a3d_conv2d_bwd_filter_pooled_ws_bytes': (c_size_t, [_D]),
     'a3d_conv2d_bwd_filter_pooled': (c_int, [_D, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     'a3d_conv2d_bwd_both_supported': (c_int, [_D]),

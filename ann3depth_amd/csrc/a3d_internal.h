@@ -95,7 +95,8 @@ int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void
 // ---- few-channel forward convolution straight from L2 (conv3.hip) ----
 bool conv3_applicable(const a3d_conv_desc* d, const void* x);
 size_t conv3_ws_bytes(const a3d_conv_desc* d);
+int conv3_pack(const a3d_conv_desc* d, const float* w, float* wp, hipStream_t st);
 int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
-              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st);
+              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 
 }  // namespace a3d

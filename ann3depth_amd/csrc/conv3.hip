@@ -276,16 +276,28 @@ static int conv3_launch(const Conv3Params& p, bool pool, unsigned blocks, bool s
   return A3D_OK;
 }
 
-int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
-              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st) {
+// the filter as conv3_fwd_kernel reads it: [K/4][Np][4] (a3d_conv2d_fwd_prepare_filter, or per call into the workspace)
+int conv3_pack(const a3d_conv_desc* d, const float* w, float* wp, hipStream_t st) {
   const Conv3Shape s = conv3_shape(d);
-  if (!ws || ws_bytes < conv3_ws_bytes(d)) return set_error(A3D_EWORKSPACE, "conv3_fwd: need %zu workspace bytes", conv3_ws_bytes(d));
-  float* wp = static_cast<float*>(ws);
   clear_stale_error();
   hipLaunchKernelGGL(conv3_pack_kernel, dim3(std::min((s.Kp * s.Np + 255) / 256, 1024)), dim3(256), 0, st, w, wp, d->r, s.RL,
                      s.RLP, d->k, s.Np, s.Kp);
-  int rc = check_launch("conv3_pack");
-  if (rc != A3D_OK) return rc;
+  return check_launch("conv3_pack");
+}
+
+int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
+              int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+  const Conv3Shape s = conv3_shape(d);
+  const float* wp = w;                                 // prepared: w already is the packed filter
+  int rc;
+  if (!prepared) {
+    if (!ws || ws_bytes < conv3_ws_bytes(d)) return set_error(A3D_EWORKSPACE, "conv3_fwd: need %zu workspace bytes", conv3_ws_bytes(d));
+    rc = conv3_pack(d, w, static_cast<float*>(ws), st);
+    if (rc != A3D_OK) return rc;
+    wp = static_cast<const float*>(ws);
+  } else if (reinterpret_cast<uintptr_t>(w) & 15) {
+    return set_error(A3D_EINVAL, "conv3_fwd: a prepared filter is 16-byte aligned");
+  }
   Conv3Params p{};
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.argmax = argmax;
   p.x_bytes = (unsigned long long)d->n * d->h * d->w * d->c * 4ull;

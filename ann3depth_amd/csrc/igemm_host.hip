@@ -850,9 +850,16 @@ __global__ __launch_bounds__(256) void pad_filter_bf16_kernel(const float* w, __
     wp[i] = (__bf16)((q < rl && col < n) ? w[(size_t)(rr * rl + q) * n + col] : 0.f);
   }
 }
+static int pad_filter_bf16(const a3d_conv_desc* d, const float* w, __bf16* wp, hipStream_t st) {
+  const int rl = d->s * 4, rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
+  clear_stale_error();
+  hipLaunchKernelGGL(pad_filter_bf16_kernel, dim3((d->r * rlp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rl, rlp,
+                     d->k, np);
+  return check_launch("pad_filter_bf16");
+}
 static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                                int pool, int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st) {
-  const int rl = d->s * 4, rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
+  const int rlp = (d->s * 2 + 3) / 4 * 4 * 2, np = (d->k + 7) / 8 * 8;      // bf16 elements
   GemmProblem g = fwd_problem(d);
   g.K = d->r * rlp; g.avec = 4; g.bvec = 4; g.no_glds = 1;
   const int ph = d->ho / 2, pw = d->wo / 2;
@@ -860,17 +867,20 @@ static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const flo
     g.M = d->n * ph * pw * 4;
     g.plain = 1;
   }
-  const size_t ws_used = bf16_image_filter_bytes(d);
+  const bool prepared = (d->hints & A3D_HINT_W_PREPARED) != 0;      // w is already the padded bf16 filter (a3d_conv2d_fwd_prepare_filter)
+  const size_t ws_used = prepared ? 0 : bf16_image_filter_bytes(d);
   GemmPlan plan = plan_gemm(g, d->precision);
-  if (!ws || ws_used + plan.ws_bytes > ws_bytes)
+  if ((!ws && ws_used + plan.ws_bytes > 0) || ws_used + plan.ws_bytes > ws_bytes)
     return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
   A3D_CHECK_ARG(plan.prec == A3D_PREC_BF16 && aligned16(y), "conv2d_fwd: bf16 image form needs the bf16 kernel");
-  __bf16* wp = static_cast<__bf16*>(ws);
-  clear_stale_error();
-  hipLaunchKernelGGL(pad_filter_bf16_kernel, dim3((d->r * rlp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rl, rlp,
-                     d->k, np);
-  int rc = check_launch("pad_filter_bf16");
-  if (rc != A3D_OK) return rc;
+  const __bf16* wp = reinterpret_cast<const __bf16*>(w);
+  if (!prepared) {
+    int rc = pad_filter_bf16(d, w, static_cast<__bf16*>(ws), st);
+    if (rc != A3D_OK) return rc;
+    wp = static_cast<const __bf16*>(ws);
+  } else {
+    A3D_CHECK_ARG(aligned16(w), "conv2d_fwd: a prepared filter is 16-byte aligned");
+  }
   IgemmParams p;
   fill_common(p, g);
   p.a16 = 1; p.b16 = 1; p.c16 = (d->storage & A3D_STORE_Y_BF16) ? 1 : 0;
@@ -927,7 +937,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     }
     const bool timed = timing_wanted(slot.rec);
     if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
-    rc = conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+    rc = conv3_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st, (d->hints & A3D_HINT_W_PREPARED) != 0);
     if (timed) timing_end(slot, st);
     return rc;
   }
@@ -941,21 +951,25 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   if (!aligned16(w)) g.bvec = 1;
   if (d->hints & A3D_HINT_SHARE_CU) g.no_glds = 1;      // the register-staged kernels take the hint (launch_one)
   RunForm rf{};
-  const bool run = run_form_ok(d, x, &rf) && ws && ws_bytes >= run_filter_bytes(d, rf);
+  const bool prepared = (d->hints & A3D_HINT_W_PREPARED) != 0;
+  const bool run = run_form_ok(d, x, &rf) && (prepared || (ws && ws_bytes >= run_filter_bytes(d, rf)));
+  A3D_CHECK_ARG(!prepared || (run && aligned16(w)), "conv2d_fwd: A3D_HINT_W_PREPARED on a launch that reads the filter as stored");
   size_t ws_used = 0;
   const float* filter = w;
   int run_ldb = d->k;
   if (run) {                                   // window-run form: K = (r, padded run), filter padded into the workspace
     g.K = rf.kp; g.avec = rf.vec;
-    ws_used = run_filter_bytes(d, rf);
-    float* wp = static_cast<float*>(ws);
-    clear_stale_error();
     const int np = (d->storage & A3D_STORE_W_BF16) ? d->k : (d->k + 3) / 4 * 4;
-    hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
-                       rf.rlp, d->k, np);
-    rc = check_launch("pad_filter");
-    if (rc != A3D_OK) return rc;
-    filter = wp;
+    if (!prepared) {                           // (prepared: w already is the padded filter, a3d_conv2d_fwd_prepare_filter)
+      ws_used = run_filter_bytes(d, rf);
+      float* wp = static_cast<float*>(ws);
+      clear_stale_error();
+      hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * np + 255) / 256), dim3(256), 0, st, w, wp, d->r, rf.rl,
+                         rf.rlp, d->k, np);
+      rc = check_launch("pad_filter");
+      if (rc != A3D_OK) return rc;
+      filter = wp;
+    }
     run_ldb = np;
     g.bvec = (np % 4 == 0) ? 4 : 1;             // the padded copy is 256-byte aligned
   }
@@ -1013,6 +1027,47 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                    void* ws, size_t ws_bytes, void* stream) {
   return conv_fwd_impl(d, x, w, bias, y, act, 0, 0, nullptr, ws, ws_bytes, stream);
+}
+
+// Which per-call repack of the filter does this forward do?  0 none, 1 bf16 image form, 2 conv3's [K/4][N][4], 3 window-run padding
+static int fwd_filter_form(const a3d_conv_desc* d, RunForm* rf) {
+  if (check_desc(d) != A3D_OK || stencil1_applicable(d)) return 0;
+  if (bf16_image_form_ok(d, nullptr)) return 1;
+  if (conv3_applicable(d, nullptr)) return 2;
+  if (run_form_ok(d, nullptr, rf)) return 3;
+  return 0;
+}
+
+size_t a3d_conv2d_fwd_prepared_filter_bytes(const a3d_conv_desc* d) {
+  RunForm rf{};
+  switch (fwd_filter_form(d, &rf)) {
+    case 1: return bf16_image_filter_bytes(d);
+    case 2: return conv3_ws_bytes(d);
+    case 3: return run_filter_bytes(d, rf);
+    default: return 0;
+  }
+}
+
+int a3d_conv2d_fwd_prepare_filter(const a3d_conv_desc* d, const float* w, void* prepared, size_t prepared_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(w && prepared && aligned16(prepared), "conv2d_fwd_prepare_filter: null or misaligned buffer");
+  const size_t need = a3d_conv2d_fwd_prepared_filter_bytes(d);
+  A3D_CHECK_ARG(need > 0, "conv2d_fwd_prepare_filter: this forward reads the filter as stored");
+  if (prepared_bytes < need) return set_error(A3D_EWORKSPACE, "conv2d_fwd_prepare_filter: need %zu bytes", need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RunForm rf{};
+  switch (fwd_filter_form(d, &rf)) {
+    case 1: return pad_filter_bf16(d, w, static_cast<__bf16*>(prepared), st);
+    case 2: return conv3_pack(d, w, static_cast<float*>(prepared), st);
+    default: {
+      const int np = (d->storage & A3D_STORE_W_BF16) ? d->k : (d->k + 3) / 4 * 4;
+      clear_stale_error();
+      hipLaunchKernelGGL(pad_filter_kernel, dim3((rf.kp * np + 255) / 256), dim3(256), 0, st, w, static_cast<float*>(prepared), d->r,
+                         rf.rl, rf.rlp, d->k, np);
+      return check_launch("pad_filter");
+    }
+  }
 }
 
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,

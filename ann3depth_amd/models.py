@@ -167,6 +167,10 @@ class MSDNReplica:
         self._share_names = {0: (), 1: ('fine/first/conv2d', 'fine/second/conv2d'), 2: ('fine/first/conv2d',),
                              3: ('fine/second/conv2d',)}[share]
         self._shared_desc = {}
+        # the few-channel forwards' filters in the layout their kernels read, repacked when the weights change instead of on
+        # every call (a3d_conv2d_fwd_prepare_filter; A3D_PREPARED_FILTERS=0: per call, as before round 5)
+        self.prepare_filters = os.environ.get('A3D_PREPARED_FILTERS', '1') != '0' and self.device.type == 'cuda'
+        self._prep = {}
         self._alone = ()          # fine-network GEMMs of the current forward that nothing runs beside (fine phase: fine/second)
         self._deferred = None     # (all-reduce handle, group, grad scale): CoarseDense bucket still in flight, see step()
         # data-parallel replicas under the reference's frozen optimizer: the dense bucket is reduce-scattered and each
@@ -371,6 +375,23 @@ class MSDNReplica:
             return self.wcopy[name]
         return self._v(name + '/kernel')
 
+    def _prepared(self, key, desc, w):
+        """(descriptor, filter) for a few-channel forward: the prepared copy and the descriptor that says so, where the launch has one."""
+        if not self.prepare_filters:
+            return desc, w
+        pf = self._prep.get(key)
+        if pf is None:
+            pf = self._prep[key] = ops.PreparedFilter(desc, self.device)
+            pf.source = w
+            if pf.ok:
+                pf.refresh(w)
+        return (pf.desc_prepared, pf.buf) if pf.ok else (desc, w)
+
+    def _refresh_prepared(self):
+        for pf in self._prep.values():
+            if pf.ok:
+                pf.refresh(pf.source)
+
     def refresh_weight_copies(self):
         for n, c in self.wcopy.items():
             ops.cast_bf16(self._v(n + '/kernel'), c)
@@ -383,8 +404,10 @@ class MSDNReplica:
     def _weights_moved(self, *groups):
         """After an ApplyAdam that can change `var` (any optimizer but the reference's frozen beta2 = 1 one): the bf16
         copies the next forward / bwd-data read must follow the fp32 masters."""
-        if self.wcopy and not all(g.frozen() for g in groups):
-            self.refresh_weight_copies()
+        if not all(g.frozen() for g in groups):
+            if self.wcopy:
+                self.refresh_weight_copies()
+            self._refresh_prepared()
 
     # ---- variables ----
     def settle(self):
@@ -484,6 +507,8 @@ class MSDNReplica:
             g.view(g.var, n).copy_(torch.from_numpy(np.ascontiguousarray(a)))
         if getattr(self, 'wcopy', None):
             self.refresh_weight_copies()
+        if getattr(self, '_prep', None):
+            self._refresh_prepared()
 
     def _v(self, name):
         g = self.groups[self.group_of[name]]
@@ -533,6 +558,7 @@ class MSDNReplica:
         self.global_step = int(sd['global_step'].item())
         if self.wcopy:
             self.refresh_weight_copies()
+        self._refresh_prepared()
 
     uses_dropout = True
 
@@ -603,13 +629,22 @@ class MSDNReplica:
             g.beta1_power, g.beta2_power = np.float32(st[1 + 2 * i].item()), np.float32(st[2 + 2 * i].item())
         if self.wcopy:
             self.refresh_weight_copies()
+        self._refresh_prepared()
 
     def _kb(self, name):
         return self._v(name + '/kernel'), self._v(name + '/bias')
 
+    FEW_CHANNEL = ('coarse/conv/conv2d_0', 'fine/first/conv2d')
+
+    def _fwd_operands(self, name):
+        d, w = self._desc(name, 'fwd'), self._w(name)
+        if name in self.FEW_CHANNEL:
+            d, w = self._prepared((name, d.storage, d.hints, d.precision), d, w)
+        return d, w
+
     def _conv(self, name, x, y):
-        ops.conv2d_fwd(self._desc(name, 'fwd'), x, self._w(name), self._v(name + '/bias'), y,
-                       'relu' if self.conv[name].relu else None)
+        d, w = self._fwd_operands(name)
+        ops.conv2d_fwd(d, x, w, self._v(name + '/bias'), y, 'relu' if self.conv[name].relu else None)
 
     def _pool(self, x, y, extra=None, c=None):
         if self.bf16s:
@@ -661,7 +696,13 @@ class MSDNReplica:
         return out
 
     def _conv_pool(self, name, x, y_pooled, argmax=None):
-        ops.conv2d_pool_fwd(self._desc(name, 'fwd'), x, self._w(name), self._v(name + '/bias'), y_pooled, 'relu', argmax)
+        d, w = self._fwd_operands(name)
+        ops.conv2d_pool_fwd(d, x, w, self._v(name + '/bias'), y_pooled, 'relu', argmax)
+
+    def _fine_first_image_form(self, argmax=None):
+        """'bf16s': fine/first on the bf16 pipe from the 4-channel bf16 image, conv + ReLU + pool in one launch."""
+        d, w = self._prepared(('fine/first/image', 0, 0, 0), self.d4, self.w4)
+        ops.conv2d_pool_fwd(d, self.x4, w, self._v('fine/first/conv2d/bias'), self.cat, 'relu', argmax)
 
     def forward(self, images, depths, keep_mask, join=True, phase=None):
         """join=False leaves the fine network's forward in flight on the side stream (step() joins later).
@@ -711,9 +752,9 @@ class MSDNReplica:
                 if lean_fine:
                     self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1 if phase == 2 else None)   # cat[..., :63]
                 elif self.bf16s and phase in (1, 3):        # conv + ReLU + pool in one launch: f1 is never written
-                    ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu')
+                    self._fine_first_image_form()
                 elif self.bf16s and self.fine_first_bf16:   # the same launch where the layer trains: it also records the window positions
-                    ops.conv2d_pool_fwd(self.d4, self.x4, self.w4, self._v('fine/first/conv2d/bias'), self.cat, 'relu', self.af1)
+                    self._fine_first_image_form(self.af1)
                 elif self.bf16s:
                     self._conv_pool('fine/first/conv2d', self.x, self.cat, self.af1)
                 else:

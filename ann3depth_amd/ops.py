@@ -69,6 +69,27 @@ STORE_X, STORE_W, STORE_Y = 1, 2, 4      # a3d_conv_desc.storage bits: which ten
 
 
 HINT_SHARE_CU = 1                    # a3d_conv_desc.hints
+HINT_W_PREPARED = 2
+
+
+class PreparedFilter:
+    """The filter of a few-channel forward in the layout its kernel reads (a3d_conv2d_fwd_prepare_filter), kept beside the
+    stored filter so that the repack runs when the weights change instead of on every call.  desc: the descriptor the forward
+    uses WITHOUT the hint; .desc_prepared is the same descriptor with A3D_HINT_W_PREPARED, .buf the prepared copy."""
+
+    def __init__(self, desc, device):
+        lib = _lib.load()
+        nbytes = lib.a3d_conv2d_fwd_prepared_filter_bytes(ctypes.byref(desc))
+        self.ok = nbytes > 0
+        self.desc = desc
+        if self.ok:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.desc_prepared = ConvDesc.from_buffer_copy(desc)
+            self.desc_prepared.hints = desc.hints | HINT_W_PREPARED
+
+    def refresh(self, w):
+        check(_lib.load().a3d_conv2d_fwd_prepare_filter(ctypes.byref(self.desc), _ptr(w), _ptr(self.buf), self.buf.numel(), _stream()),
+              'a3d_conv2d_fwd_prepare_filter')
 
 
 def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precision='fp32', storage=0, hints=0):

@@ -61,6 +61,11 @@ typedef struct a3d_conv_desc {
  * other stream's kernels find free registers, wave slots and LDS on every CU instead of waiting for GEMM blocks to
  * retire.  The result is bit-identical with and without the hint. */
 #define A3D_HINT_SHARE_CU 1
+/* `w` of this FORWARD call is the filter as a3d_conv2d_fwd_prepare_filter laid it out for this descriptor (the few-channel
+ * layers repack or pad their filter — [K/4][N][4], zero rows for the window runs' pad positions, a bf16 copy for the image
+ * form — which otherwise happens on every call, 5 us per launch for weights that the reference's optimizer never moves:
+ * src/models.py:309).  The caller refreshes the prepared copy whenever the weights change.  Same results bit for bit. */
+#define A3D_HINT_W_PREPARED 2
 
 /* BASELINE config 5 ("bf16 activations + bf16 weight copies, fp32 master and accumulate"): tensors marked here are bf16 in
  * HBM (pass their pointers through the float* parameters); channel counts and pixel strides of a bf16 tensor must be
@@ -100,6 +105,12 @@ int a3d_stream_destroy(void* stream);
 size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d);
 int a3d_conv2d_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                    int act, void* ws, size_t ws_bytes, void* stream);
+
+/* The per-call filter repack of a3d_conv2d_fwd / a3d_conv2d_pool_fwd, hoisted (A3D_HINT_W_PREPARED): bytes of the prepared
+ * form for this descriptor with the hint bit clear (0: this forward reads the filter as stored — the hint is refused), and the
+ * repack itself into a caller-owned, 16-byte aligned buffer.  The descriptor's x is assumed 16-byte aligned. */
+size_t a3d_conv2d_fwd_prepared_filter_bytes(const a3d_conv_desc* d);
+int a3d_conv2d_fwd_prepare_filter(const a3d_conv_desc* d, const float* w, void* prepared, size_t prepared_bytes, void* stream);
 
 /* tf.layers.max_pooling2d(tf.layers.conv2d(x, ..., activation), 2, 2) in one kernel (src/models.py:211-216,241-243):
  * y_pooled[n, ho/2, wo/2, k] (pixel stride ld_pooled >= k) = 2x2 / stride-2 VALID max pool of act(conv + bias); the conv

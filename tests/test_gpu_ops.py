@@ -102,6 +102,58 @@ def test_conv2d_fwd_bwd(ops, n, h, w, c, k, ks, st, pad):
     assert rel_l2(dx.cpu().numpy(), dx_ref * (x > 0)) < RTOL_F32
 
 
+@pytest.mark.parametrize('form', ['conv3', 'window runs (bf16 arithmetic)', 'bf16 image'])
+def test_prepared_filter_gives_the_same_bits_as_the_per_call_repack(ops, form):
+    """A3D_HINT_W_PREPARED (a3d_conv2d_fwd_prepare_filter): the few-channel forwards repack their filter per call; hoisted into a
+    caller-owned copy the launch must give the same bits, with and without the fused pool; a forward that reads its filter as
+    stored has no prepared form and refuses the hint."""
+    import ctypes
+    from ann3depth_amd import _lib
+    rng = np.random.default_rng(len(form))
+    n, h, w, k, ks, st = 3, 60, 80, 63, 9, 2
+    wt = dev((rng.standard_normal((ks, ks, 3, k)) / np.sqrt(ks * ks * 3)).astype(np.float32))
+    b = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+    if form == 'conv3':
+        d = ops.conv_desc(n, h, w, 3, k, ks, ks, st, 'VALID')
+        x, filt, ydt = dev(rng.random((n, h, w, 3)).astype(np.float32)), wt, torch.float32
+    elif form == 'bf16 image':
+        d = ops.with_storage(ops.conv_desc(n, h, w, 4, k, ks, ks, st, 'VALID', ldy=64, precision='bf16'), ops.STORE_X | ops.STORE_Y)
+        x = torch.empty((n, h, w, 4), device='cuda', dtype=torch.bfloat16)
+        ops.pad_channels_bf16(dev(rng.random((n, h, w, 3)).astype(np.float32)), x)
+        filt = torch.zeros((ks, ks, 4, k), device='cuda')
+        filt[:, :, :3, :] = wt
+        ydt = torch.bfloat16
+    else:
+        n, h, w, k, ks, st = 2, 100, 132, 96, 11, 4
+        wt = dev((rng.standard_normal((ks, ks, 3, k)) / np.sqrt(ks * ks * 3)).astype(np.float32))
+        b = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+        d = ops.with_storage(ops.conv_desc(n, h, w, 3, k, ks, ks, st, 'VALID', precision='bf16'), ops.STORE_Y)
+        x, filt, ydt = dev(rng.random((n, h, w, 3)).astype(np.float32)), wt, torch.bfloat16
+    pf = ops.PreparedFilter(d, x.device)
+    assert pf.ok
+    pf.refresh(filt)
+    ld = d.ldy
+    y0 = torch.full((n, d.ho, d.wo, ld), -1.0, device='cuda', dtype=ydt)
+    y1 = torch.full_like(y0, -2.0)
+    ops.conv2d_fwd(d, x, filt, b, y0, 'relu')
+    ops.conv2d_fwd(pf.desc_prepared, x, pf.buf, b, y1, 'relu')
+    assert torch.equal(y0[..., :k], y1[..., :k])
+    p0 = torch.full((n, d.ho // 2, d.wo // 2, ld), -1.0, device='cuda', dtype=ydt)
+    p1 = torch.full_like(p0, -2.0)
+    a0 = torch.full((n, d.ho // 2, d.wo // 2, k), 9, device='cuda', dtype=torch.uint8)
+    a1 = torch.full_like(a0, 8)
+    ops.conv2d_pool_fwd(d, x, filt, b, p0, 'relu', a0)
+    ops.conv2d_pool_fwd(pf.desc_prepared, x, pf.buf, b, p1, 'relu', a1)
+    assert torch.equal(p0[..., :k], p1[..., :k]) and torch.equal(a0, a1)
+    # a layer that reads its filter as stored: nothing to prepare, and the hint is refused instead of misread
+    dg = ops.conv_desc(2, 13, 18, 256, 384, 3, 3, 1, 'SAME')
+    assert _lib.load().a3d_conv2d_fwd_prepared_filter_bytes(ctypes.byref(dg)) == 0 and not ops.PreparedFilter(dg, x.device).ok
+    dg.hints = ops.HINT_W_PREPARED
+    with pytest.raises(_lib.A3dError):
+        ops.conv2d_fwd(dg, torch.zeros((2, 13, 18, 256), device='cuda'), torch.zeros((3, 3, 256, 384), device='cuda'), None,
+                       torch.zeros((2, 13, 18, 384), device='cuda'), None)
+
+
 POOLED_BWDF_CASES = [
     # n, h, w, c, k, ksize, stride, ld (pixel stride of the pooled tensors), argmax stride
     (2, 35, 48, 3, 96, 11, 4, 96, 96),       # conv2d_0 kind: 7 x 10 conv outputs, the odd last row has no pool window
