@@ -95,6 +95,7 @@ SIGNATURES = {
     'a3d_conv2d_pool_fwd': (c_int, [_D, _P, _P, _P, _P, c_int, _P, c_int, _P, c_size_t, _P]),
     'a3d_maxpool2x2_bwd_idx': (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P]),
     'a3d_copy_channel': (c_int, [c_size_t, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    'a3d_comm_standin': (c_int, [_P, c_size_t, _P, c_size_t, c_int, c_float, _P]),
     'a3d_timing_enable': (c_int, [c_int]),
     'a3d_timing_collect': (c_int, [POINTER(TimingRecord), c_int]),
     'a3d_timing_select': (c_int, [POINTER(TimingRecord)]),

@@ -556,6 +556,41 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
 }  // namespace a3d
 
 namespace a3d {
+// A measurement aid, not part of the training path: what a collective costs the kernels it runs beside.  Shaped like one rank's
+// share of RCCL's reduce-scatter at N = 8 (src/ann3depth.py:77-92's replacement, dp.py): a few workgroups read `read_bytes`,
+// add what they read, write `write_bytes`, and pace themselves to `bytes_per_tick` (s_memrealtime runs at 100 MHz) so that the
+// launch lasts as long as the exchange would over xGMI.  bench.py --dp-rank-standin launches it on a second stream wherever a
+// data-parallel rank would start a collective.
+__global__ __launch_bounds__(256) void comm_standin_kernel(const float* __restrict__ src, size_t read_f4, float* __restrict__ dst,
+                                                           size_t write_f4, float f4_per_tick) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* s4 = reinterpret_cast<const f4*>(src);
+  f4* d4 = reinterpret_cast<f4*>(dst);
+  const size_t per = (read_f4 + gridDim.x - 1) / gridDim.x, lo = (size_t)blockIdx.x * per, hi = min(read_f4, lo + per);
+  const size_t wper = (write_f4 + gridDim.x - 1) / gridDim.x, wlo = (size_t)blockIdx.x * wper, whi = min(write_f4, wlo + wper);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  constexpr int U = 8;                                  // 8 x 256 x 16 B = 32 KiB per block and round
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  size_t wpos = wlo + threadIdx.x;
+  for (size_t i = lo; i < hi; i += 256 * U) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t e = i + u * 256 + threadIdx.x;
+      v[u] = e < hi ? __builtin_nontemporal_load(s4 + e) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+    if (wpos < whi) {                                   // one piece written per eight read (the rank keeps 1/8 of the sums)
+      __builtin_nontemporal_store(acc, d4 + wpos);
+      wpos += 256;
+    }
+    // pace: this block's share of the rate
+    const float due = (float)(i - lo + 256 * U) * (float)gridDim.x / f4_per_tick;
+    while ((float)(__builtin_amdgcn_s_memrealtime() - t0) < due) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 __global__ __launch_bounds__(256) void copy_channel_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                            size_t npix, int ld_src, int c_src, int ld_dst, int c_dst) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256)
@@ -851,6 +886,19 @@ int a3d_adam_apply_tf1_flag(size_t count, float* var, float* m, float* v, const 
                      static_cast<hipStream_t>(stream), var, m, v, g, count, 1.f - beta1, 1.f - beta2, alpha, eps,
                      grad_scale, poisoned);
   return check_launch("adam");
+}
+
+int a3d_comm_standin(const float* src, size_t read_bytes, float* dst, size_t write_bytes, int workgroups, float gbytes_per_s,
+                     void* stream) {
+  A3D_CHECK_ARG(src && dst && read_bytes >= 16 && write_bytes >= 16 && workgroups >= 1 && workgroups <= 256 && gbytes_per_s > 0.f &&
+                    ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+                "comm_standin: bad arguments");
+  // bytes per 10-ns tick of s_memrealtime: both directions count against the rate
+  const float f4_per_tick = gbytes_per_s * 10.f / 16.f * ((float)read_bytes / (float)(read_bytes + write_bytes));
+  clear_stale_error();
+  hipLaunchKernelGGL(comm_standin_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), src, read_bytes / 16,
+                     dst, write_bytes / 16, f4_per_tick);
+  return check_launch("comm_standin");
 }
 
 int a3d_copy_channel(size_t npix, const float* src, int ld_src, int c_src, float* dst, int ld_dst, int c_dst,

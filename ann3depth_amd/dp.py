@@ -166,6 +166,65 @@ class DetachedReducer:
         return [int(v) for v in values]
 
 
+class StandinReducer(DetachedReducer):
+    """DetachedReducer plus the COST of the collectives: wherever a rank of a `world_size`-way job would
+    start a collective, a stand-in kernel of the same size runs on a second HIP stream — a few workgroups reading the bucket
+    and writing the rank's share of the sums at a capped rate (a3d_comm_standin) — ordered after the kernels that produced
+    the bucket, and wait() makes the compute stream wait for it exactly as for an RCCL work handle.  One GPU, no
+    communication: the numbers the replica trains are meaningless; what is measured is how much a reduce-scatter of 268 MB
+    at xGMI-like rates slows the conv backward and the next forward it is meant to hide under.
+    gbytes_per_s: the rate the launch is paced to (reads + writes); workgroups: how many CUs it occupies (RCCL uses 16-32)."""
+
+    class _Work:
+        def __init__(self, event):
+            self.event = event
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.event)
+            return True
+
+    def __init__(self, world_size, rank=0, gbytes_per_s=200.0, workgroups=24):
+        super().__init__(world_size, rank)
+        self.gbytes_per_s, self.workgroups = float(gbytes_per_s), int(workgroups)
+        self.stream = None
+        self.scratch = None
+        self.launched_bytes = 0
+
+    def _standin(self, flat, write_fraction):
+        import ctypes
+        from . import _lib
+        from .ops import check
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=flat.device)
+        nbytes = flat.numel() * flat.element_size() // 16 * 16
+        wbytes = max(16, int(nbytes * write_fraction) // 16 * 16)
+        if self.scratch is None or self.scratch.numel() * 4 < wbytes:
+            self.scratch = torch.empty(max(wbytes // 4, 1 << 20), device=flat.device)
+        self.stream.wait_stream(torch.cuda.current_stream())          # the bucket is complete before the exchange reads it
+        with torch.cuda.stream(self.stream):
+            check(_lib.load().a3d_comm_standin(ctypes.c_void_p(flat.data_ptr()), nbytes, ctypes.c_void_p(self.scratch.data_ptr()),
+                                               wbytes, self.workgroups, self.gbytes_per_s,
+                                               ctypes.c_void_p(self.stream.cuda_stream)), 'a3d_comm_standin')
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.launched_bytes += nbytes + wbytes
+        return self._Work(ev)
+
+    def start(self, flat_grad):
+        # ring all-reduce: a rank reads and writes its bucket about twice (reduce-scatter + all-gather phases)
+        return self._standin(flat_grad, 1.0)
+
+    def reduce_scatter(self, flat):
+        n = flat.numel() // self.world_size
+        return self._standin(flat, 1.0 / self.world_size), flat[self.rank * n:(self.rank + 1) * n]
+
+    def wait(self, work):
+        work.wait()
+
+    def any(self, flag):
+        return self._Done()
+
+
 def init_from_env(backend=None):
     """Process-group setup from the launcher's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables.
     Returns (rank, local_rank, world_size); world_size 1 needs no process group."""

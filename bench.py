@@ -347,6 +347,12 @@ def main():
                          'fine = global_step 2 000 000 // B (src/models.py:302-305): a profiling aid, prints a fine-phase line')
     ap.add_argument('--no-dp-rank', action='store_true', help='N = 1: skip timing the step a data-parallel rank would run')
     ap.add_argument('--dp-world', type=int, default=8, help='world size assumed by the N = 1 dp_rank measurement')
+    ap.add_argument('--no-dp-rank-standin', action='store_true',
+                    help='N = 1: skip the dp_rank measurement WITH a stand-in for the collectives (dp.StandinReducer)')
+    ap.add_argument('--standin-gbps', type=float, default=200.0,
+                    help='rate the stand-in collective is paced to, reads + writes (xGMI: 7 links x ~153 GB/s per GPU at best, one '
+                         'ring ~150 GB/s)')
+    ap.add_argument('--standin-workgroups', type=int, default=24, help='CUs the stand-in collective occupies (RCCL: 16-32)')
     ap.add_argument('--model', default='msdn', choices=['msdn', 'dcnf'],
                     help="msdn = the headline (BASELINE config 2/3/5); dcnf = BASELINE config 4, the DCNF-lite unary stack "
                          "at batch 16 (768 patches): a separate line, 'step' = unary forward + backward")
@@ -360,6 +366,15 @@ def main():
             print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run',
                   file=sys.stderr)
         sys.exit(2)
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus or (backend != 'nccl' and not os.environ.get('A3D_DIST_BACKEND')):
+            # the line below would claim N RCCL ranks: refuse instead
+            if rank == 0:
+                print(f'bench.py: --gpus {args.gpus} needs {args.gpus} RCCL ranks, have {dist.get_world_size()} over {backend}',
+                      file=sys.stderr)
+            sys.exit(3)
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     B = args.batch
@@ -417,6 +432,23 @@ def main():
                     'dense dW written (268 MB), ApplyAdam on the rank\'s own slices; no RCCL time included',
             'scaling_ceiling': round(args.dp_world * dt / dtd, 2)}
         del dnet
+        if not args.no_dp_rank_standin:
+            # ... and with the COST of the collectives on this GPU: a stand-in kernel of each bucket's size on a second stream,
+            # paced to an xGMI-like rate, ordered and waited for exactly like the RCCL work handles (dp.StandinReducer)
+            sred = _dp.StandinReducer(args.dp_world, 0, args.standin_gbps, args.standin_workgroups)
+            snet = models.MSDNReplica(B, device=device, seed=3000, reducer=sred, precision=args.precision)
+            dts, _ = run_phase(snet, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
+            per_step = sred.launched_bytes / (args.steps + min(args.warmup, 3))
+            extra['dp_rank'].update({
+                'ms_per_step_dp_rank_with_standin': round(1e3 * dts / args.steps, 3),
+                'standin': {'gbytes_per_s': args.standin_gbps, 'workgroups': args.standin_workgroups,
+                            'mbytes_per_step': round(per_step / 1e6, 1),
+                            'ms_of_standin_per_step': round(per_step / args.standin_gbps / 1e6, 3),
+                            'what': 'one kernel per bucket on a second stream wherever the rank starts a collective: reads the '
+                                    'bucket, writes 1/world of it (reduce-scatter) or all of it (all-reduce), paced to the rate; '
+                                    'no communication happens'},
+                'scaling_ceiling_with_standin': round(args.dp_world * dt / dts, 2)})
+            del snet
     if rank == 0:
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

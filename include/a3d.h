@@ -192,6 +192,14 @@ int a3d_maxpool2x2_fwd(int n, int h, int w, int c, const float* x, float* y, int
  * y: pooled values [n,h/2,w/2] with pixel stride ldy; argmax dense [n,h/2,w/2,c]; dy pixel stride lddy. */
 int a3d_maxpool2x2_bwd_idx(int n, int h, int w, int c, const uint8_t* argmax, const float* y, int ldy, const float* dy,
                            int lddy, float* dx, int relu_mask, void* stream);
+/* MEASUREMENT AID (bench.py --dp-rank-standin; nothing in the training path calls it): a launch shaped like one rank's share
+ * of the gradient exchange that replaces the parameter servers of src/ann3depth.py:77-92 — `workgroups` blocks read read_bytes
+ * from src, add them up, write write_bytes to dst (16-byte aligned, multiples of 16), and pace themselves so that the launch
+ * lasts (read_bytes + write_bytes) / gbytes_per_s.  Run on a second stream beside a data-parallel rank's step it bounds what
+ * a collective of that size and rate costs the kernels it overlaps, on ONE GPU. */
+int a3d_comm_standin(const float* src, size_t read_bytes, float* dst, size_t write_bytes, int workgroups, float gbytes_per_s,
+                     void* stream);
+
 /* dst[pix, c_dst] = src[pix, c_src] for npix pixels (pixel strides ld_src / ld_dst): the coarse map into channel 63 of
  * the fine network's concat buffer (tf.concat, src/models.py:246) when the pooling kernel that normally does it is
  * fused away. */
