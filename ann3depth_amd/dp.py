@@ -25,15 +25,26 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, group=None):
+    def __init__(self, group=None, urgent_group=None):
+        """urgent_group: a SECOND communicator over the same ranks for the small buckets the step waits for at its end (the
+        conv group, 15 MB).  Collectives of one communicator run in the order they were started, so on the data group alone
+        those 15 MB queue behind the dense group's 268 MB reduce-scatter that was started before them and is not due for a
+        whole step (measured with the stand-in of round 5: the queueing, not the bytes, was what the step waited for).
+        None: created here when world_size > 1 (every rank constructs its reducer at the same point: new_group is
+        collective); A3D_DP_URGENT_GROUP=0 keeps everything on the data group."""
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.pending = []
+        if urgent_group is None and self.world_size > 1 and os.environ.get('A3D_DP_URGENT_GROUP', '1') != '0':
+            urgent_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None,
+                                          backend=dist.get_backend(group))
+        self.urgent_group = urgent_group
 
-    def start(self, flat_grad):
-        """Begin the all-reduce of one bucket; returns its handle (see wait())."""
-        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def start(self, flat_grad, urgent=False):
+        """Begin the all-reduce of one bucket; returns its handle (see wait()).  urgent: on the second communicator."""
+        g = self.urgent_group if (urgent and self.urgent_group is not None) else self.group
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=g, async_op=True)
         self.pending.append(work)
         return work
 
@@ -137,7 +148,7 @@ class DetachedReducer:
     def inplace_ok(self, device):
         return True
 
-    def start(self, flat_grad):
+    def start(self, flat_grad, urgent=False):
         return self._Done()
 
     def reduce_scatter(self, flat):
@@ -183,40 +194,42 @@ class StandinReducer(DetachedReducer):
             torch.cuda.current_stream().wait_event(self.event)
             return True
 
-    def __init__(self, world_size, rank=0, gbytes_per_s=200.0, workgroups=24):
+    def __init__(self, world_size, rank=0, gbytes_per_s=200.0, workgroups=24, urgent_stream=True):
         super().__init__(world_size, rank)
         self.gbytes_per_s, self.workgroups = float(gbytes_per_s), int(workgroups)
-        self.stream = None
-        self.scratch = None
+        self.streams = {}
+        self.urgent_stream = urgent_stream      # False: every stand-in on ONE stream, as with a single communicator
+        self.scratch = {}
         self.launched_bytes = 0
 
-    def _standin(self, flat, write_fraction):
+    def _standin(self, flat, write_fraction, lane):
         import ctypes
         from . import _lib
         from .ops import check
-        if self.stream is None:
-            self.stream = torch.cuda.Stream(device=flat.device)
+        if lane not in self.streams:
+            self.streams[lane] = torch.cuda.Stream(device=flat.device)
+        stream = self.streams[lane]
         nbytes = flat.numel() * flat.element_size() // 16 * 16
         wbytes = max(16, int(nbytes * write_fraction) // 16 * 16)
-        if self.scratch is None or self.scratch.numel() * 4 < wbytes:
-            self.scratch = torch.empty(max(wbytes // 4, 1 << 20), device=flat.device)
-        self.stream.wait_stream(torch.cuda.current_stream())          # the bucket is complete before the exchange reads it
-        with torch.cuda.stream(self.stream):
-            check(_lib.load().a3d_comm_standin(ctypes.c_void_p(flat.data_ptr()), nbytes, ctypes.c_void_p(self.scratch.data_ptr()),
+        if lane not in self.scratch or self.scratch[lane].numel() * 4 < wbytes:
+            self.scratch[lane] = torch.empty(max(wbytes // 4, 1 << 20), device=flat.device)
+        stream.wait_stream(torch.cuda.current_stream())               # the bucket is complete before the exchange reads it
+        with torch.cuda.stream(stream):
+            check(_lib.load().a3d_comm_standin(ctypes.c_void_p(flat.data_ptr()), nbytes, ctypes.c_void_p(self.scratch[lane].data_ptr()),
                                                wbytes, self.workgroups, self.gbytes_per_s,
-                                               ctypes.c_void_p(self.stream.cuda_stream)), 'a3d_comm_standin')
+                                               ctypes.c_void_p(stream.cuda_stream)), 'a3d_comm_standin')
             ev = torch.cuda.Event()
-            ev.record(self.stream)
+            ev.record(stream)
         self.launched_bytes += nbytes + wbytes
         return self._Work(ev)
 
-    def start(self, flat_grad):
+    def start(self, flat_grad, urgent=False):
         # ring all-reduce: a rank reads and writes its bucket about twice (reduce-scatter + all-gather phases)
-        return self._standin(flat_grad, 1.0)
+        return self._standin(flat_grad, 1.0, 'urgent' if (urgent and self.urgent_stream) else 'data')
 
     def reduce_scatter(self, flat):
         n = flat.numel() // self.world_size
-        return self._standin(flat, 1.0 / self.world_size), flat[self.rank * n:(self.rank + 1) * n]
+        return self._standin(flat, 1.0 / self.world_size, 'data'), flat[self.rank * n:(self.rank + 1) * n]
 
     def wait(self, work):
         work.wait()

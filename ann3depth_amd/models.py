@@ -974,8 +974,8 @@ class MSDNReplica:
                     after_dense1 = lambda: handle.append(red.start(gd.grad[d1:]))
                     after_dense = lambda: handle.extend(red.start(gd.grad[a:b]) for a, b in pieces0)
                 self.backward_coarse(after_dense1=after_dense1, after_dense=after_dense,
-                                     after_conv2=lambda: tail.append(red.start(gc.grad[cut:])))
-                head = red.start(gc.grad[:cut])
+                                     after_conv2=lambda: tail.append(red.start(gc.grad[cut:], urgent=True)))
+                head = red.start(gc.grad[:cut], urgent=True)       # (urgent: not queued behind the dense reduce-scatter, dp.py)
                 red.wait(tail[0])
                 red.wait(head)
                 gc.apply(scale)

@@ -353,6 +353,8 @@ def main():
                     help='rate the stand-in collective is paced to, reads + writes (xGMI: 7 links x ~153 GB/s per GPU at best, one '
                          'ring ~150 GB/s)')
     ap.add_argument('--standin-workgroups', type=int, default=24, help='CUs the stand-in collective occupies (RCCL: 16-32)')
+    ap.add_argument('--standin-one-stream', action='store_true',
+                    help='every stand-in on one stream (one communicator: the conv buckets queue behind the dense reduce-scatter)')
     ap.add_argument('--model', default='msdn', choices=['msdn', 'dcnf'],
                     help="msdn = the headline (BASELINE config 2/3/5); dcnf = BASELINE config 4, the DCNF-lite unary stack "
                          "at batch 16 (768 patches): a separate line, 'step' = unary forward + backward")
@@ -435,13 +437,15 @@ def main():
         if not args.no_dp_rank_standin:
             # ... and with the COST of the collectives on this GPU: a stand-in kernel of each bucket's size on a second stream,
             # paced to an xGMI-like rate, ordered and waited for exactly like the RCCL work handles (dp.StandinReducer)
-            sred = _dp.StandinReducer(args.dp_world, 0, args.standin_gbps, args.standin_workgroups)
+            sred = _dp.StandinReducer(args.dp_world, 0, args.standin_gbps, args.standin_workgroups,
+                                      urgent_stream=not args.standin_one_stream)
             snet = models.MSDNReplica(B, device=device, seed=3000, reducer=sred, precision=args.precision)
             dts, _ = run_phase(snet, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
             per_step = sred.launched_bytes / (args.steps + min(args.warmup, 3))
             extra['dp_rank'].update({
                 'ms_per_step_dp_rank_with_standin': round(1e3 * dts / args.steps, 3),
                 'standin': {'gbytes_per_s': args.standin_gbps, 'workgroups': args.standin_workgroups,
+                            'communicators': 1 if args.standin_one_stream else 2,
                             'mbytes_per_step': round(per_step / 1e6, 1),
                             'ms_of_standin_per_step': round(per_step / args.standin_gbps / 1e6, 3),
                             'what': 'one kernel per bucket on a second stream wherever the rank starts a collective: reads the '
