@@ -29,14 +29,16 @@ class GradReducer:
         """urgent_group: a SECOND communicator over the same ranks for the small buckets the step waits for at its end (the
         conv group, 15 MB).  Collectives of one communicator run in the order they were started, so on the data group alone
         those 15 MB queue behind the dense group's 268 MB reduce-scatter that was started before them and is not due for a
-        whole step (measured with the stand-in of round 5: the queueing, not the bytes, was what the step waited for).
-        None: created here when world_size > 1 (every rank constructs its reducer at the same point: new_group is
-        collective); A3D_DP_URGENT_GROUP=0 keeps everything on the data group."""
+        whole step.  OFF by default: measured with the one-GPU stand-in of round 5 (bench.py --standin-one-stream vs not) the
+        queueing is not what a rank's step waits for — 3.17 ms on one stream, 3.21 on two, 2.89 without stand-ins: the cost is
+        the CUs and the HBM bandwidth the exchange takes from the GEMMs beside it.  A3D_DP_URGENT_GROUP=1 creates the second
+        communicator here (every rank constructs its reducer at the same point: new_group is collective) for the first job
+        that can measure it over xGMI."""
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.pending = []
-        if urgent_group is None and self.world_size > 1 and os.environ.get('A3D_DP_URGENT_GROUP', '1') != '0':
+        if urgent_group is None and self.world_size > 1 and os.environ.get('A3D_DP_URGENT_GROUP', '0') == '1':
             urgent_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None,
                                           backend=dist.get_backend(group))
         self.urgent_group = urgent_group
