@@ -99,4 +99,11 @@ int conv3_pack(const a3d_conv_desc* d, const float* w, float* wp, hipStream_t st
 int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act, int pool,
               int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 
+// ---- the same from a 4-channel bf16 image on the bf16 matrix cores (conv3.hip, conv3b_*) ----
+bool conv3b_applicable(const a3d_conv_desc* d);
+size_t conv3b_filter_bytes(const a3d_conv_desc* d);
+int conv3b_pack(const a3d_conv_desc* d, const float* w, void* wp, hipStream_t st);
+int conv3b_fwd(const a3d_conv_desc* d, const void* x, const float* w, const float* bias, void* y, int act, int pool, int ld_out,
+               uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st, bool prepared);
+
 }  // namespace a3d

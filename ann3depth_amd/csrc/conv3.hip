@@ -60,6 +60,52 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
   }
 }
 
+// ---- epilogue shared by the fp32 and the bf16 form: bias, activation, (max pool + argmax), store ----
+template <int TM, int TN, bool POOL>
+__device__ __forceinline__ void conv3_epilogue(const f32x16 (&acc)[TM][TN], const Conv3Params& p, int m0, int n0, int li, int lh) {
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + b * 32 + li;
+      if (col >= p.N) continue;
+      const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = m0 + a * 32 + 8 * g + 4 * lh;       // the lane holds rows row .. row+3 of this column
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[a][b][4 * g + i] + bias;
+          if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
+          else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
+        }
+        if (POOL) {
+          if (row >= p.M) continue;
+          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+          float val = v[0];
+          int arg = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i)
+            if (v[i] > val) { val = v[i]; arg = i; }
+          const size_t o = (size_t)(row >> 2) * p.ldc + col;
+          if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)val;
+          else p.y[o] = val;
+          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (row + i >= p.M) continue;
+            const size_t o = (size_t)(row + i) * p.ldc + col;
+            if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)v[i];
+            else p.y[o] = v[i];
+          }
+        }
+      }
+    }
+  }
+}
+
 // DEPTH: chunks of 8 k in registers per wave (one being multiplied, DEPTH - 1 in flight).  2 for the kernel that runs
 // alone — four wavefronts per SIMD cover each other's load latency; 4 under A3D_HINT_SHARE_CU, where two wavefronts per
 // SIMD have to cover it themselves so that the other stream's bandwidth-bound kernels find half the register file free.
@@ -174,48 +220,104 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
     }
   }
 
-  // ---- epilogue: bias, activation, (max pool + argmax), store ----
+  conv3_epilogue<TM, TN, POOL>(acc, p, m0, n0, li, lh);
+}
+
+// ================================================================================================================
+// The same forward on the bf16 matrix cores (round 5; BASELINE config 5: conv2d_0 and fine/first at batch 64), from the
+// 4-channel bf16 copy of the image (a3d_pad_channels_bf16: 8-byte pixels, so a filter row's run of S*4 bf16 starts on a
+// 16-byte boundary for every even stride).  K = (r, q) with the run padded to a multiple of 8 elements: lane (row li,
+// half lh) of v_mfma_f32_32x32x16_bf16 holds k = 16u + 8 lh .. + 7 — ONE 16-byte load straight from L2, as is its B
+// fragment from the filter packed [K/8][N][8].  No LDS, no barrier; per k-step a wave issues TM + TN loads for TM * TN
+// MFMAs of 32 cycles.  The generic bf16 kernel (igemm_bf16.h) staged these layers through LDS at 0.06-0.11 of the bf16
+// peak (profiles/r04_bench_layers_bf16.txt).  Pad positions of a run hold the next pixels of the row and meet zero
+// weights (the stated deviation of the bf16 modes for non-finite pixels, include/a3d.h).
+// ================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// filter [R][S][4][N] float32 (HWIO, 4 channels: the 4th is the pad channel) -> bf16 [Kp/8][Np][8], zero where q >= RL, r >= R, n >= N
+__global__ __launch_bounds__(256) void conv3b_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int R, int RL,
+                                                          int RLP, int N, int Np, int Kp) {
+  const int total = Kp * Np;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int j = i & 7, col = (i >> 3) % Np, k8 = (i >> 3) / Np;
+    const int k = 8 * k8 + j, r = k / RLP, q = k - r * RLP;
+    wp[i] = (__bf16)((r < R && q < RL && col < N) ? w[(size_t)(r * RL + q) * N + col] : 0.f);
+  }
+}
+
+template <int TM, int TN, bool POOL>
+__global__ __launch_bounds__(256, TM * TN > 4 ? 2 : 3) void conv3b_fwd_kernel(const Conv3Params p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile = (int)bid * 4 + wave;
+  const int tiles_n = p.Np / (32 * TN);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  if (tile_m >= p.m_tiles) return;
+  const int m0 = tile_m * (32 * TM), n0 = tile_n * (32 * TN);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.x, p.x_bytes), rsB = make_rsrc(p.wp, p.wp_bytes);
+  uint32_t a_base[TM];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
+    const int row = m0 + a * 32 + li;
+    uint32_t off = kOOB;
+    if (row < p.M) {
+      uint32_t pix, sub = 0;
+      if (POOL) { pix = (uint32_t)row >> 2; sub = (uint32_t)row & 3u; } else pix = (uint32_t)row;
+      const uint32_t img = fdiv(pix, p.div_img), rem = pix - img * p.div_img.d;
+      uint32_t oy = fdiv(rem, p.div_row), ox = rem - oy * p.div_row.d;
+      if (POOL) { oy = 2 * oy + (sub >> 1); ox = 2 * ox + (sub & 1u); }
+      off = (img * (uint32_t)p.imgpitch + oy * (uint32_t)(p.stride * p.rowpitch) + ox * (uint32_t)p.step) * 2u;     // bf16 elements
+    }
+    a_base[a] = off;
+  }
+  const uint32_t b_base = (uint32_t)((n0 + li) * 16);
+  f32x16 acc[TM][TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = n0 + b * 32 + li;
-      if (col >= p.N) continue;
-      const float bias = p.bias ? p.bias[col] : 0.f;
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = m0 + a * 32 + 8 * g + 4 * lh;       // the lane holds rows row .. row+3 of this column
-        float v[4];
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = acc[a][b][4 * g + i] + bias;
-          if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
-          else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
-        }
-        if (POOL) {
-          if (row >= p.M) continue;
-          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
-          float val = v[0];
-          int arg = 0;
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+  const int nsteps = p.Kp / 16;
+  constexpr int DEPTH = 3;                            // k-steps in registers: one being multiplied, two in flight
+  bf16x8 af[DEPTH][TM], bf[DEPTH][TN];
+  auto fetch = [&](int u, int buf) {
+    const int k = 16 * u + 8 * lh;                    // this half's eight k: inside one filter row (RLP % 8 == 0)
+    const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
+    const uint32_t koff = (u < nsteps && k < p.Kreal) ? (r * (uint32_t)p.rowpitch + q) * 2u : kOOB;
 #pragma unroll
-          for (int i = 1; i < 4; ++i)
-            if (v[i] > val) { val = v[i]; arg = i; }
-          const size_t o = (size_t)(row >> 2) * p.ldc + col;
-          if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)val;
-          else p.y[o] = val;
-          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
-        } else {
+    for (int a = 0; a < TM; ++a) {
+      const uint32_t off = (a_base[a] | koff) & kOOB ? kOOB : a_base[a] + koff;
+      af[buf][a] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+    }
+    const uint32_t boff = u < nsteps ? (uint32_t)((2 * u + lh) * p.Np) * 16u + b_base : kOOB;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (row + i >= p.M) continue;
-            const size_t o = (size_t)(row + i) * p.ldc + col;
-            if (p.c16) reinterpret_cast<__bf16*>(p.y)[o] = (__bf16)v[i];
-            else p.y[o] = v[i];
-          }
-        }
-      }
+    for (int b = 0; b < TN; ++b)
+      bf[buf][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(boff == kOOB ? kOOB : boff + (uint32_t)b * 512u), 0, 0));
+  };
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf][a], bf[buf][b], acc[a][b], 0, 0, 0);
+  };
+  // a ring of DEPTH register sets, DEPTH k-steps per trip (static indices); a k-step past the end fetches zeros
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i) fetch(i, i);
+  for (int u = 0; u < nsteps; u += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      fetch(u + i + DEPTH - 1, (i + DEPTH - 1) % DEPTH);
+      multiply(i);
     }
   }
+  conv3_epilogue<TM, TN, POOL>(acc, p, m0, n0, li, lh);
 }
 
 // ---- host side ----
@@ -321,5 +423,82 @@ int conv3_fwd(const a3d_conv_desc* d, const float* x, const float* w, const floa
   return check_launch("conv3_fwd");
 }
 
+
+
+// ---- bf16 form from the 4-channel bf16 image (conv3b_fwd_kernel) ----
+struct Conv3bShape {
+  int RL, RLP, Kreal, Kp, TN, Np;
+};
+static Conv3bShape conv3b_shape(const a3d_conv_desc* d) {
+  Conv3bShape s;
+  s.RL = d->s * 4;
+  s.RLP = (s.RL + 7) / 8 * 8;
+  s.Kreal = d->r * s.RLP;
+  s.Kp = (s.Kreal + 15) / 16 * 16;
+  s.TN = (d->k + 31) / 32 >= 3 ? 3 : 2;
+  s.Np = (d->k + 32 * s.TN - 1) / (32 * s.TN) * (32 * s.TN);
+  return s;
+}
+
+// (the caller has checked the image form: 4 bf16 channels, densely packed, no padding, even stride, padded runs inside their row)
+bool conv3b_applicable(const a3d_conv_desc* d) {
+  if (tune_int("A3D_NO_CONV3B", 0) != 0) return false;       // A/B aid (tuning processes only)
+  if (d->k < 33) return false;
+  if ((double)d->n * d->h * d->w * 4 * 2.0 >= 2147483647.0) return false;        // 31-bit byte offsets into the image
+  return true;
+}
+
+size_t conv3b_filter_bytes(const a3d_conv_desc* d) {
+  const Conv3bShape s = conv3b_shape(d);
+  return ((size_t)s.Kp * s.Np * 2 + 255) / 256 * 256;
+}
+
+int conv3b_pack(const a3d_conv_desc* d, const float* w, void* wp, hipStream_t st) {
+  const Conv3bShape s = conv3b_shape(d);
+  clear_stale_error();
+  hipLaunchKernelGGL(conv3b_pack_kernel, dim3(std::min((s.Kp * s.Np + 255) / 256, 1024)), dim3(256), 0, st, w, static_cast<__bf16*>(wp),
+                     d->r, s.RL, s.RLP, d->k, s.Np, s.Kp);
+  return check_launch("conv3b_pack");
+}
+
+int conv3b_fwd(const a3d_conv_desc* d, const void* x, const float* w, const float* bias, void* y, int act, int pool, int ld_out,
+               uint8_t* argmax, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+  const Conv3bShape s = conv3b_shape(d);
+  const void* wp = w;
+  int rc;
+  if (!prepared) {
+    if (!ws || ws_bytes < conv3b_filter_bytes(d)) return set_error(A3D_EWORKSPACE, "conv3b_fwd: need %zu workspace bytes", conv3b_filter_bytes(d));
+    rc = conv3b_pack(d, w, ws, st);
+    if (rc != A3D_OK) return rc;
+    wp = ws;
+  } else if (reinterpret_cast<uintptr_t>(w) & 15) {
+    return set_error(A3D_EINVAL, "conv3b_fwd: a prepared filter is 16-byte aligned");
+  }
+  Conv3Params p{};
+  p.x = static_cast<const float*>(x); p.wp = static_cast<const float*>(wp); p.bias = bias; p.y = static_cast<float*>(y); p.argmax = argmax;
+  p.x_bytes = (unsigned long long)d->n * d->h * d->w * 4 * 2ull;
+  p.wp_bytes = (unsigned long long)s.Kp * s.Np * 2ull;
+  const int ph = d->ho / 2, pw = d->wo / 2;
+  p.M = pool ? d->n * ph * pw * 4 : d->n * d->ho * d->wo;
+  p.N = d->k; p.Np = s.Np; p.Kp = s.Kp; p.Kreal = s.Kreal; p.RL = s.RL; p.RLP = s.RLP;
+  p.rowpitch = d->w * 4; p.imgpitch = d->h * d->w * 4; p.step = d->stride * 4; p.stride = d->stride;
+  p.ldc = pool ? ld_out : d->ldy; p.act = act; p.pool = pool; p.c16 = (d->storage & A3D_STORE_Y_BF16) ? 1 : 0;
+  p.div_img = make_fastdiv(pool ? ph * pw : d->ho * d->wo);
+  p.div_row = make_fastdiv(pool ? pw : d->wo);
+  p.div_rlp = make_fastdiv(s.RLP);
+  const int tiles_n = s.Np / (32 * s.TN);
+  const int TM = 2;
+  p.m_tiles = (p.M + 32 * TM - 1) / (32 * TM);
+  const unsigned blocks = (unsigned)(((long)p.m_tiles * tiles_n + 3) / 4);
+  clear_stale_error();
+  if (s.TN == 3) {
+    if (pool) hipLaunchKernelGGL((conv3b_fwd_kernel<2, 3, true>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3b_fwd_kernel<2, 3, false>), dim3(blocks), dim3(256), 0, st, p);
+  } else {
+    if (pool) hipLaunchKernelGGL((conv3b_fwd_kernel<2, 2, true>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv3b_fwd_kernel<2, 2, false>), dim3(blocks), dim3(256), 0, st, p);
+  }
+  return check_launch("conv3b_fwd");
+}
 
 }  // namespace a3d

@@ -823,6 +823,7 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
     GemmProblem g = fwd_problem(d);
     g.K = d->r * ((d->s * 2 + 3) / 4 * 4 * 2); g.avec = 4; g.bvec = 4; g.no_glds = 1;
     need = std::max(need, bf16_image_filter_bytes(d) + plan_gemm(g, d->precision).ws_bytes);
+    need = std::max(need, conv3b_filter_bytes(d));
   }
   return need;
 }
@@ -924,8 +925,22 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     return stencil1_fwd(d, x, w, bias, y, act, static_cast<hipStream_t>(stream));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bf16_image_form_ok(d, x))
-    return conv_fwd_bf16_image(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+  if (bf16_image_form_ok(d, x)) {
+    if (!conv3b_applicable(d)) return conv_fwd_bf16_image(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st);
+    TimingSlot slot{};                          // straight from L2 on the bf16 matrix cores (conv3.hip, conv3b_fwd_kernel)
+    {
+      a3d_timing_record& r = slot.rec;
+      r.mode = MODE_FWD; r.prec = A3D_PREC_BF16; r.bm = 64; r.bn = d->k > 64 ? 96 : 64; r.waves_m = 1; r.nwaves = 1; r.bk = 16;
+      r.avec = 4; r.bvec = 4; r.splitk = 1; r.lds_dma = 2;
+      r.m = pool ? d->n * (d->ho / 2) * (d->wo / 2) * 4 : d->n * d->ho * d->wo; r.n = d->k; r.k = d->r * d->s * 3; r.ms = 0.f;
+      r.flops = 2.0 * r.m * r.n * r.k;          // (algorithmic: the image's three real channels)
+    }
+    const bool timed = timing_wanted(slot.rec);
+    if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+    rc = conv3b_fwd(d, x, w, bias, y, act, pool, ld_out, argmax, ws, ws_bytes, st, (d->hints & A3D_HINT_W_PREPARED) != 0);
+    if (timed) timing_end(slot, st);
+    return rc;
+  }
   if (conv3_applicable(d, x)) {                  // few-channel layers: operands straight from L2 (conv3.hip)
     TimingSlot slot{};
     {
@@ -1041,7 +1056,7 @@ static int fwd_filter_form(const a3d_conv_desc* d, RunForm* rf) {
 size_t a3d_conv2d_fwd_prepared_filter_bytes(const a3d_conv_desc* d) {
   RunForm rf{};
   switch (fwd_filter_form(d, &rf)) {
-    case 1: return bf16_image_filter_bytes(d);
+    case 1: return conv3b_applicable(d) ? conv3b_filter_bytes(d) : bf16_image_filter_bytes(d);
     case 2: return conv3_ws_bytes(d);
     case 3: return run_filter_bytes(d, rf);
     default: return 0;
@@ -1058,7 +1073,7 @@ int a3d_conv2d_fwd_prepare_filter(const a3d_conv_desc* d, const float* w, void* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   RunForm rf{};
   switch (fwd_filter_form(d, &rf)) {
-    case 1: return pad_filter_bf16(d, w, static_cast<__bf16*>(prepared), st);
+    case 1: return conv3b_applicable(d) ? conv3b_pack(d, w, prepared, st) : pad_filter_bf16(d, w, static_cast<__bf16*>(prepared), st);
     case 2: return conv3_pack(d, w, static_cast<float*>(prepared), st);
     default: {
       const int np = (d->storage & A3D_STORE_W_BF16) ? d->k : (d->k + 3) / 4 * 4;

@@ -141,7 +141,7 @@ class MSDNReplica:
         # layers' filters, fine/second's output (fine/third is a single-output-channel stencil on fp32), and the
         # tensors of the dense layers' small side (x, y, dz, dx: a few MB; dense_0's 201 MB of weights are read as bf16).
         self.bf16s = precision == 'bf16s'
-        self.fine_first_bf16 = False
+        self.fine_first_bf16 = self.conv0_image = False
         if self.bf16s:
             precision = 'bf16'
         self.precision = precision
@@ -337,6 +337,12 @@ class MSDNReplica:
             # took 0.38 ms of that phase's 1.73 at B = 64.  A3D_BF16S_FINE1=0: the fp32 conv + pool there, as before.
             self.fine_first_bf16 = os.environ.get('A3D_BF16S_FINE1', '1') != '0'
             self.x4 = torch.empty((B, NET_H, NET_W, 4), device=dev, dtype=torch.bfloat16)
+            # round 5: conv2d_0's forward from the same 4-channel bf16 image (conv3.hip's bf16 form, straight from L2) instead
+            # of the fp32 image through igemm_bf16's window runs.  A3D_BF16S_CONV0_IMAGE=0: as before.
+            self.conv0_image = os.environ.get('A3D_BF16S_CONV0_IMAGE', '1') != '0' and self.pool0_fused
+            self.w0_4 = torch.zeros((11, 11, 4, 96), device=dev)
+            self.d0_4 = ops.with_storage(ops.conv_desc(B, NET_H, NET_W, 4, 96, 11, 11, 4, 'VALID', ldy=96, precision='bf16'),
+                                         X | Y)
             self.w4 = torch.zeros((9, 9, 4, 63), device=dev)
             self.d4 = ops.with_storage(ops.conv_desc(B, NET_H, NET_W, 4, 63, 9, 9, 2, 'VALID', ldy=64, precision='bf16'),
                                        X | Y)
@@ -397,6 +403,7 @@ class MSDNReplica:
             ops.cast_bf16(self._v(n + '/kernel'), c)
         if self.bf16s:
             self.w4[:, :, :3, :] = self._v('fine/first/conv2d/kernel')
+            self.w0_4[:, :, :3, :] = self._v('coarse/conv/conv2d_0/kernel')
             n = 'coarse/dense/dense_1'
             ops.cast_rows(self._v(n + '/kernel'), self.w1pad)
             ops.cast_rows(self._v(n + '/bias').view(1, -1), self.b1pad)
@@ -720,7 +727,7 @@ class MSDNReplica:
         # fine phase: the main queue has nothing left to run beside fine/second (the coarse backward does not exist there and
         # the fine backward waits for this forward), so the launch takes the whole CU instead of leaving room (A3D_HINT_SHARE_CU)
         self._alone = ('fine/second/conv2d',) if phase == 2 else ()
-        if self.bf16s and (phase in (1, 3) or self.fine_first_bf16) and not (self.fuse_pool and phase in (1, 2, 3)):
+        if self.bf16s and (phase in (1, 3) or self.fine_first_bf16 or self.conv0_image) and not (self.fuse_pool and phase in (1, 2, 3)):
             # the fine network's 4-channel bf16 image, on the main stream: the side stream's chain (fine/first .. loss) is
             # the longer one at the join, the main stream idles there
             ops.pad_channels_bf16(self.x, self.x4)
@@ -732,7 +739,10 @@ class MSDNReplica:
             self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0 if train else None)
             self._conv_pool('coarse/conv/conv2d_1', self.p0, self.p1, self.a1 if train else None)
         elif self.bf16s:
-            if self.pool0_fused:
+            if self.pool0_fused and self.conv0_image:
+                d, w = self._prepared(('conv2d_0/image', 0, 0, 0), self.d0_4, self.w0_4)
+                ops.conv2d_pool_fwd(d, self.x4, w, self._v('coarse/conv/conv2d_0/bias'), self.p0, 'relu', self.a0)
+            elif self.pool0_fused:
                 self._conv_pool('coarse/conv/conv2d_0', self.x, self.p0, self.a0)
             else:
                 self._conv('coarse/conv/conv2d_0', self.x, self.c0)
