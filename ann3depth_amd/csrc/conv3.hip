@@ -82,7 +82,12 @@ __device__ __forceinline__ void conv3_epilogue(const f32x16 (&acc)[TM][TN], cons
         }
         if (POOL) {
           if (row >= p.M) continue;
-          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+          // the values a separate conv would have stored (rounded to bf16 where the output is), compared the way MaxPool /
+          // MaxPoolGrad scan them: the first maximum wins
+          if (p.c16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (float)(__bf16)v[i];
+          }
           float val = v[0];
           int arg = 0;
 #pragma unroll
