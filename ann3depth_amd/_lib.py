@@ -18,6 +18,11 @@ class ConvDesc(ctypes.Structure):
                                        'ldx', 'ldy', 'precision', 'storage', 'hints')]
 
 
+class SecondOutput(ctypes.Structure):
+    """struct a3d_second_output"""
+    _fields_ = [('ptr', c_void_p), ('ld', c_int32), ('step', c_int32), ('offset', c_int32), ('bf16', c_int32), ('cols', c_int32)]
+
+
 class ExampleView(ctypes.Structure):
     """struct a3d_example_view"""
     _fields_ = [('image_height', c_int64), ('image_width', c_int64), ('image_channels', c_int64),
@@ -73,6 +78,12 @@ SIGNATURES = {
                                         c_float, _P, _P]),
     'a3d_dense_fwd_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     'a3d_dense_bwd_data_ex': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, c_size_t, _P]),
+    'a3d_dense_fwd_ex2': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, POINTER(SecondOutput), _P,
+                                  c_size_t, _P]),
+    'a3d_dense_bwd_data_ex2': (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, c_int, c_int, POINTER(SecondOutput), _P,
+                                       c_size_t, _P]),
+    'a3d_conv2d_fwd_ex2': (c_int, [_D, _P, _P, _P, _P, c_int, POINTER(SecondOutput), _P, c_size_t, _P]),
+    'a3d_silog_loss_bwd_ex': (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     'a3d_cast_bf16': (c_int, [c_size_t, _P, _P, c_int, _P]),
     'a3d_cast_rows': (c_int, [c_size_t, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
     'a3d_pad_channels_bf16': (c_int, [c_size_t, c_int, _P, c_int, _P, _P]),

@@ -188,6 +188,11 @@ struct IgemmParams {
   // filter (run rows of unpad_rl floats out of padded rows of unpad_rlp); unpad_done reports that it did
   float* unpad_dst;
   int unpad_rl, unpad_rlp, unpad_done;
+  // host only (launch_igemm): a second copy of the finished output, written by the split-K reduction that writes the first
+  // (a3d_second_output: another type, pitch or place — the cast / copy launch that would follow otherwise); c_cols > 0:
+  // only the first c_cols columns of the GEMM's N are stored to C (rows of a tensor narrower than the padded GEMM)
+  void* out2;
+  int out2_ld, out2_step, out2_off, out2_bf16, out2_cols, c_cols;
   FastDiv div_nk;               // k-tiles per tile
   int share;                    // host only: A3D_HINT_SHARE_CU — launch with enough dynamic LDS that <= 8 waves fit a CU
   int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
@@ -1101,6 +1106,8 @@ struct ReduceParams {
   int vec4;              // plain 16-byte sum (bwd-filter slabs)
   int c16;               // output (and BWD_D mask) tensors are bf16
   const float* dbias_ws; float* dbias_out;     // bwd-filter: the [splitk][N] BiasAddGrad slabs ride along, or null
+  void* C2; int ld2, step2, off2, c2_16, cols2;      // second output: element (row, col < cols2) at (row * ld2 + col) * step2 + off2
+  int c_cols;            // > 0: columns >= c_cols are not stored to C
   int row_rl, row_rlp;   // vec4 sums of a window-run filter gradient: row rr*row_rlp + q of the slabs is row rr*row_rl + q of
                          // C for q < row_rl and a pad row otherwise (not stored); row_rlp == 0: rows as they are
 };

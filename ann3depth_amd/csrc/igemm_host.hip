@@ -430,8 +430,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
         s = apply_act_grad(s, y, p.mask_act, p.mask_scale);
       }
     }
-    if (p.c16) reinterpret_cast<__bf16*>(p.C)[o] = (__bf16)s;
-    else p.C[o] = s;
+    if (p.c_cols == 0 || col < p.c_cols) {
+      if (p.c16) reinterpret_cast<__bf16*>(p.C)[o] = (__bf16)s;
+      else p.C[o] = s;
+    }
+    if (p.C2 && col < p.cols2) {
+      const size_t o2 = ((size_t)row * p.ld2 + col) * p.step2 + p.off2;
+      if (p.c2_16) static_cast<__bf16*>(p.C2)[o2] = (__bf16)(p.c16 ? (float)(__bf16)s : s);
+      else static_cast<float*>(p.C2)[o2] = p.c16 ? (float)(__bf16)s : s;
+    }
+  }
+}
+
+// the second output of a launch that had no reduction stage to write it: a copy of the finished tensor
+__global__ __launch_bounds__(256) void second_output_kernel(const void* C, int c16, int M, int ldc, void* C2, int ld2, int step2, int off2,
+                                                            int c2_16, int cols2) {
+  const size_t total = (size_t)M * cols2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / cols2), col = (int)(i - (size_t)row * cols2);
+    const size_t o = (size_t)row * ldc + col;
+    const float s = c16 ? (float)static_cast<const __bf16*>(C)[o] : static_cast<const float*>(C)[o];
+    const size_t o2 = ((size_t)row * ld2 + col) * step2 + off2;
+    if (c2_16) static_cast<__bf16*>(C2)[o2] = (__bf16)s;
+    else static_cast<float*>(C2)[o2] = s;
   }
 }
 
@@ -556,6 +577,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   if (timed) timing_end(slot, st);
   if (rc != A3D_OK) return rc;
   if (plan.streamk > 0) {
+    A3D_CHECK_ARG(!p.out2 && !p.c_cols, "second output: not on stream-K launches");
     const unsigned tiles = (unsigned)(plan.tiles_m * plan.tiles_n);
     if (mode == MODE_FWD) return launch_fixup_mode0(plan.cfg, p, tiles, grid, st);
     if (mode == MODE_BWD_D) return launch_fixup_mode1(plan.cfg, p, tiles, grid, st);
@@ -575,9 +597,31 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
       r.C = p.unpad_dst; r.row_rl = p.unpad_rl; r.row_rlp = p.unpad_rlp;
       p.unpad_done = 1;
     }
+    r.C2 = p.out2; r.ld2 = p.out2_ld; r.step2 = p.out2_step; r.off2 = p.out2_off; r.c2_16 = p.out2_bf16; r.cols2 = p.out2_cols;
+    r.c_cols = p.c_cols;
+    if (r.vec4 || mode == MODE_BWD_F) A3D_CHECK_ARG(!p.out2 && !p.c_cols, "a second output belongs to a forward or bwd-data launch");
     rc = launch_splitk_reduce(r, st);
+    return rc;
+  }
+  A3D_CHECK_ARG(!p.c_cols || p.c_cols == p.N, "this launch has no reduction stage: the output cannot be narrower than the GEMM");
+  if (p.out2) {                                       // no reduction stage wrote it: one copy launch (what the caller saved otherwise)
+    A3D_CHECK_ARG(plan.streamk == 0 && p.sub_step == 1 && !p.pool, "second output: plain forward / bwd-data launches only");
+    const size_t total = (size_t)p.M * p.out2_cols;
+    clear_stale_error();
+    hipLaunchKernelGGL(second_output_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st,
+                       static_cast<const void*>(final_c), p.c16, p.M, p.ldc, p.out2, p.out2_ld, p.out2_step, p.out2_off, p.out2_bf16,
+                       p.out2_cols);
+    rc = check_launch("second_output");
   }
   return rc;
+}
+
+// a3d_second_output -> the host-only fields of IgemmParams
+static int take_second_output(IgemmParams& p, const a3d_second_output* o) {
+  if (!o || !o->ptr) return A3D_OK;
+  A3D_CHECK_ARG(o->ld > 0 && o->step > 0 && o->offset >= 0 && o->cols > 0 && o->cols <= p.N, "second output: bad geometry");
+  p.out2 = o->ptr; p.out2_ld = o->ld; p.out2_step = o->step; p.out2_off = o->offset; p.out2_bf16 = o->bf16 ? 1 : 0; p.out2_cols = o->cols;
+  return A3D_OK;
 }
 
 // ---- "window-run" form of few-channel VALID convolutions (Cin = 3: conv2d_0, fine/first) ----
@@ -723,6 +767,7 @@ static int apply_storage(IgemmParams& p, GemmProblem& g, int precision, bool a16
   return A3D_OK;
 }
 
+static int take_second_output(IgemmParams& p, const a3d_second_output* o);
 static void fill_common(IgemmParams& p, const GemmProblem& g) {
   p = IgemmParams{};
   p.M = g.M; p.N = g.N; p.K = g.K;
@@ -907,9 +952,12 @@ static int conv_fwd_bf16_image(const a3d_conv_desc* d, const float* x, const flo
 // conv2d forward; pool != 0: y is the 2x2 / stride-2 max pool of the activated conv output, [n, ho/2, wo/2, k] with
 // pixel stride ld_out, and the conv output itself is never written
 static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                         int pool, int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, void* stream) {
+                         int pool, int ld_out, uint8_t* argmax, void* ws, size_t ws_bytes, void* stream,
+                         const a3d_second_output* out2 = nullptr) {
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
+  A3D_CHECK_ARG(!(out2 && out2->ptr) || (!pool && !stencil1_applicable(d) && !bf16_image_form_ok(d, x) && !conv3_applicable(d, x)),
+                "conv2d_fwd_ex2: a second output on the implicit-GEMM forwards only (no fused pool, no few-channel / one-filter kernels)");
   A3D_CHECK_ARG(x && w && y, "conv2d_fwd: null tensor");
   A3D_CHECK_ARG(act == A3D_ACT_NONE || act == A3D_ACT_RELU || act == A3D_ACT_SIGMOID, "conv2d_fwd: bad act");
   if (pool) {
@@ -1036,6 +1084,8 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
     fill_staging(p, MODE_FWD, (unsigned long long)d->n * d->h * d->w * d->ldx, (unsigned long long)g.K * (run ? run_ldb : d->k),
                  run ? d->r : d->r, run ? 1 : d->s, inside ? d->r : 0, inside ? d->s : 0);
   }
+  rc = take_second_output(p, out2);
+  if (rc != A3D_OK) return rc;
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, static_cast<char*>(ws) + ws_used, st);
 }
 
@@ -1083,6 +1133,11 @@ int a3d_conv2d_fwd_prepare_filter(const a3d_conv_desc* d, const float* w, void* 
       return check_launch("pad_filter");
     }
   }
+}
+
+int a3d_conv2d_fwd_ex2(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                       const a3d_second_output* out2, void* ws, size_t ws_bytes, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y, act, 0, 0, nullptr, ws, ws_bytes, stream, out2);
 }
 
 int a3d_conv2d_pool_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y_pooled,
@@ -1445,14 +1500,21 @@ int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const flo
 
 int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
                      const uint8_t* drop_keep, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
+  return a3d_dense_fwd_ex2(m, k, n, x, w, bias, y, n, n, act, drop_keep, precision, storage, nullptr, ws, ws_bytes, stream);
+}
+
+int a3d_dense_fwd_ex2(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int ldy, int ncols_y, int act,
+                      const uint8_t* drop_keep, int precision, int storage, const a3d_second_output* out2, void* ws,
+                      size_t ws_bytes, void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_fwd: bad dims");
+  A3D_CHECK_ARG(ncols_y > 0 && ncols_y <= n && ldy >= ncols_y, "dense_fwd: y rows of %d columns at pitch %d from a GEMM of %d", ncols_y, ldy, n);
   A3D_CHECK_ARG((storage & ~(A3D_STORE_W_BF16 | A3D_STORE_X_BF16)) == 0, "dense_fwd: the weights and x may be bf16, y is float32");
   a3d_conv_desc d = dense_desc(m, k, n);
   d.precision = precision;
   int rc = check_desc(&d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && w && y, "dense_fwd: null tensor");
-  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) &&
+  if (precision == A3D_PREC_F32 && !storage && dense_stream_applicable(m, k, n) && aligned16(x) && !out2 && ldy == n && ncols_y == n &&
       !tune_int("A3D_NO_DENSE_KERNELS", 0))
     return dense_fwd_stream(m, k, n, x, w, bias, y, act, drop_keep, 2.f, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(&d);
@@ -1471,7 +1533,9 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
   p.npix = m; p.nrsc = k; p.H = 1; p.W = 1; p.ld = k; p.pHW = 1; p.stride = 1; p.lstride = 0; p.S = 1; p.Cg = k;
   p.div_phw = make_fastdiv(1); p.div_pw = make_fastdiv(1); p.div_c = make_fastdiv(k); p.div_s = make_fastdiv(1);
   p.div_c_half = make_fastdiv(std::max(1, k / 2));
-  p.ldb = n; p.ldc = n;
+  p.ldb = n; p.ldc = ldy; p.c_cols = ncols_y == n ? 0 : ncols_y;
+  rc = take_second_output(p, out2);
+  if (rc != A3D_OK) return rc;
   fill_staging(p, MODE_FWD, (unsigned long long)m * k, (unsigned long long)k * n, 1, 1, 1, 1);
   return launch_igemm(MODE_FWD, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
 }
@@ -1488,6 +1552,12 @@ int a3d_dense_bwd_data(int m, int k, int n, const float* dz, const float* w, flo
 
 int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
                           float scale, int precision, int storage, void* ws, size_t ws_bytes, void* stream) {
+  return a3d_dense_bwd_data_ex2(m, k, n, dz, w, dx, mask, mask_act, scale, precision, storage, nullptr, ws, ws_bytes, stream);
+}
+
+int a3d_dense_bwd_data_ex2(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
+                           float scale, int precision, int storage, const a3d_second_output* out2, void* ws, size_t ws_bytes,
+                           void* stream) {
   A3D_CHECK_ARG(m > 0 && k > 0 && n > 0, "dense_bwd_data: bad dims");
   // storage bits as a3d_conv2d_bwd_data's: Y = dz, W = w, X = dx and the mask
   A3D_CHECK_ARG(precision >= A3D_PREC_F32 && precision <= A3D_PREC_BF16, "dense_bwd_data: unknown precision %d", precision);
@@ -1517,6 +1587,8 @@ int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, 
   p.div_c_half = make_fastdiv(std::max(1, n / 2));
   p.ldc = k;
   p.S_full = 1;
+  rc = take_second_output(p, out2);
+  if (rc != A3D_OK) return rc;
   fill_staging(p, MODE_BWD_D, (unsigned long long)m * n, (unsigned long long)k * n, 1, 1, 0, 0);
   return launch_igemm(MODE_BWD_D, plan, g.avec, g.bvec, p, ws, static_cast<hipStream_t>(stream));
 }

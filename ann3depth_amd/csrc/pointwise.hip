@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                         const float* __restrict__ ws, float* __restrict__ dout, int b,
-                                                        int npix, float c, float inv_b) {
+                                                        int npix, float c, float inv_b, __bf16* __restrict__ dout16 = nullptr,
+                                                        int ld16 = 0) {
   const size_t total = (size_t)b * npix;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int smp = (int)(i / npix);
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict_
       g = __fdiv_rn(__fmul_rn(__fsub_rn(__fmul_rn(2.f, d), __fmul_rn(__fmul_rn(2.f, c), sd)), inv_b), arg);
     }
     dout[i] = g;
+    if (dout16) dout16[(size_t)smp * ld16 + (i - (size_t)smp * npix)] = (__bf16)g;      // the copy the bf16 dense layer reads (a3d_silog_loss_bwd_ex)
   }
 }
 
@@ -849,6 +851,16 @@ int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, cons
   clear_stale_error();
   hipLaunchKernelGGL(silog_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), out, tgt,
                      ws, dout, b, npix, kSilogC, 1.0f / (float)b);
+  return check_launch("silog_bwd");
+}
+
+int a3d_silog_loss_bwd_ex(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout, void* dout_bf16,
+                          int ld_bf16, void* stream) {
+  A3D_CHECK_ARG(b > 0 && npix > 0 && out && tgt && ws && dout && (!dout_bf16 || ld_bf16 >= npix), "silog_bwd: bad arguments");
+  const size_t total = (size_t)b * npix;
+  clear_stale_error();
+  hipLaunchKernelGGL(silog_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), out, tgt,
+                     ws, dout, b, npix, kSilogC, 1.0f / (float)b, static_cast<__bf16*>(dout_bf16), ld_bf16);
   return check_launch("silog_bwd");
 }
 

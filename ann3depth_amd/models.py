@@ -141,7 +141,8 @@ class MSDNReplica:
         # layers' filters, fine/second's output (fine/third is a single-output-channel stencil on fp32), and the
         # tensors of the dense layers' small side (x, y, dz, dx: a few MB; dense_0's 201 MB of weights are read as bf16).
         self.bf16s = precision == 'bf16s'
-        self.fine_first_bf16 = self.conv0_image = False
+        self.fine_first_bf16 = self.conv0_image = self.fuse_casts = False
+        self._c4_32_fresh = False
         if self.bf16s:
             precision = 'bf16'
         self.precision = precision
@@ -273,6 +274,9 @@ class MSDNReplica:
             # bf16 x / dz into the dense layers: the LDS-DMA kernel takes them as a weight stream of at most 64 rows (ring_plan,
             # igemm_host.hip); a larger batch keeps the dense layers' small side fp32 (B = 65..383 had no kernel)
             self.dense_bf16_x = B <= 64
+            # round 5: the casts between the bf16 conv stack and the fp32 dense side leave through the reductions that produce
+            # their sources (a3d_second_output) instead of five 5-us launches; A3D_BF16S_FUSE_CASTS=0: separate launches
+            self.fuse_casts = os.environ.get('A3D_BF16S_FUSE_CASTS', '1') != '0'
             self.dense1_bf16 = os.environ.get('A3D_BF16S_DENSE1', '1') != '0' and self.dense_bf16_x
             if not self.dense_bf16_x:
                 self.dc4_32 = buf(B, 6, 8, 256)
@@ -281,7 +285,7 @@ class MSDNReplica:
             self.b1pad = torch.zeros((1, NP), device=dev)
             self.drop16 = torch.empty((B, 4096), device=dev, dtype=torch.bfloat16)
             self.y1pad = torch.empty((B, NP), device=dev)
-            self.dz1_16 = torch.empty((B, NP), device=dev, dtype=torch.bfloat16)
+            self.dz1_16 = torch.zeros((B, NP), device=dev, dtype=torch.bfloat16)       # (columns 4070.. stay zero)
         # descriptors
         def D(*a):
             return ops.conv_desc(*a, precision=precision)
@@ -776,13 +780,23 @@ class MSDNReplica:
         self._conv('coarse/conv/conv2d_2', self.p1, self.c2)
         self._conv('coarse/conv/conv2d_3', self.c2, self.c3)
         fine_first()
-        self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
+        self._c4_32_fresh = False
+        if self.bf16s and self.dense_bf16_x and self.fuse_casts and phase == 1:
+            # c4 also as float32 (dense_0's filter gradient reads it in that type) from the same reduction
+            n4 = 'coarse/conv/conv2d_4'
+            ops.conv2d_fwd(self._desc(n4, 'fwd'), self.c3, self._w(n4), self._v(n4 + '/bias'), self.c4, 'relu',
+                           out2=ops.second_output(self.c4_32.view(-1, 256)))
+            self._c4_32_fresh = True
+        else:
+            self._conv('coarse/conv/conv2d_4', self.c3, self.c4)
         if not self._sharded_in_flight():
             self.settle()           # the previous step's dense-layer update is due now, not earlier
         w, b = self._kb('coarse/dense/dense_0')
         if self.bf16s and self.dense_bf16_x:   # dense_0 streams its 100 MB bf16 weight copy against c4 as it stands (bf16): LDS-DMA kernel
+            # (its bf16 copy for dense_1 leaves through the same reduction: a3d_second_output, round 5)
             ops.dense_fwd_ex(self.c4.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
-                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W | ops.STORE_X)
+                             drop_keep=keep_mask, precision='bf16', storage=ops.STORE_W | ops.STORE_X,
+                             out2=ops.second_output(self.drop16) if (self.dense1_bf16 and self.fuse_casts) else None)
         elif self.bf16s:            # more than 64 rows: the LDS-DMA kernel's weight-stream tiles do not apply; fp32 x, bf16 weight copy
             ops.cast_bf16(self.c4, self.c4_32)
             ops.dense_fwd_ex(self.c4_32.view(B, -1), self.wcopy['coarse/dense/dense_0'], b, self.drop, 'relu',
@@ -790,7 +804,15 @@ class MSDNReplica:
         else:
             ops.dense_fwd(self.c4.view(B, -1), w, b, self.drop, 'relu', drop_keep=keep_mask)     # relu + dropout fused
         w, b = self._kb('coarse/dense/dense_1')
-        if self.bf16s and self.dense1_bf16:
+        cat_done = False
+        if self.bf16s and self.dense1_bf16 and self.fuse_casts:
+            # the padded GEMM (4072 columns) writes the 4070-column depth map AND channel 63 of the concat buffer from its
+            # reduction: no cast_rows, no copy_channel launch
+            ops.dense_fwd_ex(self.drop16, self.w1pad, self.b1pad, self.coarse.view(B, -1), None, precision='bf16',
+                             storage=ops.STORE_W | ops.STORE_X, n=self.w1pad.shape[1],
+                             out2=ops.second_output(self.cat, cols=OUT_H * OUT_W, step=64, offset=63, ld=OUT_H * OUT_W))
+            cat_done = True
+        elif self.bf16s and self.dense1_bf16:
             ops.cast_bf16(self.drop, self.drop16)
             ops.dense_fwd_ex(self.drop16, self.w1pad, self.b1pad, self.y1pad, None, precision='bf16',
                              storage=ops.STORE_W | ops.STORE_X)
@@ -798,7 +820,9 @@ class MSDNReplica:
         else:
             ops.dense_fwd(self.drop, w, b, self.coarse.view(B, -1))
         with self._beside():
-            if lean_fine or self.bf16s:
+            if cat_done:
+                pass
+            elif lean_fine or self.bf16s:
                 ops.copy_channel(self.coarse, 0, self.cat, 63)                                # tf.concat([pool, coarse])
             else:
                 self._pool(self.f1, self.cat, extra=self.coarse, c=63)                        # pool + concat fused
@@ -836,7 +860,9 @@ class MSDNReplica:
     # ---- backward of loss_coarse wrt coarse/* : src/models.py:318-324 ----
     def backward_coarse(self, after_dense=None, after_conv2=None, after_dense1=None):
         B = self.B
-        ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1))
+        fused16 = self.bf16s and self.dense1_bf16 and self.fuse_casts
+        ops.silog_loss_bwd(self.coarse, self.t, self.ws_c, self.dz1.view(B, OUT_H, OUT_W, 1),
+                           dout16=self.dz1_16 if fused16 else None)       # (dz1 a second time as bf16 rows of 4072: dense_1's bwd-data)
         self.settle()              # a reduce-scatter of the previous step may still be reading the dense gradient buffer
         n = 'coarse/dense/dense_1'
         self._bwd_filter(n, self.drop, self.dz1)
@@ -845,18 +871,21 @@ class MSDNReplica:
         # dropout-grad (x2 on kept units) and dense_0's ReluGrad in one mask: drop > 0  <=>  kept and relu active
         # (train=False, src/models.py:230: tf.layers.dropout is the identity; only the ReluGrad remains)
         if self.bf16s and self.dense1_bf16:
-            ops.cast_rows(self.dz1, self.dz1_16)
+            if not fused16:
+                ops.cast_rows(self.dz1, self.dz1_16)
             ops.dense_bwd_data_ex(self.dz1_16, self.w1pad, self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0,
-                                  precision='bf16', storage=ops.STORE_W | ops.STORE_Y)
+                                  precision='bf16', storage=ops.STORE_W | ops.STORE_Y,
+                                  out2=ops.second_output(self.dz0_16) if fused16 else None)     # dz0 as bf16 too: dense_0's bwd-data
         else:
             ops.dense_bwd_data(self.dz1, self._v(n + '/kernel'), self.dz0, mask=self.drop, scale=2.0 if self.dropout_on else 1.0)
         n = 'coarse/dense/dense_0'
-        if self.bf16s and self.dense_bf16_x:   # the filter gradient takes c4 on the dense layers' fp32 side
-            ops.cast_bf16(self.c4, self.c4_32)      # (B > 64: the forward already made this copy)
+        if self.bf16s and self.dense_bf16_x and not self._c4_32_fresh:   # the filter gradient takes c4 on the dense layers' fp32 side
+            ops.cast_bf16(self.c4, self.c4_32)      # (B > 64: the forward already made this copy; fused casts: conv2d_4's reduction did)
         flat = (self.c4_32 if self.bf16s else self.c4).view(B, -1)
         self._bwd_filter(n, flat, self.dz0)
         if self.bf16s and self.dense_bf16_x:   # dz0 -> bf16 (1 MB); dc4 leaves as bf16, masked by the bf16 c4: no fp32 detour
-            ops.cast_bf16(self.dz0, self.dz0_16)
+            if not fused16:
+                ops.cast_bf16(self.dz0, self.dz0_16)
             ops.dense_bwd_data_ex(self.dz0_16, self.wcopy[n], self.dc4.view(B, -1), mask=self.c4.view(B, -1), scale=1.0,
                                   precision='bf16', storage=ops.STORE_W | ops.STORE_X | ops.STORE_Y)
         elif self.bf16s:            # B > 64: fp32 dz0 and mask against the bf16 weight copy, dc4 through an fp32 buffer

@@ -108,9 +108,28 @@ def conv_desc(n, h, w, c, k, r, s, stride, padding, ldx=None, ldy=None, precisio
                     ldx=ldx or c, ldy=ldy or k, precision=PREC[precision], storage=storage, hints=hints)
 
 
-def conv2d_fwd(d, x, w, bias, y, act=None):
+def second_output(t, cols=None, step=1, offset=0, ld=None):
+    """a3d_second_output for tensor t: element (row, col < cols) of the launch's output also goes to
+    t.flat[(row * ld + col) * step + offset], in t's type (float32 or bfloat16).  Default: t as a [rows, ld] matrix."""
+    if t is None:
+        return None
+    ld = t.shape[-1] if ld is None else ld
+    o = _lib.SecondOutput(t.data_ptr(), ld, step, offset, int(t.dtype == torch.bfloat16), ld if cols is None else cols)
+    o._keep = t
+    return o
+
+
+def _o2(out2):
+    return None if out2 is None else ctypes.byref(out2)
+
+
+def conv2d_fwd(d, x, w, bias, y, act=None, out2=None):
     lib = _lib.load()
     ws, n = _ws().get(lib.a3d_conv2d_fwd_ws_bytes(ctypes.byref(d)), x.device)
+    if out2 is not None:
+        check(lib.a3d_conv2d_fwd_ex2(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], _o2(out2), ws, n, _stream()),
+              'a3d_conv2d_fwd_ex2')
+        return y
     check(lib.a3d_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], ws, n, _stream()),
           'a3d_conv2d_fwd')
     return y
@@ -312,11 +331,12 @@ def silog_loss_fwd(out, tgt, loss, ws):
     return loss
 
 
-def silog_loss_bwd(out, tgt, ws, dout):
+def silog_loss_bwd(out, tgt, ws, dout, dout16=None):
+    """dout16: optional bfloat16 [b, ld >= npix], receives the same gradient (columns npix.. stay as they are: keep them zero)."""
     b = out.shape[0]
     npix = out.numel() // b
-    check(_lib.load().a3d_silog_loss_bwd(b, npix, _ptr(out), _ptr(tgt), _ptr(ws), _ptr(dout), _stream()),
-          'a3d_silog_loss_bwd')
+    check(_lib.load().a3d_silog_loss_bwd_ex(b, npix, _ptr(out), _ptr(tgt), _ptr(ws), _ptr(dout), _ptr(dout16),
+                                            0 if dout16 is None else dout16.shape[-1], _stream()), 'a3d_silog_loss_bwd_ex')
     return dout
 
 
@@ -357,24 +377,27 @@ def _dense_ws(lib, m, k, n, precision, storage, device):
     return _ws().get(need, device)
 
 
-def dense_fwd_ex(x, w, bias, y, act=None, drop_keep=None, precision='fp32', storage=0):
-    """dense_fwd with the arithmetic / weight storage of BASELINE config 5 (w may be the layer's bf16 copy)."""
+def dense_fwd_ex(x, w, bias, y, act=None, drop_keep=None, precision='fp32', storage=0, out2=None, n=None):
+    """dense_fwd with the arithmetic / weight storage of BASELINE config 5 (w may be the layer's bf16 copy).  n: the GEMM's
+    column count where it is wider than y (w padded to whole 16-byte pieces): y then receives its own y.shape[1] columns at its
+    own pitch; out2: a3d_second_output (second_output())."""
     m, k = x.shape
-    n = y.shape[1]
+    ncols = y.shape[1]
+    n = ncols if n is None else n
     lib = _lib.load()
     ws, nb = _dense_ws(lib, m, k, n, precision, storage, x.device)
-    check(lib.a3d_dense_fwd_ex(m, k, n, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ACT[act], _ptr(drop_keep), PREC[precision],
-                               storage, ws, nb, _stream()), 'a3d_dense_fwd_ex')
+    check(lib.a3d_dense_fwd_ex2(m, k, n, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), ncols, ncols, ACT[act], _ptr(drop_keep),
+                                PREC[precision], storage, _o2(out2), ws, nb, _stream()), 'a3d_dense_fwd_ex2')
     return y
 
 
-def dense_bwd_data_ex(dz, w, dx, mask=None, mask_act='relu', scale=1.0, precision='fp32', storage=0):
+def dense_bwd_data_ex(dz, w, dx, mask=None, mask_act='relu', scale=1.0, precision='fp32', storage=0, out2=None):
     m, n = dz.shape
     k = dx.shape[1]
     lib = _lib.load()
     ws, nb = _dense_ws(lib, m, k, n, precision, storage, dz.device)
-    check(lib.a3d_dense_bwd_data_ex(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), ACT[mask_act], scale, PREC[precision],
-                                    storage, ws, nb, _stream()), 'a3d_dense_bwd_data_ex')
+    check(lib.a3d_dense_bwd_data_ex2(m, k, n, _ptr(dz), _ptr(w), _ptr(dx), _ptr(mask), ACT[mask_act], scale, PREC[precision],
+                                     storage, _o2(out2), ws, nb, _stream()), 'a3d_dense_bwd_data_ex2')
     return dx
 
 

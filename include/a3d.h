@@ -165,6 +165,23 @@ int a3d_conv2d_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz,
                         void* dx, int lddx, int dx_bf16, int relu_mask, uint32_t* state, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* A SECOND copy of a launch's finished output (after bias / activation / dropout / mask), in another type, pitch or place —
+ * written by the split-K reduction that writes the first, instead of the cast or copy launch that would otherwise follow
+ * (BASELINE config 5 keeps five such tensors in two types: the bf16 side of the conv stacks and the fp32 side of the dense
+ * layers and the loss; src/models.py:222-234).  Element (row, col), col < cols, goes to ptr[(row * ld + col) * step + offset],
+ * as bf16 (bf16 != 0) or float32.  Rows are GEMM rows: samples for a dense layer, output pixels for a conv.  Where the launch
+ * has no reduction stage the library adds the copy launch itself.  NULL / ptr == NULL: none. */
+typedef struct a3d_second_output {
+  void* ptr;
+  int32_t ld, step, offset;
+  int32_t bf16;
+  int32_t cols;
+} a3d_second_output;
+
+/* a3d_conv2d_fwd with a second output (implicit-GEMM forwards: no fused pool, not the few-channel / one-filter kernels). */
+int a3d_conv2d_fwd_ex2(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                       const a3d_second_output* out2, void* ws, size_t ws_bytes, void* stream);
+
 /* tf.layers.dense (src/models.py:80-82,228,231): y[m,n] = act(x[m,:] @ w[:,n] + b[n]).
  * If drop_keep != NULL (uint8 [m,n]) the tf.layers.dropout(rate=.5, training=True) of src/models.py:230 is fused:
  * y *= 2 * keep. */
@@ -235,6 +252,10 @@ int a3d_silog_loss_fwd(int b, int npix, const float* out, const float* tgt, floa
 /* d loss / d out, using the per-sample sums left in ws by the forward call. */
 int a3d_silog_loss_bwd(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout,
                        void* stream);
+/* ... and the same gradient a second time as bf16 rows of pitch ld_bf16 >= npix (the form config 5's dense_1 reads dz in: rows
+ * of whole 16-byte pieces; columns npix .. ld_bf16 are the caller's, kept zero).  dout_bf16 == NULL: a3d_silog_loss_bwd. */
+int a3d_silog_loss_bwd_ex(int b, int npix, const float* out, const float* tgt, const float* ws, float* dout, void* dout_bf16,
+                          int ld_bf16, void* stream);
 
 /* Keep mask of tf.layers.dropout(rate, training=True) (src/models.py:230): keep[i] = floor((1-rate) + u_i),
  * u from Philox4x32-10 keyed by (seed, step).  TF's own random stream is not reproducible, so parity tests pass
@@ -248,6 +269,15 @@ int a3d_dense_fwd_ex(int m, int k, int n, const float* x, const float* w, const 
                      const uint8_t* drop_keep, int precision, int storage, void* ws, size_t ws_bytes, void* stream);
 int a3d_dense_bwd_data_ex(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
                           float scale, int precision, int storage, void* ws, size_t ws_bytes, void* stream);
+/* ... with a second output (a3d_second_output); the forward may also store y as rows of ncols_y <= n columns at pitch ldy
+ * (a GEMM padded to whole 16-byte pieces — dense_1: 4072 for 4070 — writing the unpadded tensor; needs a launch with a
+ * reduction stage, A3D_EINVAL otherwise). */
+int a3d_dense_fwd_ex2(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int ldy, int ncols_y, int act,
+                      const uint8_t* drop_keep, int precision, int storage, const a3d_second_output* out2, void* ws,
+                      size_t ws_bytes, void* stream);
+int a3d_dense_bwd_data_ex2(int m, int k, int n, const float* dz, const float* w, float* dx, const float* mask, int mask_act,
+                           float scale, int precision, int storage, const a3d_second_output* out2, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* float32 <-> bf16 (round to nearest even) of `count` elements: weight copies after ApplyAdam, and the two small tensors
  * that cross between the bf16 conv stack and the float32 dense layers (to_bf16 != 0: src float32 -> dst bf16). */

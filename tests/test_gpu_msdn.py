@@ -497,6 +497,31 @@ def test_msdn_bf16_storage_at_config5_batch(models):
         print(f'  {k:45s} {v:.3e}')
 
 
+def test_bf16_storage_fused_casts_are_the_same_step(models, monkeypatch):
+    """Round 5: under precision 'bf16s' the five tensors that cross between the bf16 conv stack and the fp32 dense side are
+    written by the reductions that produce their sources (a3d_second_output) instead of five cast / copy launches, and
+    conv2d_0 / fine/first run from the 4-channel bf16 image: the fused casts change no bit of the step."""
+    B = 64
+    img, dep, keep = synth(B, 4242, 240, 320)
+    params = O.init_params(3000)
+    args = [torch.from_numpy(a).cuda() for a in (img, dep, keep)]
+    nets = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('A3D_BF16S_FUSE_CASTS', flag)
+        nets.append(models.MSDNReplica(B, params=params, precision='bf16s'))
+    assert nets[0].fuse_casts and not nets[1].fuse_casts
+    for _ in range(2):
+        outs = [n.step(*args) for n in nets]
+        torch.cuda.synchronize()
+        for k in ('coarse_loss', 'fine_loss'):
+            assert float(outs[0][k]) == float(outs[1][k])
+    for name in ('coarse', 'fine', 'cat', 'drop', 'dz0', 'dc4', 'dc0' if nets[0].dc0 is not None else 'dp0'):
+        assert torch.equal(getattr(nets[0], name), getattr(nets[1], name)), name
+    for gname in nets[0].groups:
+        for buf in ('grad', 'm'):
+            assert torch.equal(getattr(nets[0].groups[gname], buf), getattr(nets[1].groups[gname], buf)), (gname, buf)
+
+
 def test_bf16_storage_above_64_rows_per_batch(models):
     """precision 'bf16s' at a batch of 65..383 — the dense layers' bf16 x / dz form is the LDS-DMA kernel's
     64-row weight stream only; above that the replica keeps the dense layers' small side float32 (weight copies bf16).  B = 96,

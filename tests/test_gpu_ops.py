@@ -154,6 +154,62 @@ def test_prepared_filter_gives_the_same_bits_as_the_per_call_repack(ops, form):
                        torch.zeros((2, 13, 18, 384), device='cuda'), None)
 
 
+def test_second_outputs_leave_through_the_reduction(ops):
+    """a3d_second_output (a3d_dense_fwd_ex2 / a3d_dense_bwd_data_ex2 / a3d_conv2d_fwd_ex2): a second copy of a launch's finished
+    output in another type / pitch / place equals the cast or copy launch it replaces bit for bit — config 5's five tensors that
+    cross between the bf16 conv stack and the fp32 dense side (dense_0's dropout output as bf16, dense_1's padded GEMM into the
+    4070-column depth map and channel 63 of the concat buffer, dz0 as bf16, conv2d_4's output as float32)."""
+    rng = np.random.default_rng(77)
+    bf = torch.bfloat16
+    B, K, N, NP = 64, 4096, 4070, 4072
+    x16 = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32)).cuda().to(bf)
+    wpad = torch.zeros((K, NP), device='cuda', dtype=bf)
+    wpad[:, :N] = torch.from_numpy((rng.standard_normal((K, N)) / 64).astype(np.float32)).cuda().to(bf)
+    bpad = torch.zeros((1, NP), device='cuda')
+    bpad[0, :N] = dev(rng.standard_normal(N).astype(np.float32))
+    st = ops.STORE_W | ops.STORE_X
+    # dense_1's form: padded GEMM -> y of 4070 columns + channel 63 of a [B, 55, 74, 64] bf16 buffer
+    ypad = torch.empty((B, NP), device='cuda')
+    ops.dense_fwd_ex(x16, wpad, bpad, ypad, None, precision='bf16', storage=st)
+    y = torch.full((B, N), float('nan'), device='cuda')
+    cat = torch.full((B, 55, 74, 64), 5.0, device='cuda', dtype=bf)
+    ops.dense_fwd_ex(x16, wpad, bpad, y, None, precision='bf16', storage=st, n=NP,
+                     out2=ops.second_output(cat, cols=N, step=64, offset=63, ld=N))
+    assert torch.equal(y, ypad[:, :N])
+    assert torch.equal(cat[..., 63].reshape(B, N), ypad[:, :N].to(bf)) and bool((cat[..., :63] == 5.0).all())
+    # dense_0's form: relu + dropout, second output = the same values as bf16
+    keep = torch.from_numpy((rng.random((B, NP)) >= 0.5).astype(np.uint8)).cuda()
+    y1 = torch.empty((B, NP), device='cuda')
+    y2 = torch.empty((B, NP), device='cuda')
+    y16 = torch.empty((B, NP), device='cuda', dtype=bf)
+    ops.dense_fwd_ex(x16, wpad, bpad, y1, 'relu', drop_keep=keep, precision='bf16', storage=st)
+    ops.dense_fwd_ex(x16, wpad, bpad, y2, 'relu', drop_keep=keep, precision='bf16', storage=st, out2=ops.second_output(y16))
+    assert torch.equal(y1, y2) and torch.equal(y16, y1.to(bf))
+    # bwd-data: dx float32 (masked, scaled) + its bf16 copy
+    dz16 = torch.from_numpy(rng.standard_normal((B, NP)).astype(np.float32)).cuda().to(bf)
+    mask = dev(rng.standard_normal((B, K)).astype(np.float32))
+    dx1 = torch.empty((B, K), device='cuda')
+    dx2 = torch.empty((B, K), device='cuda')
+    dx16 = torch.empty((B, K), device='cuda', dtype=bf)
+    ops.dense_bwd_data_ex(dz16, wpad, dx1, mask=mask, scale=2.0, precision='bf16', storage=ops.STORE_W | ops.STORE_Y)
+    ops.dense_bwd_data_ex(dz16, wpad, dx2, mask=mask, scale=2.0, precision='bf16', storage=ops.STORE_W | ops.STORE_Y,
+                          out2=ops.second_output(dx16))
+    assert torch.equal(dx1, dx2) and torch.equal(dx16, dx1.to(bf))
+    # a conv forward to a bf16 tensor with a float32 second copy: with a reduction stage (conv2d_4 at batch 64) and without one
+    for n, h, w, c, k, ks, stv in ((64, 13, 18, 384, 256, 3, 2), (2, 27, 37, 96, 256, 5, 1)):
+        X, W, Y = ops.STORE_X, ops.STORE_W, ops.STORE_Y
+        d = ops.with_storage(ops.conv_desc(n, h, w, c, k, ks, ks, stv, 'VALID', precision='bf16'), X | W | Y)
+        xc = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).cuda().to(bf)
+        wc = torch.from_numpy((rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)).cuda().to(bf)
+        bc = dev(rng.standard_normal(k).astype(np.float32) * 0.1)
+        ya = torch.empty((n, d.ho, d.wo, k), device='cuda', dtype=bf)
+        yb = torch.empty_like(ya)
+        y32 = torch.full((n, d.ho, d.wo, k), float('nan'), device='cuda')
+        ops.conv2d_fwd(d, xc, wc, bc, ya, 'relu')
+        ops.conv2d_fwd(d, xc, wc, bc, yb, 'relu', out2=ops.second_output(y32.view(-1, k)))
+        assert torch.equal(ya, yb) and torch.equal(y32, ya.float())
+
+
 POOLED_BWDF_CASES = [
     # n, h, w, c, k, ksize, stride, ld (pixel stride of the pooled tensors), argmax stride
     (2, 35, 48, 3, 96, 11, 4, 96, 96),       # conv2d_0 kind: 7 x 10 conv outputs, the odd last row has no pool window
