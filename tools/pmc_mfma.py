@@ -28,7 +28,7 @@ def main(counters, trace, out):
         dur[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     kernels = {}
     for k, c in tot.items():
-        if 'igemm' not in k and 'dense' not in k and 'conv3' not in k:
+        if not any(t in k for t in ('igemm', 'dense', 'conv3', 'fewch', 'stencil1_bwd_kernel')):
             continue
         name = k.replace('void ', '').split('(')[0]
         m = n[k]
