@@ -92,6 +92,13 @@ size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled);
 int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void* dz, int ldz, const void* pooled_act,
                      const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st);
 
+int fewch_reduce_launch(const float* slabs, int splits, int Mp, int NP, int M, int N, float* dw, float* db, hipStream_t st);
+// ... on the bf16 matrix cores (float32 image, bf16 gradient tensors: config 5; fewch16.hip)
+bool fewch16_bwdf_applicable(const a3d_conv_desc* d, bool pooled);
+size_t fewch16_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled);
+int fewch16_bwd_filter(const a3d_conv_desc* d, const float* x, bool pooled, const void* dz, int ldz, const void* pooled_act,
+                       const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st);
+
 // ---- few-channel forward convolution straight from L2 (conv3.hip) ----
 bool conv3_applicable(const a3d_conv_desc* d, const void* x);
 size_t conv3_ws_bytes(const a3d_conv_desc* d);

@@ -373,10 +373,13 @@ int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void
   else fewch_launch<2>(src, p, blocks, s.lds, st);
   int rc = check_launch("fewch_bwd_filter");
   if (rc != A3D_OK) return rc;
-  const int outs = (s.M + 1) * d->k;
+  return fewch_reduce_launch(p.slabs, s.splits, s.Mp, s.NP, s.M, d->k, dw, db, st);
+}
+
+int fewch_reduce_launch(const float* slabs, int splits, int Mp, int NP, int M, int N, float* dw, float* db, hipStream_t st) {
+  const int outs = (M + 1) * N;
   clear_stale_error();
-  hipLaunchKernelGGL(fewch_reduce_kernel, dim3((outs + 255) / 256), dim3(256), 0, st, static_cast<const float*>(p.slabs), s.splits,
-                     s.Mp, s.NP, s.M, d->k, dw, db);
+  hipLaunchKernelGGL(fewch_reduce_kernel, dim3((outs + 255) / 256), dim3(256), 0, st, slabs, splits, Mp, NP, M, N, dw, db);
   return check_launch("fewch_reduce");
 }
 

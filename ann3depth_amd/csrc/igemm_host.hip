@@ -1367,8 +1367,15 @@ static int fewch_timed(const a3d_conv_desc* d, const float* x, int src, const vo
   return rc;
 }
 
+// config 5: bf16 arithmetic on the fp32 image and bf16 pooled tensors (fewch16.hip); A3D_FEWCH16=0 (tuning processes): refused
+static bool fewch16_wanted(const a3d_conv_desc* d, bool pooled) {
+  return !d->storage && fewch16_bwdf_applicable(d, pooled) && tune_int("A3D_FEWCH16", 1) != 0;
+}
+
 size_t a3d_conv2d_bwd_filter_pooled_ws_bytes(const a3d_conv_desc* d) {
-  if (check_desc(d) != A3D_OK || d->storage || !fewch_bwdf_applicable(d, true)) return 0;
+  if (check_desc(d) != A3D_OK || d->storage) return 0;
+  if (fewch16_wanted(d, true)) return fewch16_bwdf_ws_bytes(d, true);
+  if (!fewch_bwdf_applicable(d, true)) return 0;
   return fewch_bwdf_ws_bytes(d, true);
 }
 
@@ -1378,8 +1385,30 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
   int rc = check_desc(d);
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(x && dpool && argmax && dw, "conv2d_bwd_filter_pooled: null tensor");
+  if (fewch16_wanted(d, true)) {                    // bf16 arithmetic: float32 image, bf16 pooled tensors
+    A3D_CHECK_ARG(pooled_bf16 && ld_dpool >= d->k && ld_argmax >= d->k && ld_dpool % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(dpool) & 7) == 0 && (reinterpret_cast<uintptr_t>(pooled) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(x) & 3) == 0,
+                  "conv2d_bwd_filter_pooled: bf16 arithmetic takes bf16 pooled tensors in whole aligned 4-channel groups");
+    if (fewch16_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
+    TimingSlot slot{};
+    {
+      a3d_timing_record& r = slot.rec;
+      r.mode = MODE_BWD_F; r.prec = A3D_PREC_BF16; r.bm = 128; r.bn = (d->k + 31) / 32 * 32; r.waves_m = 4; r.nwaves = 4; r.bk = 16;
+      r.avec = 1; r.bvec = 1; r.splitk = 1; r.lds_dma = 4;
+      r.m = d->r * d->s * d->c; r.n = d->k; r.k = d->n * d->ho * d->wo; r.ms = 0.f;
+      r.flops = 2.0 * r.m * r.n * r.k;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool timed = timing_wanted(slot.rec);
+    if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
+    rc = fewch16_bwd_filter(d, x, true, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws, st);
+    if (timed) timing_end(slot, st);
+    return rc;
+  }
   A3D_CHECK_ARG(!d->storage && fewch_bwdf_applicable(d, true),
-                "conv2d_bwd_filter_pooled: an unpadded fp32 conv of <= 4 densely packed input channels and 33..96 filters");
+                "conv2d_bwd_filter_pooled: an unpadded conv of <= 4 densely packed float32 input channels and 33..96 filters (fp32 "
+                "arithmetic; or bf16 arithmetic with bf16 pooled tensors)");
   A3D_CHECK_ARG(ld_dpool >= d->k && ld_argmax >= d->k, "conv2d_bwd_filter_pooled: pixel strides below the filter count");
   A3D_CHECK_ARG(ld_dpool % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(dpool) & (pooled_bf16 ? 7 : 15)) == 0 &&
                     (reinterpret_cast<uintptr_t>(pooled) & (pooled_bf16 ? 7 : 15)) == 0,

@@ -304,12 +304,15 @@ class MSDNReplica:
         # fp32 arithmetic on the fp32 image in every precision mode.  A3D_FEWCH_POOLED=0: the separate launches.
         self.d_few = {}
         if os.environ.get('A3D_FEWCH_POOLED', '1') != '0' and dev.type == 'cuda':
-            for n, dd in (('coarse/conv/conv2d_0', ops.conv_desc(B, NET_H, NET_W, 3, 96, 11, 11, 4, 'VALID')),
-                          ('fine/first/conv2d', ops.conv_desc(B, NET_H, NET_W, 3, 63, 9, 9, 2, 'VALID'))):
+            # 'bf16s' (config 5): the same launch in bf16 arithmetic (fewch16.hip: fp32 image, bf16 pooled tensors, both operands
+            # transposed into LDS); A3D_BF16S_FEWCH16=0: fp32 arithmetic for fine/first, igemm_bf16 + MaxPoolGrad for conv2d_0
+            few_prec = 'bf16' if (self.bf16s and os.environ.get('A3D_BF16S_FEWCH16', '1') != '0') else 'fp32'
+            for n, dd in (('coarse/conv/conv2d_0', ops.conv_desc(B, NET_H, NET_W, 3, 96, 11, 11, 4, 'VALID', precision=few_prec)),
+                          ('fine/first/conv2d', ops.conv_desc(B, NET_H, NET_W, 3, 63, 9, 9, 2, 'VALID', precision=few_prec))):
                 if ops.conv2d_bwd_filter_pooled_supported(dd):
                     self.d_few[n] = dd
-        if self.bf16s and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
-            self.d_few.pop('coarse/conv/conv2d_0', None)      # config 5: conv2d_0's filter gradient stays on the bf16 matrix cores
+            if self.bf16s and few_prec == 'fp32' and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
+                self.d_few.pop('coarse/conv/conv2d_0', None)   # (fp32 arithmetic there: 191 us against 78 + 18 for igemm_bf16 + MaxPoolGrad)
         # bf16 storage: per layer, which tensors of the forward / bwd-data / bwd-filter call are bf16 (ops.STORE_*), and
         # the bf16 copies of the kernels (refreshed whenever the fp32 masters change)
         self.store = {}

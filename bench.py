@@ -68,7 +68,7 @@ def collect_timing(lib):
 
 def kernel_name(r):
     if r.lds_dma == 4:
-        return f'fewch_bwdf_kernel<{r.bn // 32}>'
+        return f'fewch16_bwdf_kernel<{r.bn // 32}>' if r.prec else f'fewch_bwdf_kernel<{r.bn // 32}>'
     if r.lds_dma == 3:
         return f'igemm_ring_kernel<{r.mode}, {r.bm}, {r.bn}>'
     if r.prec:

@@ -259,6 +259,40 @@ def test_conv2d_bwd_filter_with_the_pool_gradient_fused(ops, n, h, w, c, k, ks, 
         assert rel_l2(dw3.cpu().numpy(), dw.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('n,h,w,c,k,ks,st,ld,lda', POOLED_BWDF_CASES[:2] + [(3, 228, 304, 3, 63, 9, 2, 64, 63)])
+def test_conv2d_bwd_filter_pooled_on_the_bf16_matrix_cores(ops, n, h, w, c, k, ks, st, ld, lda):
+    """Config 5's form of a3d_conv2d_bwd_filter_pooled (fewch16.hip): bf16 arithmetic on the float32 image and bf16 pooled
+    tensors, both operands transposed into LDS.  Against the float64 oracle ON THE ROUNDED OPERANDS (x rounded to bf16, the
+    gradient as the bf16 tensor holds it) the only error left is the fp32 accumulation: 1e-5; against the unrounded image it
+    is the mode's bf16 rounding.  fine/first at full width runs two segments per output row."""
+    rng = np.random.default_rng(1900 + h * w + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, 'VALID', precision='bf16')
+    assert ops.conv2d_bwd_filter_pooled_supported(d)
+    ph, pw = d.ho // 2, d.wo // 2
+    bf = torch.bfloat16
+    pooled_d = dev(rng.standard_normal((n, ph, pw, ld)).astype(np.float32)).to(bf)
+    dpool_d = dev(rng.standard_normal((n, ph, pw, ld)).astype(np.float32)).to(bf)
+    arg = rng.integers(0, 4, (n, ph, pw, lda)).astype(np.uint8)
+    pooled_r, dpool_r = pooled_d.float().cpu().numpy(), dpool_d.float().cpu().numpy()
+    dz = np.zeros((n, d.ho, d.wo, k), np.float64)
+    g = np.where(pooled_r[..., :k] > 0, dpool_r[..., :k], 0.0)
+    for pos in range(4):
+        dz[:, pos >> 1:2 * ph:2, pos & 1:2 * pw:2, :] = np.where(arg[..., :k] == pos, g, 0.0)
+    xr = dev(x).to(bf).double().cpu().numpy()
+    dw_ref, db_ref = T.conv2d_bwd_filter(xr, dz, (ks, ks, c, k), st, 'VALID')
+    dw = torch.full((ks, ks, c, k), float('nan'), device='cuda')
+    db = torch.full((k,), float('nan'), device='cuda')
+    ops.conv2d_bwd_filter_pooled(d, dev(x), dpool_d, pooled_d, torch.from_numpy(arg).cuda(), dw, db)
+    assert rel_l2(dw.cpu().numpy(), dw_ref) < RTOL_F32
+    assert rel_l2(db.cpu().numpy(), db_ref) < RTOL_F32
+    dw_exact, _ = T.conv2d_bwd_filter(x.astype(np.float64), dz, (ks, ks, c, k), st, 'VALID')
+    assert rel_l2(dw.cpu().numpy(), dw_exact) < 4e-3
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_bwd_filter_pooled(d, dev(x), dpool_d, pooled_d, torch.from_numpy(arg).cuda(), dw2, None)
+    np.testing.assert_array_equal(dw.cpu().numpy(), dw2.cpu().numpy())
+
+
 BOTH_CASES = [
     # n, h, w, c, padding, ldx, lddx          (single-output-channel 5x5 convs: fine/third, src/models.py:250-251)
     (2, 21, 30, 64, 'SAME', 64, 64),
