@@ -3,16 +3,19 @@
 // batch 64, where the gradient tensors are bf16 and the fp32 form of the kernel was the largest launch of the fine phase.
 //
 // v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane for BOTH operands, and k is the PIXEL axis here: neither x (a tap's
-// pixels are stride*C floats apart) nor dz (pixel-major, channel-minor) has that in memory.  So both are TRANSPOSED on their
-// way into LDS, a segment of one output row (<= 80 pixels) at a time:
-//   At [128 taps][pixels]  bf16: At[m][p] = x[oy*st + r_m][(p*st + s_m)*C + c_m], gathered with 4-byte loads (L1-resident rows),
-//                          two pixels per thread -> one v_cvt_pk_bf16_f32 and one 4-byte LDS write;
-//   dzT[N][pixels]         bf16: from a bf16 dz tensor, or — MaxPoolGrad + ReluGrad fused, as in fewch.hip — from the pooled
-//                          gradient, the argmax bytes and the pooled activation (two pixels of a window row per 4-byte write).
-// A wave then reads its A fragment and TN B fragments with one 16-byte LDS read each per 16 pixels.  BiasAddGrad is row M of
-// the tile again (At[M][p] = 1).  The MFMAs are a sixth of a segment's time: the kernel is bound by the staging (≈65 gathered
-// loads and as many LDS writes per thread and segment), which is what makes it 4-5x the fp32 form, not 16x.
-// Partial tiles per pixel range go to fp32 slabs and fewch.hip's reduction adds them in split order.
+// pixels are stride*C floats apart) nor dz (pixel-major, channel-minor) has that in memory.  Both tiles therefore sit in LDS
+// pixel-major — as they are produced — and the fragments are read with the transposing LDS read (ds_read_b64_tr_b16), a
+// segment of one output row (<= 80 pixels) at a time:
+//   xs  [<= 6 rows][floats]  the input rows' share of the segment, float32, as 16-byte pieces (coalesced);
+//   Ats [pixels][128 taps]   bf16: Ats[p][m] = x[oy*st + r_m][(p*st + s_m)*C + c_m], built from xs — a thread takes two
+//                            neighbouring taps of one pixel: two LDS reads, one v_cvt_pk_bf16_f32, one 4-byte write;
+//   dzs [pixels][N]          bf16: a bf16 dz tensor as it lies in memory, or — MaxPoolGrad + ReluGrad fused, as in fewch.hip —
+//                            built from the pooled gradient, the argmax bytes and the pooled activation (8-byte writes).
+// (Transposing while WRITING instead — [tap][pixel] / [channel][pixel] tiles, 16-byte fragment reads — put 12- to 32-way
+// bank conflicts on the channel-major scatter: the LDS pipe was busy 7.5 k of a segment's 9.7 k cycles, 92 us for conv2d_0
+// at B = 64.)  BiasAddGrad is tap M of the tile again (Ats[p][M] = 1).  The operands of segment s + 1 are fetched into
+// registers behind the barrier that publishes segment s.  Partial tiles per pixel range go to fp32 slabs and fewch.hip's
+// reduction adds them in split order.
 #include <algorithm>
 
 #include "a3d_internal.h"
@@ -30,6 +33,7 @@ struct Few16Params {
   int ldz, ld_arg;
   int rows_per_img, rows_total, splits, mgroups;
   int rowlen, seg, nseg, PP, ksteps, hp, n4;
+  int XP, xl4;             // floats per staged input row in LDS, 16-byte pieces fetched per row and segment
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,15 +41,52 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKA = 19;              // pixel pairs of the A tile per thread and segment (128 taps x 37 pairs / 256)
+__device__ __forceinline__ bf16x4 few16_read_tr(const __bf16* p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+// fragment of a [k][col] plane for the 32 columns col0 .. col0+31: lane l gets column col0 + (l & 31), k = kbase + 8*(l >> 5) + 0..7
+__device__ __forceinline__ bf16x8 few16_frag_tr(const __bf16* plane, int ld, int col0, int kbase, int lane) {
+  const int g = lane >> 4, l16 = lane & 15;
+  const int q = l16 >> 2, pp = l16 & 3, h = g >> 1, cb = g & 1;
+  const __bf16* a0 = plane + (kbase + 8 * h + q) * ld + col0 + 16 * cb + 4 * pp;
+  const bf16x4 lo4 = few16_read_tr(a0), hi4 = few16_read_tr(a0 + 4 * ld);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo4[e]; r[4 + e] = hi4[e]; }
+  return r;
+}
+
+// A workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also waits for every outstanding global
+// load (s_waitcnt vmcnt(0)): the next segment's operands, fetched into registers a segment ahead, would be waited for at the
+// very next barrier and each segment would expose one memory latency (115 us for conv2d_0 at B = 64, half of all wave cycles
+// waiting: profiles/r05_pmc_fewch16.txt).  Registers that a buffer load still owes are guarded by the compiler's own vmcnt
+// wait at their first use.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kNT = 256;             // (eight waves sharing the staging, halves of a segment's k-steps each, were slower: 108 vs 88 us)
+constexpr int kKA = 19;              // (tap pair, pixel) items of the A tile per thread and segment (64 pairs x 74 pixels / 256)
 constexpr int kKD = 4;               // 4-channel groups of the dz segment per thread (37 windows x 24 groups / 256)
+constexpr int kKX = 6;               // 16-byte pieces of the input rows per thread and segment (6 rows x 228 pieces / 256)
+constexpr int kRows16 = 6;           // input rows one 128-row group of M can touch
 
 template <int TN, bool POOLED, bool VEC>
-__global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params p) {
+__global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-  __bf16* At = reinterpret_cast<__bf16*>(smem16);            // [128][PP]
-  __bf16* dzT = At + 128 * p.PP;                             // [NP][PP]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  constexpr int LDA = 128 + 32;                              // row stride of the [pixel][tap] tile (cols + 32: the transposing read's rows 16 banks apart)
+  const int LDD = p.NP + 32;
+  __bf16* At = reinterpret_cast<__bf16*>(smem16);            // [PPk pixels][LDA]
+  __bf16* dzT = At + p.PP * LDA;                             // [PPk pixels][LDD]
+  float* xs = reinterpret_cast<float*>(dzT + p.PP * LDD);    // [kRows16][XP]: the input rows' segment, float32 as it lies in memory
+  // every LDS access of the staging is UNCONDITIONAL: a slot a thread does not have reads index 0 and writes its own 16 bytes
+  // of this scrap area.  Guarded accesses are one basic block each — the compiler cannot batch reads across them, and every
+  // slot paid an LDS round trip of its own (387 scalar instructions per wave and segment were exec-mask branches).
+  unsigned char* scrap = reinterpret_cast<unsigned char*>(xs + kRows16 * p.XP) + tid * 16;
+  const int scrapA = (int)(scrap - reinterpret_cast<unsigned char*>(At)), scrapD = (int)(scrap - reinterpret_cast<unsigned char*>(dzT));
+  const int scrapX = (int)((scrap - reinterpret_cast<unsigned char*>(xs)) >> 2);
   uint32_t bid = blockIdx.x;
   {                                                          // XCD-aware order: the m-groups of one pixel range share an L2
     const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
@@ -55,32 +96,44 @@ __global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params 
   const int SC = p.S * p.c, stC = p.stride * p.c;
   const int rlo = (mg * 128) / SC;
   // zero both tiles (pad pixels, pad taps, pad channels), then the bias row: ones
-  for (int i = tid; i < (128 + p.NP) * p.PP / 2; i += 256) reinterpret_cast<uint32_t*>(At)[i] = 0u;
+  for (int i = tid; i < p.PP * (LDA + LDD) / 2; i += kNT) reinterpret_cast<uint32_t*>(At)[i] = 0u;
   __syncthreads();
   {
-    const int mb = p.M - mg * 128;                           // the bias row's position in this m-group, if it has it
+    const int mb = p.M - mg * 128;                           // the bias tap's position in this m-group, if it has it
     if (mb >= 0 && mb < 128)
-      for (int i = tid; i < p.PP; i += 256) At[mb * p.PP + i] = (__bf16)1.f;
+      for (int i = tid; i < p.PP; i += kNT) At[i * LDA + mb] = (__bf16)1.f;
   }
   // ---- per-thread constants of the staging: which pixel pairs of which taps, which channel groups of which windows
-  int adst[kKA];
-  uint32_t xoff[kKA];
+  // consecutive threads take consecutive tap PAIRS of one pixel (conflict-free reads of xs, conflict-free 4-byte writes of the
+  // tile).  256 is a multiple of 64, so a thread keeps ONE tap pair for all its slots and walks the pixels in steps of four: no
+  // per-slot tables (they were 95 registers and pushed the kernel into spilling).
+  const int mp = tid & 63, px0 = tid >> 6, m0 = mg * 128 + 2 * mp;
+  const bool ok0 = m0 < p.M, ok1 = m0 + 1 < p.M;
+  const int r0 = ok0 ? m0 / SC : 0, r1 = ok1 ? (m0 + 1) / SC : 0;
+  const int base0 = ok0 ? (r0 - rlo) * p.XP + (m0 - r0 * SC) : 0;                 // float index into xs of pixel 0 (plus the segment's shift)
+  const int base1 = ok1 ? (r1 - rlo) * p.XP + (m0 + 1 - r1 * SC) : 0;
+  const float fill1 = (ok0 && m0 + 1 == p.M) ? 1.f : 0.f;                         // the pair's second tap is the bias tap (ones) or padding
+  // the input rows reach LDS as 16-byte pieces (coalesced), the taps are gathered from there: 4-byte gathers straight from
+  // global memory kept the address unit busy for the whole segment (103 us for conv2d_0 at B = 64)
+  const int nr = min(p.M - 1, mg * 128 + 127) / SC - rlo + 1;
+  int xsdst[kKX];
+  uint32_t xsrc[kKX];
 #pragma unroll
-  for (int i = 0; i < kKA; ++i) {
-    const int e = tid + i * 256, ml = e / p.hp, pp = e - ml * p.hp, m = mg * 128 + ml;
-    const bool ok = ml < 128 && m < p.M;
-    const int r = ok ? m / SC : 0, j = ok ? m - r * SC : 0;
-    adst[i] = ok ? (ml * p.PP + 2 * pp) * 2 : -1;
-    xoff[i] = ok ? (uint32_t)(((r - rlo) * p.rowlen + j + 2 * pp * stC) * 4) : kOOB;
+  for (int i = 0; i < kKX; ++i) {
+    const int e = tid + i * kNT, rr = e / p.xl4, q = e - rr * p.xl4;
+    const bool ok = rr < nr;
+    xsdst[i] = ok ? rr * p.XP + 4 * q : scrapX;
+    xsrc[i] = ok ? (uint32_t)((rr * p.rowlen + 4 * q) * 4) : kOOB;
   }
-  int ddst[kKD];
+  int ddst[kKD], ddst2[kKD];
   uint32_t doff[kKD], aoff[kKD], dlive[kKD];
   const int dtotal = p.hp * p.n4;
 #pragma unroll
   for (int i = 0; i < kKD; ++i) {
-    const int e = tid + i * 256, px = e / p.n4, q = 4 * (e - px * p.n4);
+    const int e = tid + i * kNT, px = e / p.n4, q = 4 * (e - px * p.n4);
     const bool ok = e < dtotal;
-    ddst[i] = ok ? (q * p.PP + 2 * px) * 2 : -1;
+    ddst[i] = ok ? (2 * px * LDD + q) * 2 : scrapD;           // byte offset of dzs[2px][q]; the second pixel: + LDD
+    ddst2[i] = ok ? ddst[i] + LDD * 2 : scrapD + 8;
     // plain source: the pixel PAIR (2px, 2px+1) of the segment; pooled: window px of the segment's half
     doff[i] = ok ? (uint32_t)(((POOLED ? px : 2 * px) * p.ldz + q) * 2) : kOOB;
     aoff[i] = ok ? (uint32_t)(px * p.ld_arg + q) : kOOB;
@@ -99,22 +152,25 @@ __global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params 
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
-  const long stages_total = (long)p.rows_total * p.nseg;
-  const long st_lo = (long)split * stages_total / p.splits, st_hi = (long)(split + 1) * stages_total / p.splits;
-  for (long stg = st_lo; stg < st_hi; ++stg) {
-    const int row = (int)(stg / p.nseg), segi = (int)(stg - (long)row * p.nseg);
-    const int img = row / p.rows_per_img, oy = row - img * p.rows_per_img;
-    const int seg0 = segi * p.seg;
-    // ---- every load of the segment in flight, then convert and write
-    const uint32_t xbase = (uint32_t)((((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen + (size_t)seg0 * stC) * 4);
-    float a0[kKA], a1[kKA];
+  // ---- a segment's operands: fetch() issues every global load of it into registers — one segment ahead, behind the barrier
+  //      that publishes the previous one, so the loads fly while At is built and the MFMAs run (without it every segment
+  //      exposed one memory latency: 112 us for conv2d_0 at B = 64) — commit() writes them to LDS
+  u32x4 xv[kKX];
+  bf16x4 g0[kKD], g1[kKD];
+  uint32_t argv[kKD];
+  auto where = [&](int stg, int& img, int& oy, int& seg0) {      // (32-bit: a 64-bit division here cost more than the segment's MFMAs)
+    const int row = stg / p.nseg, segi = stg - row * p.nseg;
+    img = row / p.rows_per_img;
+    oy = row - img * p.rows_per_img;
+    seg0 = segi * p.seg;
+  };
+  auto fetch = [&](int stg) {
+    int img, oy, seg0;
+    where(stg, img, oy, seg0);
+    const int start4 = (seg0 * stC) & ~3;              // the segment's first float, rounded down to a 16-byte piece
+    const uint32_t xbase = (uint32_t)((((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen + (size_t)start4) * 4);
 #pragma unroll
-    for (int i = 0; i < kKA; ++i) {
-      a0[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)(xbase + xoff[i]), 0, 0));
-      a1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)(xoff[i] == kOOB ? kOOB : xbase + xoff[i] + (uint32_t)stC * 4u), 0, 0));
-    }
-    bf16x4 g0[kKD], g1[kKD];
-    uint32_t argv[kKD];
+    for (int i = 0; i < kKX; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xsrc[i] == kOOB ? kOOB : xbase + xsrc[i]), 0, 0);
     if constexpr (POOLED) {
       const size_t prow = ((size_t)img * ph + (oy >> 1)) * pw + (seg0 >> 1);
       const uint32_t dbase = (uint32_t)(prow * p.ldz * 2), abase = (uint32_t)(prow * p.ld_arg);
@@ -140,15 +196,17 @@ __global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params 
         g1[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rd, (int)(doff[i] == kOOB ? kOOB : dbase + doff[i] + (uint32_t)p.ldz * 2u), 0, 0));
       }
     }
-    __syncthreads();                                  // the previous segment's MFMAs have read their operands
+  };
+  auto commit = [&](int stg) {
+    int img, oy, seg0;
+    where(stg, img, oy, seg0);
 #pragma unroll
-    for (int i = 0; i < kKA; ++i)
-      if (adst[i] >= 0)
-        *reinterpret_cast<bf16x2*>(reinterpret_cast<unsigned char*>(At) + adst[i]) = bf16x2{(__bf16)a0[i], (__bf16)a1[i]};
+    for (int i = 0; i < kKX; ++i)
+      *reinterpret_cast<u32x4*>(xs + xsdst[i]) = xv[i];
 #pragma unroll
-    for (int i = 0; i < kKD; ++i)
-      if (ddst[i] >= 0) {
+    for (int i = 0; i < kKD; ++i) {
         unsigned char* dst = reinterpret_cast<unsigned char*>(dzT) + ddst[i];
+        bf16x4 lo, hi;
         if constexpr (POOLED) {
           // MaxPoolGrad + ReluGrad: window px hands its gradient to position argmax, if the maximum was > 0
           const uint32_t want = (uint32_t)(oy & 1) * 2u;
@@ -157,28 +215,78 @@ __global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params 
             const bool live = (uint32_t)e < dlive[i] && (!p.pooled || (float)g1[i][e] > 0.f);
             const __bf16 g = live ? g0[i][e] : (__bf16)0.f;
             const uint32_t a = (argv[i] >> (8 * e)) & 0xffu;
-            *reinterpret_cast<bf16x2*>(dst + (size_t)e * p.PP * 2) = bf16x2{a == want ? g : (__bf16)0.f, a == want + 1u ? g : (__bf16)0.f};
+            lo[e] = a == want ? g : (__bf16)0.f;
+            hi[e] = a == want + 1u ? g : (__bf16)0.f;
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool live = (uint32_t)e < dlive[i];
-            *reinterpret_cast<bf16x2*>(dst + (size_t)e * p.PP * 2) = bf16x2{live ? g0[i][e] : (__bf16)0.f, live ? g1[i][e] : (__bf16)0.f};
+            lo[e] = live ? g0[i][e] : (__bf16)0.f;
+            hi[e] = live ? g1[i][e] : (__bf16)0.f;
           }
         }
+        *reinterpret_cast<bf16x4*>(dst) = lo;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned char*>(dzT) + ddst2[i]) = hi;
       }
-    __syncthreads();
-    // ---- 16 pixels per MFMA: one 16-byte LDS read per fragment
-    const __bf16* ap = At + (wv * 32 + li) * p.PP + 8 * lh;
-    const __bf16* bp = dzT + li * p.PP + 8 * lh;
-    for (int u = 0; u < p.ksteps; ++u) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + 16 * u);
+  };
+
+  const int stages_total = p.rows_total * p.nseg;
+  const int st_lo = (int)((long)split * stages_total / p.splits), st_hi = (int)((long)(split + 1) * stages_total / p.splits);
+  if (st_lo < st_hi) fetch(st_lo);
+  for (int stg = st_lo; stg < st_hi; ++stg) {
+    int img, oy, seg0;
+    where(stg, img, oy, seg0);
+    const int shift = seg0 * stC - ((seg0 * stC) & ~3);
+    lds_barrier();                                  // the previous segment's MFMAs (and its At build) have read their operands
+    commit(stg);
+    lds_barrier();
+    if (stg + 1 < st_hi) fetch(stg + 1);
+    // ---- the [pixel][tap] tile from the staged rows: two neighbouring taps of one pixel per thread and slot.  All reads
+    //      first, then all writes: interleaved, every write had to precede the next read (both are LDS: they may alias as far
+    //      as the compiler knows) and the build was nineteen serial LDS round trips.
+    // (five slots at a time: reads batched, their lane masks not kept alive across all nineteen)
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + t * 32 * p.PP + 16 * u);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    for (int c = 0; c < kKA; c += 5) {
+      float t0[5], t1[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int px = px0 + 4 * (c + i);
+        const bool v = c + i < kKA && ok0 && px < p.seg;
+        t0[i] = xs[v ? base0 + px * stC + shift : 0];
+        t1[i] = xs[(v && ok1) ? base1 + px * stC + shift : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int px = px0 + 4 * (c + i);
+        const bool v = c + i < kKA && ok0 && px < p.seg;
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<unsigned char*>(At) + (v ? (px * LDA + 2 * mp) * 2 : scrapA)) =
+            bf16x2{(__bf16)t0[i], ok1 ? (__bf16)t1[i] : (__bf16)fill1};
       }
     }
+    lds_barrier();
+    // ---- 16 pixels per MFMA: fragments through the transposing LDS read (two 8-byte reads each), the next k-step's
+    //      fragments read while this one's MFMAs run
+    bf16x8 fa[2], fb[2][TN];
+    auto frags = [&](int u, int buf) {
+      fa[buf] = few16_frag_tr(At, LDA, wv * 32, 16 * u, lane);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) fb[buf][t] = few16_frag_tr(dzT, LDD, t * 32, 16 * u, lane);
+    };
+    auto mul = [&](int buf) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf], fb[buf][t], acc[t], 0, 0, 0);
+    };
+    const int u_lo = 0, u_hi = p.ksteps;
+    if (u_lo < u_hi) frags(u_lo, 0);
+    int u = u_lo;
+    for (; u + 2 <= u_hi; u += 2) {
+      frags(u + 1, 1);
+      mul(0);
+      if (u + 2 < u_hi) frags(u + 2, 0);
+      mul(1);
+    }
+    if (u < u_hi) mul(0);
   }
   float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * p.NP;
 #pragma unroll
@@ -191,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void fewch16_bwdf_kernel(const Few16Params 
 
 // ---- host side ----
 struct Few16Shape {
-  int M, Mp, mgroups, TN, NP, rows_per_img, rows_total, splits, seg, nseg, PP, ksteps, hp, n4;
+  int M, Mp, mgroups, TN, NP, rows_per_img, rows_total, splits, seg, nseg, PP, ksteps, hp, n4, XP, xl4;
   size_t lds;
   bool ok;
 };
@@ -213,10 +321,15 @@ static Few16Shape few16_shape(const a3d_conv_desc* d, bool pooled) {
   s.hp = s.seg / 2;
   s.n4 = (d->k + 3) / 4;
   s.ksteps = (s.seg + 15) / 16;
-  s.PP = s.ksteps * 16 + 8;
+  s.PP = s.ksteps * 16;                               // pixels of a segment, padded to whole MFMA k-steps
   s.splits = std::max(1, std::min(s.rows_total * s.nseg / 4, tune_int("A3D_FEWCH_BLOCKS", 512) / s.mgroups));
-  s.lds = (size_t)(128 + s.NP) * s.PP * 2;
-  s.ok = 128 * s.hp <= kKA * 256 && s.hp * s.n4 <= kKD * 256 && s.lds <= 64 * 1024;
+  // the input rows' share of a segment: (seg - 1) * st*C + S*C floats after a start rounded down to a 16-byte piece
+  const int need = 3 + (s.seg - 1) * d->stride * d->c + d->s * d->c;
+  s.xl4 = std::min((need + 3) / 4, (d->w * d->c) / 4);
+  s.XP = s.xl4 * 4 + 4;
+  s.lds = (size_t)s.PP * (160 + s.NP + 32) * 2 + (size_t)kRows16 * s.XP * 4 + kNT * 16;
+  s.ok = 64 * s.seg <= kKA * kNT && s.hp * s.n4 <= kKD * kNT && kRows16 * s.xl4 <= kKX * kNT && s.lds <= 78 * 1024 &&
+         (d->w * d->c) % 4 == 0;
   return s;
 }
 
@@ -238,7 +351,10 @@ size_t fewch16_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled) {
 
 template <int TN, bool POOLED, bool VEC>
 static void few16_launch(const Few16Params& p, int blocks, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((fewch16_bwdf_kernel<TN, POOLED, VEC>), dim3(blocks), dim3(256), lds, st, p);
+  // a little above 64 KiB of dynamic LDS: the attribute is per device and cheap, set on every call
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch16_bwdf_kernel<TN, POOLED, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            80 * 1024);
+  hipLaunchKernelGGL((fewch16_bwdf_kernel<TN, POOLED, VEC>), dim3(blocks), dim3(kNT), lds, st, p);
 }
 
 int fewch16_bwd_filter(const a3d_conv_desc* d, const float* x, bool pooled, const void* dz, int ldz, const void* pooled_act,
@@ -251,6 +367,7 @@ int fewch16_bwd_filter(const a3d_conv_desc* d, const float* x, bool pooled, cons
   p.N = d->k; p.M = s.M; p.Mp = s.Mp; p.NP = s.NP; p.ldz = ldz; p.ld_arg = ld_arg;
   p.rows_per_img = s.rows_per_img; p.rows_total = s.rows_total; p.splits = s.splits; p.mgroups = s.mgroups;
   p.rowlen = d->w * d->c; p.seg = s.seg; p.nseg = s.nseg; p.PP = s.PP; p.ksteps = s.ksteps; p.hp = s.hp; p.n4 = s.n4;
+  p.XP = s.XP; p.xl4 = s.xl4;
   const bool vec = pooled && d->k % 4 == 0 && ld_arg % 4 == 0 && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0;
   const int blocks = s.splits * s.mgroups;
   clear_stale_error();

@@ -1388,7 +1388,7 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
   if (fewch16_wanted(d, true)) {                    // bf16 arithmetic: float32 image, bf16 pooled tensors
     A3D_CHECK_ARG(pooled_bf16 && ld_dpool >= d->k && ld_argmax >= d->k && ld_dpool % 4 == 0 &&
                       (reinterpret_cast<uintptr_t>(dpool) & 7) == 0 && (reinterpret_cast<uintptr_t>(pooled) & 7) == 0 &&
-                      (reinterpret_cast<uintptr_t>(x) & 3) == 0,
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0,
                   "conv2d_bwd_filter_pooled: bf16 arithmetic takes bf16 pooled tensors in whole aligned 4-channel groups");
     if (fewch16_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
     TimingSlot slot{};

@@ -311,8 +311,10 @@ class MSDNReplica:
                           ('fine/first/conv2d', ops.conv_desc(B, NET_H, NET_W, 3, 63, 9, 9, 2, 'VALID', precision=few_prec))):
                 if ops.conv2d_bwd_filter_pooled_supported(dd):
                     self.d_few[n] = dd
-            if self.bf16s and few_prec == 'fp32' and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
-                self.d_few.pop('coarse/conv/conv2d_0', None)   # (fp32 arithmetic there: 191 us against 78 + 18 for igemm_bf16 + MaxPoolGrad)
+            if self.bf16s and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
+                # config 5's conv2d_0 keeps igemm_bf16 + MaxPoolGrad (78 + 18 us at B = 64) — fewch16 takes 91 + 11 there, the
+                # fp32 form 191; fine/first is where the fused kernel pays (222 + 11 against 373 + 13 for the fp32 form)
+                self.d_few.pop('coarse/conv/conv2d_0', None)
         # bf16 storage: per layer, which tensors of the forward / bwd-data / bwd-filter call are bf16 (ops.STORE_*), and
         # the bf16 copies of the kernels (refreshed whenever the fp32 masters change)
         self.store = {}
