@@ -16,5 +16,5 @@ def grad_tol(name):
     if name.startswith('fine/second'):
         return 3.2e-3                                   # observed 2.1e-3
     if name.startswith('fine/first'):
-        return 4.6e-3                                   # observed 3.1e-3
+        return 5.5e-3                                   # observed 3.6e-3 (its filter gradient in bf16 arithmetic: fewch16.hip)
     raise KeyError(name)
