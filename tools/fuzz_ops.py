@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ann3depth_amd import ops  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+R5 = float(os.environ.get('FUZZ_R5', '5'))       # weight of round 5's kernel classes (x 5 %): FUZZ_R5=19 fuzzes almost only those
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 TOL = 3e-6
 TOL_POOL = 2e-5
@@ -253,6 +254,168 @@ def run_dense():
     return (m, k, n), err
 
 
+RAN = {}
+
+
+def ran(what):
+    RAN[what] = RAN.get(what, 0) + 1
+
+
+def fewch_case():
+    """Few-channel VALID convolutions the LDS-staged filter-gradient kernels take (fewch.hip / fewch16.hip): 1..4 channels,
+    S*C >= 27, 33..96 filters, input rows of whole 16-byte pieces, rows short enough for the staging registers."""
+    c = int(rng.choice([3, 3, 3, 4, 2]))
+    ks = int(rng.choice([k for k in (7, 9, 9, 11, 11, 13, 14) if k * c >= 27]))
+    st = int(rng.choice([1, 2, 2, 4, 4]))
+    k = int(rng.choice([33, 40, 48, 63, 64, 80, 96]))
+    while True:
+        w = int(rng.integers(ks + 2 * st, 320))
+        if (w * c) % 4 == 0:
+            break
+    h = int(rng.integers(ks + 2 * st, 120))
+    n = int(rng.integers(1, 9))
+    return n, h, w, c, k, ks, st
+
+
+def run_fewch(n, h, w, c, k, ks, st):
+    """a3d_conv2d_bwd_filter (plain) and a3d_conv2d_bwd_filter_pooled (MaxPoolGrad + ReluGrad fused; float32 and bf16 pooled
+    tensors; fp32 and bf16 arithmetic) against torch float64 on the gradient the separate path would materialise.
+    -> error relative to TOL (bf16 arithmetic: against the oracle on the bf16-rounded image, same yardstick)"""
+    bf = torch.bfloat16
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, st, 'VALID')
+    if d.ho < 2 or d.wo < 2:
+        return 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, h, w, c), device='cuda', generator=g)
+    ph, pw = d.ho // 2, d.wo // 2
+    ld = int(rng.choice([k, (k + 7) // 8 * 8, (k + 3) // 4 * 4 + 4]))
+    ld = (ld + 3) // 4 * 4
+    lda = int(rng.choice([k, ld]))
+    pooled = torch.randn((n, ph, pw, ld), device='cuda', generator=g)
+    dpool = torch.randn((n, ph, pw, ld), device='cuda', generator=g)
+    arg = torch.randint(0, 4, (n, ph, pw, lda), device='cuda', generator=g, dtype=torch.uint8)
+
+    def reference(xs, dp, pl):
+        gsel = torch.where(pl[..., :k] > 0, dp[..., :k], torch.zeros_like(dp[..., :k])).double()
+        exp = torch.zeros((n, ph, pw, k, 4), device='cuda', dtype=torch.float64)
+        exp.scatter_(-1, arg[..., :k].long().unsqueeze(-1), gsel.unsqueeze(-1))
+        dz = torch.zeros((n, d.ho, d.wo, k), device='cuda', dtype=torch.float64)
+        dz[:, :2 * ph, :2 * pw] = exp.reshape(n, ph, pw, k, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2 * ph, 2 * pw, k)
+        xd = xs.double().permute(0, 3, 1, 2)
+        wd = torch.zeros((k, c, ks, ks), device='cuda', dtype=torch.float64, requires_grad=True)
+        ref = F.conv2d(xd, wd, stride=st)
+        gw, = torch.autograd.grad(ref, [wd], dz.permute(0, 3, 1, 2))
+        wa = torch.zeros_like(wd).requires_grad_(True)
+        gwa, = torch.autograd.grad(F.conv2d(xd.abs(), wa, stride=st), [wa], dz.abs().permute(0, 3, 1, 2))
+        return dz, gw.permute(2, 3, 1, 0), gwa.permute(2, 3, 1, 0)
+
+    err = 0.0
+    dw = torch.full((ks, ks, c, k), float('nan'), device='cuda')
+    db = torch.full((k,), float('nan'), device='cuda')
+    if ops.conv2d_bwd_filter_pooled_supported(d):
+        ran('fewch fp32 arithmetic (pooled f32 + bf16 sources, plain)')
+        for dt in (torch.float32, bf):
+            dp, pl = dpool.to(dt), pooled.to(dt)
+            dz, gw, gwa = reference(x, dp.float(), pl.float())
+            ops.conv2d_bwd_filter_pooled(d, x, dp, pl, arg, dw.fill_(float('nan')), db.fill_(float('nan')))
+            err = max(err, rel(dw, gw, gwa), rel(db, dz.sum((0, 1, 2)), dz.abs().sum((0, 1, 2))))
+        # the plain form on the materialised gradient
+        dzf = dz.float()
+        dz64, gw, gwa = reference(x, dpool.to(bf).float(), pooled.to(bf).float())
+        ops.conv2d_bwd_filter(d, x, dzf, dw.fill_(float('nan')), db.fill_(float('nan')))
+        err = max(err, rel(dw, gw, gwa))
+    d16 = ops.conv_desc(n, h, w, c, k, ks, ks, st, 'VALID', precision='bf16')
+    if ops.conv2d_bwd_filter_pooled_supported(d16):
+        ran('fewch16 bf16 arithmetic')
+        dp, pl = dpool.to(bf), pooled.to(bf)
+        dz, gw, gwa = reference(x.to(bf), dp.float(), pl.float())
+        ops.conv2d_bwd_filter_pooled(d16, x, dp, pl, arg, dw.fill_(float('nan')), db.fill_(float('nan')))
+        err = max(err, rel(dw, gw, gwa), rel(db, dz.sum((0, 1, 2)), dz.abs().sum((0, 1, 2))))
+    return err
+
+
+def run_bwd_both():
+    """a3d_conv2d_bwd_both (one output channel, 5x5: filter, bias and input gradient + ReluGrad in one pass) against torch
+    float64; float32 and bf16 dx; twice on one state buffer, bit-identical."""
+    bf = torch.bfloat16
+    c = int(rng.choice([2, 8, 24, 40, 64, 64, 64]))
+    ldx = c + int(rng.choice([0, 0, 2, 8]))
+    n, h, w = int(rng.integers(1, 12)), int(rng.integers(5, 60)), int(rng.integers(5, 78))
+    pad = str(rng.choice(['SAME', 'VALID']))
+    d = ops.conv_desc(n, h, w, c, 1, 5, 5, 1, pad, ldx=ldx)
+    if d.ho < 1 or d.wo < 1 or not ops.conv2d_bwd_both_supported(d):
+        return (n, h, w, c, pad), 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    xb = torch.randn((n, h, w, ldx), device='cuda', generator=g)
+    wt = torch.randn((5, 5, c, 1), device='cuda', generator=g) / np.sqrt(25 * c)
+    dz = torch.randn((n, d.ho, d.wo, 1), device='cuda', generator=g)
+    pt = 2 if pad == 'SAME' else 0
+    xd = xb[..., :c].double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = wt.double().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    ref = F.conv2d(F.pad(xd, (pt, pt, pt, pt)), wd)
+    gx, gw = torch.autograd.grad(ref, [xd, wd], dz.double().permute(0, 3, 1, 2))
+    xa = xb[..., :c].double().abs().permute(0, 3, 1, 2).requires_grad_(True)
+    wa = wt.double().abs().permute(3, 2, 0, 1).contiguous().requires_grad_(True)
+    gxa, gwa = torch.autograd.grad(F.conv2d(F.pad(xa, (pt, pt, pt, pt)), wa), [xa, wa], dz.double().abs().permute(0, 3, 1, 2))
+    mask = (xb[..., :c] > 0).double()
+    err = 0.0
+    ran('bwd_both')
+    for dt, tol_scale in ((torch.float32, 1.0), (bf, TOL / TOL_BF16_OUT)):
+        outs = []
+        for _ in range(2):
+            dw = torch.full_like(wt, float('nan'))
+            db = torch.full((1,), float('nan'), device='cuda')
+            dx = torch.full((n, h, w, c), float('nan'), device='cuda', dtype=dt)
+            ops.conv2d_bwd_both(d, xb, dz, wt, dw, db, dx, relu_mask=True)
+            outs.append((dw, db, dx))
+        if not all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])):
+            return (n, h, w, c, pad), 1.0
+        dw, db, dx = outs[0]
+        err = max(err, rel(dw, gw.permute(2, 3, 1, 0), gwa.permute(2, 3, 1, 0)), rel(db, dz.double().sum().reshape(1), dz.double().abs().sum().reshape(1)),
+                  rel(dx.float(), gx.permute(0, 2, 3, 1) * mask, gxa.permute(0, 2, 3, 1)) * tol_scale)
+    return (n, h, w, c, pad), err
+
+
+def run_image_form(n, h, w, c, k, ks, st):
+    """The bf16 image form of the few-channel forward (conv3b_fwd_kernel for >= 33 filters): 4-channel bf16 image, with and
+    without the fused pool and a prepared filter, against torch float64 on the rounded operands (outputs bf16: 4e-3)."""
+    bf = torch.bfloat16
+    if st % 2 or c > 3:
+        return 0.0
+    ldy = (k + 7) // 8 * 8
+    d = ops.with_storage(ops.conv_desc(n, h, w, 4, k, ks, ks, st, 'VALID', ldy=ldy, precision='bf16'), ops.STORE_X | ops.STORE_Y)
+    if d.ho < 2 or d.wo < 2:
+        return 0.0
+    g = torch.Generator(device='cuda').manual_seed(int(rng.integers(1 << 30)))
+    x3 = torch.rand((n, h, w, 3), device='cuda', generator=g)
+    x4 = torch.empty((n, h, w, 4), device='cuda', dtype=bf)
+    ops.pad_channels_bf16(x3, x4)
+    w4 = torch.zeros((ks, ks, 4, k), device='cuda')
+    w4[:, :, :3] = torch.randn((ks, ks, 3, k), device='cuda', generator=g) / np.sqrt(ks * ks * 3)
+    w4[:, :, 3] = 5.0                                   # the pad channel of the filter: anything (its pixels are zero)
+    b = torch.randn((k,), device='cuda', generator=g) * 0.1
+    ran('bf16 image form, >= 33 filters (conv3b)' if k >= 33 else 'bf16 image form (igemm_bf16)')
+    ref = F.conv2d(x4[..., :3].double().permute(0, 3, 1, 2), w4[:, :, :3].to(bf).double().permute(3, 2, 0, 1).contiguous(), b.double(),
+                   stride=st).clamp_min(0).permute(0, 2, 3, 1)
+    y = torch.full((n, d.ho, d.wo, ldy), -3.0, device='cuda', dtype=bf)
+    pf = ops.PreparedFilter(d, x4.device)
+    if pf.ok and rng.random() < 0.5:
+        pf.refresh(w4)
+        ops.conv2d_fwd(pf.desc_prepared, x4, pf.buf, b, y, 'relu')
+    else:
+        ops.conv2d_fwd(d, x4, w4, b, y, 'relu')
+    err = rel(y[..., :k].float(), ref)
+    ph, pw = d.ho // 2, d.wo // 2
+    pooled = torch.full((n, ph, pw, ldy), -3.0, device='cuda', dtype=bf)
+    arg = torch.full((n, ph, pw, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, x4, w4, b, pooled, 'relu', arg)
+    win = y[:, :2 * ph, :2 * pw, :k].float().reshape(n, ph, 2, pw, 2, k).permute(0, 1, 3, 5, 2, 4).reshape(n, ph, pw, k, 4)
+    want, want_arg = win.max(-1).values, (win == win.max(-1, keepdim=True).values).float().argmax(-1)
+    if not (torch.equal(pooled[..., :k].float(), want) and torch.equal(arg.long(), want_arg)):
+        return 1.0
+    return err * TOL / TOL_BF16_OUT
+
+
 def force_plan():
     """Half of the cases pin a tile config and either a split-K factor or a stream-K grid (the planner's own picks cover
     only a few of the combinations the kernels support)."""
@@ -277,7 +440,24 @@ count, worst = 0, (0.0, None)
 while time.time() < t_end:
     forced = force_plan()
     u = rng.random()
-    if u < 0.05:
+    if u < 0.05 * R5:
+        # round 5's kernels: their own plans, no forced tiles
+        for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK', 'A3D_FORCE_SK_SLICED'):
+            os.environ.pop(v, None)
+        forced = 'auto'
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            case = fewch_case()
+            err = run_fewch(*case)
+            case = ('fewch / fewch16 filter gradient',) + case
+        elif kind == 1:
+            case, err = run_bwd_both()
+            case = ('bwd_both',) + case
+        else:
+            case = fewch_case()
+            err = run_image_form(*case)
+            case = ('bf16 image form',) + case
+    elif u < 0.05 * R5 + 0.05:
         for v in ('A3D_FORCE_CFG', 'A3D_FORCE_SPLITK', 'A3D_FORCE_STREAMK', 'A3D_FORCE_SK_SLICED'):
             os.environ.pop(v, None)                       # both paths on the weight-streaming kernels
         forced = 'auto'
@@ -321,4 +501,5 @@ while time.time() < t_end:
     if err > worst[0]:
         worst = (err, case)
 print(f'{count} cases, worst rel-L2 {worst[0]:.2e} at {worst[1]}')
+print('round-5 kernels exercised:', RAN)
 sys.exit(0 if worst[0] <= TOL else 1)
