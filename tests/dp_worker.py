@@ -90,6 +90,25 @@ def main(out_path):
     assert np.array_equal(gathered.numpy(), one.m['w']), 'sharded m differs from one rank on the summed gradient'
     assert float(np.abs(one.m['w']).max()) > 0
     assert red.agree_all([rank, 5 - rank, 0]) == [1, 5, 0]
+    # ---- the second communicator for the buckets the step waits for at its end (A3D_DP_URGENT_GROUP=1; off by default,
+    # DESIGN 5): a large bucket started first on the data group, the small one after it on the urgent group — the small one
+    # can be waited for FIRST, both sums are right, and without the switch `urgent=True` falls back to the one group
+    assert red.urgent_group is None
+    os.environ['A3D_DP_URGENT_GROUP'] = '1'
+    red2 = dp.GradReducer()                                   # (new_group is collective: both ranks construct it here)
+    del os.environ['A3D_DP_URGENT_GROUP']
+    assert red2.urgent_group is not None and red2.urgent_group is not red2.group
+    big = torch.full((1 << 20,), float(rank + 1))
+    small = torch.full((256,), float(10 * (rank + 1)))
+    hb = red2.start(big)
+    hs = red2.start(small, urgent=True)
+    red2.wait(hs)
+    assert red2.pending == [hb] and torch.equal(small, torch.full((256,), 30.0))
+    red2.finish()
+    assert red2.pending == [] and torch.equal(big, torch.full((1 << 20,), 3.0))
+    again = torch.full((8,), float(rank))
+    red.wait(red.start(again, urgent=True))                   # no second communicator: same result on the data group
+    assert torch.equal(again, torch.full((8,), 1.0))
     # ---- the driver's per-step decision (ann3depth.Session._decide): an exhausted input on ONE rank stops both cleanly, a
     # reader FAILURE on one rank is raised on both (it used to look like a clean end of input), the chief's
     # checkpoint request reaches everybody
