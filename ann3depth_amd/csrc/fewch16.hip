@@ -111,8 +111,18 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
   const bool ok0 = m0 < p.M, ok1 = m0 + 1 < p.M;
   const int r0 = ok0 ? m0 / SC : 0, r1 = ok1 ? (m0 + 1) / SC : 0;
   const int base0 = ok0 ? (r0 - rlo) * p.XP + (m0 - r0 * SC) : 0;                 // float index into xs of pixel 0 (plus the segment's shift)
-  const int base1 = ok1 ? (r1 - rlo) * p.XP + (m0 + 1 - r1 * SC) : 0;
+  const int base1 = ok1 ? (r1 - rlo) * p.XP + (m0 + 1 - r1 * SC) : base0;
   const float fill1 = (ok0 && m0 + 1 == p.M) ? 1.f : 0.f;                         // the pair's second tap is the bias tap (ones) or padding
+  // The build below has NO per-slot validity test (nineteen lane masks were 38 scalar registers: the kernel spilled 90-170 of
+  // them into vector lanes and read them back with one v_readlane each, 85 per segment, and every address went through a
+  // select): a slot past the segment's last pixel is CLAMPED to that pixel and writes the same values to the same place as the
+  // slot that owns it; a thread whose tap pair lies past M reads pixel addresses of tap 0 and writes all its slots to its own
+  // scrap bytes (stride 0).
+  const int rstride = stC * 4, rdelta = (base1 - base0) * 4;
+  const int wbase = ok0 ? 4 * mp : scrapA, wstride = ok0 ? LDA * 2 : 0;
+  int pxc[kKA];
+#pragma unroll
+  for (int k = 0; k < kKA; ++k) pxc[k] = min(px0 + 4 * k, p.seg - 1);
   // the input rows reach LDS as 16-byte pieces (coalesced), the taps are gathered from there: 4-byte gathers straight from
   // global memory kept the address unit busy for the whole segment (103 us for conv2d_0 at B = 64)
   const int nr = min(p.M - 1, mg * 128 + 127) / SC - rlo + 1;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
     const int start4 = (seg0 * stC) & ~3;              // the segment's first float, rounded down to a 16-byte piece
     const uint32_t xbase = (uint32_t)((((size_t)img * p.h + (size_t)oy * p.stride + rlo) * p.rowlen + (size_t)start4) * 4);
 #pragma unroll
-    for (int i = 0; i < kKX; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xsrc[i] == kOOB ? kOOB : xbase + xsrc[i]), 0, 0);
+    for (int i = 0; i < kKX; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xbase + xsrc[i]), 0, 0);     // (a slot without a piece: 2^31 past a base below 2^31, outside every buffer)
     if constexpr (POOLED) {
       const size_t prow = ((size_t)img * ph + (oy >> 1)) * pw + (seg0 >> 1);
       const uint32_t dbase = (uint32_t)(prow * p.ldz * 2), abase = (uint32_t)(prow * p.ld_arg);
@@ -193,42 +203,60 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
 #pragma unroll
       for (int i = 0; i < kKD; ++i) {
         g0[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rd, (int)(dbase + doff[i]), 0, 0));
-        g1[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rd, (int)(doff[i] == kOOB ? kOOB : dbase + doff[i] + (uint32_t)p.ldz * 2u), 0, 0));
+        g1[i] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rd, (int)(dbase + doff[i] + (uint32_t)p.ldz * 2u), 0, 0));
       }
     }
   };
+  // 16-bit lanes of a dword: all ones where ...
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  auto positive = [](uint32_t two_bf16) -> uint32_t {        // ... the bf16 is > 0 (+inf yes; NaN, -0, 0 no): u - 1 < 0x7f80 unsigned
+    const u16x2 u = __builtin_bit_cast(u16x2, two_bf16);
+    const u16x2 t = __builtin_elementwise_min((u16x2)(u - (u16x2){1, 1}), (u16x2){0x7f80, 0x7f80});
+    return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, (u16x2)(t - (u16x2){0x7f80, 0x7f80})) >> (s16x2){15, 15}));
+  };
+  auto is_zero = [](uint32_t two_u16) -> uint32_t {          // ... the 16-bit value is 0 (values below 2^15)
+    return __builtin_bit_cast(uint32_t, (s16x2)((__builtin_bit_cast(s16x2, two_u16) - (s16x2){1, 1}) >> (s16x2){15, 15}));
+  };
+  // per-slot channel masks of a group that straddles N (N % 4 != 0): stage-invariant
+  uint32_t dm0[kKD], dm1[kKD];
+#pragma unroll
+  for (int i = 0; i < kKD; ++i) {
+    dm0[i] = dlive[i] >= 2 ? 0xffffffffu : dlive[i] == 1 ? 0xffffu : 0u;
+    dm1[i] = dlive[i] >= 4 ? 0xffffffffu : dlive[i] == 3 ? 0xffffu : 0u;
+  }
   auto commit = [&](int stg) {
     int img, oy, seg0;
     where(stg, img, oy, seg0);
 #pragma unroll
     for (int i = 0; i < kKX; ++i)
       *reinterpret_cast<u32x4*>(xs + xsdst[i]) = xv[i];
+    // MaxPoolGrad + ReluGrad on packed 16-bit lanes, no lane masks: window px hands its gradient to position argmax, if the
+    // maximum was > 0.  This output row holds positions `want` (left pixel of the pair) and `want + 1` (right pixel).
+    const uint32_t wantx = (uint32_t)(oy & 1) * 0x02020202u;
 #pragma unroll
     for (int i = 0; i < kKD; ++i) {
-        unsigned char* dst = reinterpret_cast<unsigned char*>(dzT) + ddst[i];
-        bf16x4 lo, hi;
-        if constexpr (POOLED) {
-          // MaxPoolGrad + ReluGrad: window px hands its gradient to position argmax, if the maximum was > 0
-          const uint32_t want = (uint32_t)(oy & 1) * 2u;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool live = (uint32_t)e < dlive[i] && (!p.pooled || (float)g1[i][e] > 0.f);
-            const __bf16 g = live ? g0[i][e] : (__bf16)0.f;
-            const uint32_t a = (argv[i] >> (8 * e)) & 0xffu;
-            lo[e] = a == want ? g : (__bf16)0.f;
-            hi[e] = a == want + 1u ? g : (__bf16)0.f;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool live = (uint32_t)e < dlive[i];
-            lo[e] = live ? g0[i][e] : (__bf16)0.f;
-            hi[e] = live ? g1[i][e] : (__bf16)0.f;
-          }
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 g = __builtin_bit_cast(u32x2, g0[i]);
+      u32x2 lo, hi;
+      if constexpr (POOLED) {
+        if (p.pooled) {
+          const u32x2 a = __builtin_bit_cast(u32x2, g1[i]);
+          g[0] &= positive(a[0]); g[1] &= positive(a[1]);
         }
-        *reinterpret_cast<bf16x4*>(dst) = lo;
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned char*>(dzT) + ddst2[i]) = hi;
+        g[0] &= dm0[i]; g[1] &= dm1[i];                            // (channels past N of the last group)
+        const uint32_t t = argv[i] ^ wantx;                        // byte e: 0 = this row's left pixel, 1 = its right pixel
+        const uint32_t t01 = __builtin_amdgcn_perm(0u, t, 0x0c010c00u), t23 = __builtin_amdgcn_perm(0u, t, 0x0c030c02u);   // bytes -> 16-bit lanes
+        lo[0] = g[0] & is_zero(t01); lo[1] = g[1] & is_zero(t23);
+        hi[0] = g[0] & is_zero(t01 ^ 0x00010001u); hi[1] = g[1] & is_zero(t23 ^ 0x00010001u);
+      } else {
+        u32x2 h = __builtin_bit_cast(u32x2, g1[i]);
+        g[0] &= dm0[i]; g[1] &= dm1[i]; h[0] &= dm0[i]; h[1] &= dm1[i];
+        lo = g; hi = h;
       }
+      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(dzT) + ddst[i]) = lo;
+      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(dzT) + ddst2[i]) = hi;
+    }
   };
 
   const int stages_total = p.rows_total * p.nseg;
@@ -246,22 +274,25 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
     //      first, then all writes: interleaved, every write had to precede the next read (both are LDS: they may alias as far
     //      as the compiler knows) and the build was nineteen serial LDS round trips.
     // (five slots at a time: reads batched, their lane masks not kept alive across all nineteen)
+    const int rbs = (base0 + shift) * 4;
 #pragma unroll
     for (int c = 0; c < kKA; c += 5) {
       float t0[5], t1[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const int px = px0 + 4 * (c + i);
-        const bool v = c + i < kKA && ok0 && px < p.seg;
-        t0[i] = xs[v ? base0 + px * stC + shift : 0];
-        t1[i] = xs[(v && ok1) ? base1 + px * stC + shift : 0];
+        if (c + i < kKA) {
+          const unsigned char* a = reinterpret_cast<const unsigned char*>(xs) + (pxc[c + i] * rstride + rbs);
+          t0[i] = *reinterpret_cast<const float*>(a);
+          t1[i] = *reinterpret_cast<const float*>(a + rdelta);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const int px = px0 + 4 * (c + i);
-        const bool v = c + i < kKA && ok0 && px < p.seg;
-        *reinterpret_cast<bf16x2*>(reinterpret_cast<unsigned char*>(At) + (v ? (px * LDA + 2 * mp) * 2 : scrapA)) =
-            bf16x2{(__bf16)t0[i], ok1 ? (__bf16)t1[i] : (__bf16)fill1};
+        if (c + i < kKA) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 v = {t0[i], ok1 ? t1[i] : fill1};
+          *reinterpret_cast<bf16x2*>(reinterpret_cast<unsigned char*>(At) + (pxc[c + i] * wstride + wbase)) = __builtin_convertvector(v, bf16x2);
+        }
       }
     }
     lds_barrier();
