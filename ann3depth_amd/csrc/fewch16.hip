@@ -34,6 +34,7 @@ struct Few16Params {
   int rows_per_img, rows_total, splits, mgroups;
   int rowlen, seg, nseg, PP, ksteps, hp, n4;
   int XP, xl4;             // floats per staged input row in LDS, 16-byte pieces fetched per row and segment
+  int LDD;                 // row stride of the [pixel][channel] tile
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   constexpr int LDA = 128 + 32;                              // row stride of the [pixel][tap] tile (cols + 32: the transposing read's rows 16 banks apart)
-  const int LDD = p.NP + 32;
+  const int LDD = p.LDD;                                     // (>= NP, 32 or 96 mod 128: see few16_ldd)
   __bf16* At = reinterpret_cast<__bf16*>(smem16);            // [PPk pixels][LDA]
   __bf16* dzT = At + p.PP * LDA;                             // [PPk pixels][LDD]
   float* xs = reinterpret_cast<float*>(dzT + p.PP * LDD);    // [kRows16][XP]: the input rows' segment, float32 as it lies in memory
@@ -100,19 +101,22 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
   __syncthreads();
   {
     const int mb = p.M - mg * 128;                           // the bias tap's position in this m-group, if it has it
-    if (mb >= 0 && mb < 128)
-      for (int i = tid; i < p.PP; i += kNT) At[i * LDA + mb] = (__bf16)1.f;
+    if (mb >= 0 && mb < 128)                                 // (tile column of tap t: 2 * (t % 64) + t / 64, see below)
+      for (int i = tid; i < p.PP; i += kNT) At[i * LDA + 2 * (mb & 63) + (mb >> 6)] = (__bf16)1.f;
   }
   // ---- per-thread constants of the staging: which pixel pairs of which taps, which channel groups of which windows
   // consecutive threads take consecutive tap PAIRS of one pixel (conflict-free reads of xs, conflict-free 4-byte writes of the
   // tile).  256 is a multiple of 64, so a thread keeps ONE tap pair for all its slots and walks the pixels in steps of four: no
   // per-slot tables (they were 95 registers and pushed the kernel into spilling).
-  const int mp = tid & 63, px0 = tid >> 6, m0 = mg * 128 + 2 * mp;
-  const bool ok0 = m0 < p.M, ok1 = m0 + 1 < p.M;
-  const int r0 = ok0 ? m0 / SC : 0, r1 = ok1 ? (m0 + 1) / SC : 0;
+  // A thread's pair is taps mp and mp + 64 of the group, stored side by side: tile column 2 * (t % 64) + t / 64 holds tap t (the
+  // slabs are written back in tap order).  With neighbouring taps 2mp, 2mp + 1 per thread a wave read every other float of a
+  // filter row — a 2-way bank conflict on each of the segment's 38 reads, half of the LDS pipe's busy cycles.
+  const int mp = tid & 63, px0 = tid >> 6, m0 = mg * 128 + mp, m1 = m0 + 64;
+  const bool ok0 = m0 < p.M, ok1 = m1 < p.M;
+  const int r0 = ok0 ? m0 / SC : 0, r1 = ok1 ? m1 / SC : 0;
   const int base0 = ok0 ? (r0 - rlo) * p.XP + (m0 - r0 * SC) : 0;                 // float index into xs of pixel 0 (plus the segment's shift)
-  const int base1 = ok1 ? (r1 - rlo) * p.XP + (m0 + 1 - r1 * SC) : base0;
-  const float fill1 = (ok0 && m0 + 1 == p.M) ? 1.f : 0.f;                         // the pair's second tap is the bias tap (ones) or padding
+  const int base1 = ok1 ? (r1 - rlo) * p.XP + (m1 - r1 * SC) : base0;
+  const float fill1 = (ok0 && m1 == p.M) ? 1.f : 0.f;                             // the pair's second tap is the bias tap (ones) or padding
   // The build below has NO per-slot validity test (nineteen lane masks were 38 scalar registers: the kernel spilled 90-170 of
   // them into vector lanes and read them back with one v_readlane each, 85 per segment, and every address went through a
   // select): a slot past the segment's last pixel is CLAMPED to that pixel and writes the same values to the same place as the
@@ -319,16 +323,27 @@ __global__ __launch_bounds__(kNT, 2) void fewch16_bwdf_kernel(const Few16Params 
     }
     if (u < u_hi) mul(0);
   }
-  float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * p.NP;
+  float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128) * p.NP;
 #pragma unroll
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) slab[(size_t)(8 * g + 4 * lh + i) * p.NP + t * 32 + li] = acc[t][4 * g + i];
+      for (int i = 0; i < 4; ++i) {
+        const int col = wv * 32 + 8 * g + 4 * lh + i, tap = (col >> 1) + 64 * (col & 1);      // tile column -> tap of the group
+        slab[(size_t)tap * p.NP + t * 32 + li] = acc[t][4 * g + i];
+      }
 }
 
 // ---- host side ----
+// Row stride (bf16 elements) of the [pixel][channel] tile: the transposing read takes four consecutive rows per 16 lanes, 64 bytes
+// of each — conflict-free when the rows start 16 banks apart, i.e. a stride of 64 or 192 bytes modulo 256 (NP + 32 = 128
+// elements put all four rows of conv2d_0's 96-channel tile on the same banks).
+static int few16_ldd(int NP) {
+  int ld = NP;
+  while (ld % 128 != 32 && ld % 128 != 96) ld += 32;
+  return ld;
+}
 struct Few16Shape {
   int M, Mp, mgroups, TN, NP, rows_per_img, rows_total, splits, seg, nseg, PP, ksteps, hp, n4, XP, xl4;
   size_t lds;
@@ -358,7 +373,7 @@ static Few16Shape few16_shape(const a3d_conv_desc* d, bool pooled) {
   const int need = 3 + (s.seg - 1) * d->stride * d->c + d->s * d->c;
   s.xl4 = std::min((need + 3) / 4, (d->w * d->c) / 4);
   s.XP = s.xl4 * 4 + 4;
-  s.lds = (size_t)s.PP * (160 + s.NP + 32) * 2 + (size_t)kRows16 * s.XP * 4 + kNT * 16;
+  s.lds = (size_t)s.PP * (160 + few16_ldd(s.NP)) * 2 + (size_t)kRows16 * s.XP * 4 + kNT * 16;
   s.ok = 64 * s.seg <= kKA * kNT && s.hp * s.n4 <= kKD * kNT && kRows16 * s.xl4 <= kKX * kNT && s.lds <= 78 * 1024 &&
          (d->w * d->c) % 4 == 0;
   return s;
@@ -398,7 +413,7 @@ int fewch16_bwd_filter(const a3d_conv_desc* d, const float* x, bool pooled, cons
   p.N = d->k; p.M = s.M; p.Mp = s.Mp; p.NP = s.NP; p.ldz = ldz; p.ld_arg = ld_arg;
   p.rows_per_img = s.rows_per_img; p.rows_total = s.rows_total; p.splits = s.splits; p.mgroups = s.mgroups;
   p.rowlen = d->w * d->c; p.seg = s.seg; p.nseg = s.nseg; p.PP = s.PP; p.ksteps = s.ksteps; p.hp = s.hp; p.n4 = s.n4;
-  p.XP = s.XP; p.xl4 = s.xl4;
+  p.XP = s.XP; p.xl4 = s.xl4; p.LDD = few16_ldd(s.NP);
   const bool vec = pooled && d->k % 4 == 0 && ld_arg % 4 == 0 && (reinterpret_cast<uintptr_t>(argmax) & 3) == 0;
   const int blocks = s.splits * s.mgroups;
   clear_stale_error();
