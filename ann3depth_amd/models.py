@@ -261,7 +261,7 @@ class MSDNReplica:
         self.dz1 = buf(B, OUT_H * OUT_W); self.dz0 = buf(B, 4096)
         self.dc4 = abuf(B, 6, 8, 256); self.dc3 = abuf(B, 13, 18, 384); self.dc2 = abuf(B, 13, 18, 384)
         self.dp1 = abuf(B, 13, 18, 256); self.dc1 = abuf(B, 27, 37, 256)
-        self.dp0 = abuf(B, 27, 37, 96); self.dc0 = abuf(B, 55, 74, 96)
+        self.dp0 = abuf(B, 27, 37, 96); self.dc0 = None            # dc0 (50 MB at B = 32): allocated only if the unfused path runs
         # fine/third's backward writes df2 in the type fine/second's backward reads it: bf16 under 'bf16s' (round 5)
         self.dfine = buf(B, OUT_H, OUT_W, 1); self.df2 = abuf(B, OUT_H, OUT_W, 64)
         self.dcat = abuf(B, OUT_H, OUT_W, 64); self.df1 = None      # df1 (131 MB at B = 32): allocated only if the unfused path runs
@@ -311,9 +311,9 @@ class MSDNReplica:
                           ('fine/first/conv2d', ops.conv_desc(B, NET_H, NET_W, 3, 63, 9, 9, 2, 'VALID', precision=few_prec))):
                 if ops.conv2d_bwd_filter_pooled_supported(dd):
                     self.d_few[n] = dd
-            if self.bf16s and os.environ.get('A3D_BF16S_FEWCH0', '0') != '1':
-                # config 5's conv2d_0 keeps igemm_bf16 + MaxPoolGrad (78 + 18 us at B = 64) — fewch16 takes 91 + 11 there, the
-                # fp32 form 191; fine/first is where the fused kernel pays (222 + 11 against 373 + 13 for the fp32 form)
+            if self.bf16s and os.environ.get('A3D_BF16S_FEWCH0', '1') == '0':
+                # A3D_BF16S_FEWCH0=0: config 5's conv2d_0 on igemm_bf16 + MaxPoolGrad by index (78 + 5 + 18 us at B = 64; the fused
+                # kernel: 68 + 11 since its staging lost its lane masks, 91 + 11 before)
                 self.d_few.pop('coarse/conv/conv2d_0', None)
         # bf16 storage: per layer, which tensors of the forward / bwd-data / bwd-filter call are bf16 (ops.STORE_*), and
         # the bf16 copies of the kernels (refreshed whenever the fp32 masters change)
@@ -932,6 +932,8 @@ class MSDNReplica:
             ops.conv2d_bwd_filter_pooled(self.d_few[n], self.x, self.dp0, self.p0, self.a0, self._g(n + '/kernel'),
                                          self._g(n + '/bias'))
             return
+        if self.dc0 is None:
+            self.dc0 = torch.empty((self.B, 55, 74, 96), device=self.device, dtype=self.dp0.dtype)
         if self.pooled_fwd == 1 or self.pool0_fused:
             ops.maxpool2x2_bwd_idx(self.a0, self.p0, self.dp0, self.dc0, relu_mask=True)
         else:

@@ -23,7 +23,10 @@ def t(fn, n=20):
     return 1e3 * e0.elapsed_time(e1) / n
 
 
+ONLY = sys.argv[1:]            # e.g. 'B=32': only the cases whose name contains one of these
 for name, (n, h, w, c, k, ks, st, ld) in CASES.items():
+    if ONLY and not any(o in name for o in ONLY):
+        continue
     d = ops.conv_desc(n, h, w, c, k, ks, ks, st, 'VALID')
     x = torch.randn((n, h, w, c), device='cuda')
     dz = torch.randn((n, d.ho, d.wo, k), device='cuda')
