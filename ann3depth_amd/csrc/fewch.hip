@@ -45,6 +45,9 @@ constexpr int kPX = 6;               // 16-byte pieces of input rows per thread 
 constexpr int kPDPlain = 10;         // ... of the dz row (148 pixels x 16 pieces)
 constexpr int kPDPooled = 5;         // 4-channel groups of the pooled row (74 windows x 16 groups), three registers each
 
+#ifdef A3D_STAMPS
+__device__ unsigned long long g_fewch_stamps[1024 * 4 * 8];       // diagnostic build (never shipped): [block][wave][8] phase cycle sums
+#endif
 template <int TN, int SRC, bool VEC>
 __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p) {
   constexpr int kPD = SRC == FEW_SRC_DZ ? kPDPlain : kPDPooled;
@@ -52,7 +55,16 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   float* xs = smem;                                   // [kFewRows][xpitch]
   float* dzs = xs + kFewRows * p.xpitch;              // [wo_pad][NP]
   float* consts = dzs + p.wo_pad * p.NP;              // 1.0, 0.0
+  // every LDS write of the staging is unconditional: a piece a thread does not have goes to its own 16 bytes of this scrap area
+  // (a pooled source's second piece: NP floats further on, still inside it).  A guarded write is a basic block of its own and
+  // its lane mask a pair of scalar registers for the whole loop: the kernel spilled 50-180 of them into vector lanes and read
+  // them back one v_readlane at a time.
+  const int scrap = (int)(consts - xs) + 4 + threadIdx.x * 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+#ifdef A3D_STAMPS
+  unsigned long long t_entry = 0;
+  A3D_STAMP(t_entry);
+#endif
   // XCD-aware order: the blocks an XCD receives (ids congruent mod 8) are consecutive tasks, so the m-groups of one pixel range —
   // which stage the same input rows and the same row of dz — share an L2 (the counters had 199 MB of fabric reads per launch
   // for conv2d_0 against ~80 MB algorithmic with the m-groups dealt round-robin over the XCDs)
@@ -109,19 +121,18 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
 #pragma unroll
   for (int i = 0; i < kPX; ++i) {
     const int e = tid + i * 256, rr = e / r4, q = e - rr * r4;
-    xdst[i] = e < xtotal ? rr * p.xpitch + 4 * q : -1;
+    xdst[i] = e < xtotal ? rr * p.xpitch + 4 * q : scrap;
     xoff[i] = e < xtotal ? (uint32_t)((rr * p.rowlen + 4 * q) * 4) : kOOB;
   }
-  int ddst[kPD];                                       // LDS float index of the piece (pooled: of its even pixel), -1: none
-  uint32_t doff[kPD], aoff[kPD], dlive[kPD];           // byte offsets into dz (or dpool / pooled) and argmax; channels of the piece below N
+  int ddst[kPD];                                       // LDS float index of the piece (pooled: of its even pixel; the odd one NP floats on)
+  uint32_t doff[kPD], aoff[kPD];                       // byte offsets into dz (or dpool / pooled) and argmax (none: 2^31, outside every buffer)
 #pragma unroll
   for (int i = 0; i < kPD; ++i) {
     const int e = tid + i * 256, px = e / n4, q = 4 * (e - px * n4);
     const bool ok = e < dtotal;
-    ddst[i] = ok ? (SRC == FEW_SRC_DZ ? px : 2 * px) * p.NP + q : -1;
+    ddst[i] = ok ? (SRC == FEW_SRC_DZ ? px : 2 * px) * p.NP + q : scrap - kFewRows * p.xpitch;      // (float index from dzs)
     doff[i] = ok ? (uint32_t)((px * p.ldz + q) * ESZ) : kOOB;
     aoff[i] = ok ? (uint32_t)(px * p.ld_arg + q) : kOOB;
-    dlive[i] = (uint32_t)max(0, min(4, p.N - q));
   }
   f32x4 xv[kPX], dv[kPD], av[kPD];
   uint32_t argv[kPD];
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
           } else {                                     // pixel strides / filter counts off the 16-byte grid: element by element
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              dv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (uint32_t)e < dlive[i] ? (int)(dbase + doff[i] + 4 * e) : (int)kOOB, 0, 0));
+              dv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)(dbase + doff[i] + 4 * e), 0, 0));      // (past N: the next pixel's, into a column nobody reads)
           }
         }
     } else {
@@ -167,35 +178,49 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
             uint32_t w = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              w |= (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(ra, (uint32_t)e < dlive[i] ? (int)(abase + aoff[i] + e) : (int)kOOB, 0, 0) << (8 * e);
+              w |= (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(ra, (int)(abase + aoff[i] + e), 0, 0) << (8 * e);
             argv[i] = w;
           }
         }
     }
   };
+#ifdef A3D_STAMPS
+  unsigned long long s_mid = 0, d_xw = 0, s_ld = 0, d_ld = 0;
+#endif
   auto commit = [&](int row) {
 #pragma unroll
     for (int i = 0; i < kPX; ++i)
-      if (i * 256 < xtotal && xdst[i] >= 0) *reinterpret_cast<f32x4*>(xs + xdst[i]) = xv[i];
+      if (i * 256 < xtotal) *reinterpret_cast<f32x4*>(xs + xdst[i]) = xv[i];
+#ifdef A3D_STAMPS
+    A3D_STAMP(s_mid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    A3D_STAMP(s_ld);
+#endif
     if constexpr (SRC == FEW_SRC_DZ) {
 #pragma unroll
       for (int i = 0; i < kPD; ++i)
-        if (i * 256 < dtotal && ddst[i] >= 0) *reinterpret_cast<f32x4*>(dzs + ddst[i]) = dv[i];
+        if (i * 256 < dtotal) *reinterpret_cast<f32x4*>(dzs + ddst[i]) = dv[i];
     } else {
       // MaxPoolGrad + ReluGrad: window (oy/2, px) hands its gradient to position argmax, if the maximum was > 0
       const int oy = row % p.rows_per_img;
       const uint32_t want = (uint32_t)(oy & 1) * 2u;
 #pragma unroll
       for (int i = 0; i < kPD; ++i)
-        if (i * 256 < dtotal && ddst[i] >= 0) {
+        if (i * 256 < dtotal) {
+          // (no test against N: a channel past N of the last group lands in a column >= N of the tile, whose sums the
+          // reduction never reads; where the group is loaded element by element such a channel is the next pixel's)
+          // on bit masks instead of compare / select pairs (each of those is a VCC round trip with its wait states): byte e of
+          // argmax == want <=> byte e of t is zero, flagged exactly in bit 7 of the byte by the carry trick
+          const uint32_t t = argv[i] ^ (want * 0x01010101u), t1 = t ^ 0x01010101u;
+          const uint32_t zl = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+          const uint32_t zh = ~(((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1 | 0x7f7f7f7fu);
           f32x4 lo, hi;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const bool live = (uint32_t)e < dlive[i] && (!p.pooled || av[i][e] > 0.f);
-            const float g = live ? dv[i][e] : 0.f;
-            const uint32_t a = (argv[i] >> (8 * e)) & 0xffu;
-            lo[e] = a == want ? g : 0.f;
-            hi[e] = a == want + 1u ? g : 0.f;
+            const uint32_t pos = (!p.pooled || av[i][e] > 0.f) ? 0xffffffffu : 0u;
+            const uint32_t g = __float_as_uint(dv[i][e]) & pos;
+            lo[e] = __uint_as_float(g & (uint32_t)__builtin_amdgcn_sbfe((int)zl, 8 * e + 7, 1));
+            hi[e] = __uint_as_float(g & (uint32_t)__builtin_amdgcn_sbfe((int)zh, 8 * e + 7, 1));
           }
           *reinterpret_cast<f32x4*>(dzs + ddst[i]) = lo;
           *reinterpret_cast<f32x4*>(dzs + ddst[i] + p.NP) = hi;
@@ -204,11 +229,18 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   };
 
   const int row_lo = (int)((long)split * p.rows_total / p.splits), row_hi = (int)((long)(split + 1) * p.rows_total / p.splits);
+#ifdef A3D_STAMPS
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, d_bar1 = 0, d_commit = 0, d_bar2 = 0, d_mfma = 0;
+#endif
   if (row_lo < row_hi) fetch(row_lo);
   for (int row = row_lo; row < row_hi; ++row) {
+    A3D_STAMP(s0);
     __syncthreads();                                  // the previous row's MFMAs have read their operands
+    A3D_STAMP(s1);
     commit(row);
+    A3D_STAMP(s2);
     __syncthreads();
+    A3D_STAMP(s3);
     // ---- 2 pixels per MFMA: A = x at the lane's tap for pixel 2kp + lh, B = dz[2kp + lh][column li]; groups of four
     //      pixel pairs, the next group's operands read from LDS while this group's MFMAs run; the NEXT row's global loads
     //      are issued behind the first group's MFMAs
@@ -259,7 +291,22 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
       ap += a_step;
       bp += 2 * p.NP;
     }
+#ifdef A3D_STAMPS
+    A3D_STAMP(s4);
+    d_ld += s_ld - s_mid; d_xw += s_mid - s1; d_bar1 += s1 - s0; d_commit += s2 - s1; d_bar2 += s3 - s2; d_mfma += s4 - s3;
+#endif
   }
+#ifdef A3D_STAMPS
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long t_end;
+    A3D_STAMP(t_end);
+    unsigned long long* o = g_fewch_stamps + ((size_t)blockIdx.x * 4 + wv) * 8;
+    o[0] = d_bar1; o[1] = d_commit; o[2] = d_bar2; o[3] = d_mfma; o[4] = (unsigned long long)(row_hi - row_lo); o[5] = d_xw; o[6] = t_end;
+    o[7] = d_ld;      // (slot 7: waiting for the gradient row's loads)
+  }
+  unsigned long long t_end2 = 0;
+  A3D_STAMP(t_end2);
+#endif
   // ---- the block's partial tile -> its slab (register 4g+i of a lane: row 8g + 4*lh + i, column li)
   float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * p.NP;
 #pragma unroll
@@ -268,6 +315,16 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int i = 0; i < 4; ++i) slab[(size_t)(8 * g + 4 * lh + i) * p.NP + t * 32 + li] = acc[t][4 * g + i];
+#ifdef A3D_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long t_exit = 0;
+  A3D_STAMP(t_exit);
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = g_fewch_stamps + ((size_t)blockIdx.x * 4 + wv) * 8;
+    o[5] = t_exit - t_end2;      // (slot 5 reused: the epilogue's slab stores)
+    o[6] = t_end2 - t_entry;     // (slot 6 reused: entry -> loop end)
+  }
+#endif
 }
 
 // dw[m][n] (m < M), db[n] (row M) = sum over splits, in split order
@@ -313,7 +370,7 @@ static FewchShape fewch_shape(const a3d_conv_desc* d, bool pooled) {
   s.xpitch = (std::max(d->w * d->c, reach) + 3) / 4 * 4;
   // two resident blocks per CU; a block needs a few rows to amortise its slab (Mp x NP floats)
   s.splits = std::max(1, std::min(s.rows_total / 4, tune_int("A3D_FEWCH_BLOCKS", 512) / s.mgroups));
-  s.lds = (size_t)(kFewRows * s.xpitch + s.wo_pad * s.NP + 4) * 4;
+  s.lds = (size_t)(kFewRows * s.xpitch + s.wo_pad * s.NP + 4 + 256 * 4 + s.NP + 4) * 4;      // rows of x, row of dz, two constants, scrap
   return s;
 }
 
@@ -375,6 +432,13 @@ int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void
   if (rc != A3D_OK) return rc;
   return fewch_reduce_launch(p.slabs, s.splits, s.Mp, s.NP, s.M, d->k, dw, db, st);
 }
+
+#ifdef A3D_STAMPS
+extern "C" int a3d_debug_fewch_stamps(unsigned long long* out, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fewch_stamps), std::min(bytes, sizeof(g_fewch_stamps)));
+}
+#endif
 
 int fewch_reduce_launch(const float* slabs, int splits, int Mp, int NP, int M, int N, float* dw, float* db, hipStream_t st) {
   const int outs = (M + 1) * N;

@@ -51,8 +51,8 @@ A3D_TUNING=1 A3D_FEWCH=0 python3 tools/bench_fewch.py 2> /dev/null | grep -v amd
 echo "fewch + fine/third done"
 # bf16 storage (config 5) per layer: the LDS-DMA kernel, and igemm_bf16 alone beside it
 python3 tools/bench_layers_bf16.py 2> $out/layers_bf16.err | grep -v amdgpu > $out/l16_ring.txt
-A3D_RING=0 python3 tools/bench_layers_bf16.py 2> /dev/null | grep -v amdgpu > $out/l16_old.txt
-paste -d'|' $out/l16_ring.txt $out/l16_old.txt | awk -F'|' '{printf "%-52s | igemm_bf16 only (A3D_RING=0): %s\n", $1, substr($2, 18)}' > $P/${tag}_bench_layers_bf16.txt
+A3D_TUNING=1 A3D_RING=0 python3 tools/bench_layers_bf16.py 2> /dev/null | grep -v amdgpu > $out/l16_old.txt
+paste -d'|' $out/l16_ring.txt $out/l16_old.txt | awk -F'|' '{printf "%-52s | igemm_bf16 only (A3D_TUNING=1 A3D_RING=0): %s\n", $1, substr($2, 18)}' > $P/${tag}_bench_layers_bf16.txt
 echo "bf16 layers done"
 rm -rf $out/kt $out/pmc_fetch $out/pmc_write $out/pmc_mfma
 bash tools/profile_fine.sh $tag
