@@ -793,11 +793,14 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   }
   __syncthreads();
 
-  int cur = 0;
 #ifdef A3D_STAMPS
   A3D_STAMP(tbeg);
 #endif
-  for (int it = 0; it < nkt; ++it) {
+  // one K tile; `cur` (which half of the double-buffered LDS tiles it reads) is a compile-time constant: the loop below is
+  // unrolled by two, so every fragment read is `lane constant + immediate` instead of an address rebuilt per tile (20 of the
+  // 31 vector instructions a wave issued per tile — and beside fp32 MFMAs none of them is hidden: DESIGN.md 3.1)
+  auto tile_body = [&](const int it, auto cur_c) {
+    constexpr int cur = decltype(cur_c)::value;
     const int kt = kt_begin + it;
     const bool more = it + 1 < nkt;
     A3D_STAMP(s0);
@@ -924,7 +927,10 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
 #ifdef A3D_STAMPS
     d01 += s1 - s0; d12 += s2 - s1; d23 += s3 - s2; d34 += s4 - s3; d45 += s5 - s4;
 #endif
-    cur ^= 1;
+  };
+  for (int it = 0; it < nkt; it += 2) {
+    tile_body(it, std::integral_constant<int, 0>{});
+    if (it + 1 < nkt) tile_body(it + 1, std::integral_constant<int, 1>{});
   }
   };
   if constexpr (MODE == MODE_BWD_F) {        // the tap belongs to the lane there: one loop body
