@@ -160,31 +160,56 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
   const int nchunks = p.Kp / 8;
   f32x4 af[DEPTH][TM], bf[DEPTH][TN];
   int nv[DEPTH];                                      // how many of a chunk's four k lie inside the run (>= 4: all)
-  auto fetch = [&](int u, int buf) {
-    const int k = 8 * u + 4 * lh;                     // this half's four k: one filter row (RLP % 4 == 0)
-    const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
-    const uint32_t koff = k < p.Kreal ? (r * (uint32_t)p.rowpitch + q) * 4u : kOOB;      // K tail: nothing to read
-    nv[buf] = p.RL - (int)q;                          // q <= RLP - 4 < RL: element 0 is always inside
+  // Beside fp32 MFMAs no vector instruction of the same wave is hidden (5-6 cycles each against the MFMA's 64), so
+  // a chunk's addresses are kept off the vector unit: chunks are fetched in order and everything that depends only on the chunk
+  // and on the lane's k half lives in SCALAR registers for both halves — position in the filter row (one compare-and-wrap per
+  // chunk instead of a division), byte offset, how many of its four k are inside the run — and a lane picks its half's with one
+  // select each.  "Outside" is 2^31 in either summand of an offset and the two are added with unsigned saturation (out of range
+  // either way, no select); a chunk past the end is fetched like any other — its A at 2^31: zeros — so the ring needs no branch
+  // and no registers to clear; the filter's offset is a scalar (the load's soffset), clamped to the last chunk.
+  int s_q = 0, s_k = 0;                               // scalar: element q of the run and k of the NEXT chunk's first half
+  uint32_t s_row = 0;                                 // ... byte offset of its filter row
+  const uint32_t rowstep = (uint32_t)p.rowpitch * 4u;
+  const uint32_t b_lane = (uint32_t)(lh * p.Np) * 16u + b_base;
+  const int bstep = 2 * p.Np * 16, b_last = (nchunks - 1) * bstep;
+  int s_b = 0;
+  bool s_tail[DEPTH];                                 // scalar: the chunk has pad positions to clear (either half)
+  auto fetch = [&](int buf) {                         // the next chunk in order
+    int q1 = s_q + 4;                                 // the second half's four k: the next 4-group of the run, or the next row's first
+    uint32_t row1 = s_row;
+    if (q1 >= p.RLP) { q1 -= p.RLP; row1 += rowstep; }
+    const uint32_t koff0 = s_k < p.Kreal ? s_row + (uint32_t)s_q * 4u : kOOB;       // K tail and chunks past the end: nothing to read
+    const uint32_t koff1 = s_k + 4 < p.Kreal ? row1 + (uint32_t)q1 * 4u : kOOB;
+    const int nv0 = p.RL - s_q, nv1 = p.RL - q1;      // q <= RLP - 4 < RL: element 0 is always inside
+    s_tail[buf] = nv0 < 4 || nv1 < 4;
+    const uint32_t koff = lh ? koff1 : koff0;
+    nv[buf] = lh ? nv1 : nv0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      const uint32_t off = (a_base[a] | koff) & kOOB ? kOOB : a_base[a] + koff;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)__builtin_elementwise_add_sat(a_base[a], koff), 0, 0);
       af[buf][a] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
     }
-    const uint32_t boff = (uint32_t)((2 * u + lh) * p.Np) * 16u + b_base;
+    const int sb = s_b < b_last ? s_b : b_last;       // (past the end: the last chunk's weights again, against zeros)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(boff + (uint32_t)b * 512u), 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(b_lane + (uint32_t)b * 512u), sb, 0);
       bf[buf][b] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
     }
+    s_k += 8;
+    s_b += bstep;
+    s_q += 8;                                         // RLP % 4 == 0: one wrap at most unless the run is a single 4-group
+    if (s_q >= p.RLP) { s_q -= p.RLP; s_row += rowstep; }
+    if (s_q >= p.RLP) { s_q -= p.RLP; s_row += rowstep; }
   };
   auto multiply = [&](int buf) {
     // pad positions of the run (only the last 4-group of a filter row has any) hold neighbouring pixels: zero them here,
     // at the point of use — the selects sit where the wait for this chunk's loads is anyway, not behind the fetch
+    if (s_tail[buf]) {                                // (scalar: only the chunk that holds a filter row's last 4-group)
 #pragma unroll
-    for (int j = 1; j < 4; ++j)
+      for (int j = 1; j < 4; ++j)
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[buf][a][j] = nv[buf] > j ? af[buf][a][j] : 0.f;
+        for (int a = 0; a < TM; ++a) af[buf][a][j] = nv[buf] > j ? af[buf][a][j] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -194,32 +219,24 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][a][j], bf[buf][b][j], acc[a][b], 0, 0, 0);
   };
   if constexpr (DEPTH == 2) {
-    fetch(0, 0);
+    fetch(0);
     int u = 0;
     for (; u + 2 <= nchunks; u += 2) {                  // two chunks per trip: the register double buffer is static
-      fetch(u + 1, 1);
+      fetch(1);
       multiply(0);
-      if (u + 2 < nchunks) fetch(u + 2, 0);
+      fetch(0);                                         // (past the end: zeros, never multiplied)
       multiply(1);
     }
     if (u < nchunks) multiply(0);
   } else {
     // ring of DEPTH register sets, DEPTH chunks per trip (static indices); a chunk past the end is fetched with every
     // offset out of range (zeros: multiplying them adds nothing), so the trip needs no tail logic
-    auto fetch_or_zero = [&](int u, int buf) {
-      if (u < nchunks) { fetch(u, buf); return; }
-      nv[buf] = 4;
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[buf][a] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int b = 0; b < TN; ++b) bf[buf][b] = {0.f, 0.f, 0.f, 0.f};
-    };
-#pragma unroll
-    for (int i = 0; i < DEPTH - 1; ++i) fetch_or_zero(i, i);
+    for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
     for (int u = 0; u < nchunks; u += DEPTH) {
 #pragma unroll
       for (int i = 0; i < DEPTH; ++i) {
-        fetch_or_zero(u + i + DEPTH - 1, (i + DEPTH - 1) % DEPTH);
+        fetch((i + DEPTH - 1) % DEPTH);
         multiply(i);
       }
     }
