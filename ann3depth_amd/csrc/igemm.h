@@ -222,11 +222,22 @@ struct IgemmCfg {
   // A: FWD/BWD_D [BM][BK+4] (K contiguous, b128 fragment reads); BWD_F [BK][BM+4] (M contiguous, b32 reads)
   static constexpr int A_ROWS = (MODE == MODE_BWD_F) ? BK : BM;
   static constexpr int A_COLS = (MODE == MODE_BWD_F) ? BM : BK;
-  static constexpr int A_LD = A_COLS + 4;
+  // Tiles read k-major (b32 fragment reads: row (k) * LD + column) whose rows are a multiple of 64 floats carry NO pad: rows are
+  // then a multiple of 256 bytes apart, and every fragment read is `one lane-constant address + immediate` (ds_read2st64_b32:
+  // offsets in units of 256 bytes) — with LD = COLS + 4 each ds_read2_b32 needed a v_add_u32 for its base (its offsets reach
+  // 1 KiB only), 23 per tile of 24 MFMAs in the bwd-filter kernel, and beside fp32 MFMAs none of them is hidden.
+  // The pad kept the two k halves of a wave (rows 4 apart) off each other's banks; without it the rows of the odd 4-groups
+  // store their columns XOR 32 (SWZ), which does the same.
+#ifndef A3D_NO_SWZ
+#define A3D_NO_SWZ 0
+#endif
+  static constexpr bool A_SWZ = !A3D_NO_SWZ && (MODE == MODE_BWD_F) && (A_COLS % 64 == 0);
+  static constexpr int A_LD = A_SWZ ? A_COLS : A_COLS + 4;
   // B: FWD/BWD_F [BK][BN+4] (N contiguous, b32 reads); BWD_D [BN][BK+4] (K contiguous, b128 reads)
   static constexpr int B_ROWS = (MODE == MODE_BWD_D) ? BN : BK;
   static constexpr int B_COLS = (MODE == MODE_BWD_D) ? BK : BN;
-  static constexpr int B_LD = B_COLS + 4;
+  static constexpr bool B_SWZ = !A3D_NO_SWZ && (MODE != MODE_BWD_D) && (B_COLS % 64 == 0);
+  static constexpr int B_LD = B_SWZ ? B_COLS : B_COLS + 4;
   static constexpr int A_ELEMS = A_ROWS * A_LD, B_ELEMS = B_ROWS * B_LD;
   static constexpr int PIX = A_ROWS;   // pixel-table entries (rows of the im2col tile)
   static constexpr size_t LDS_BYTES = (size_t)(2 * (A_ELEMS + B_ELEMS)) * 4 + (size_t)3 * PIX * 16;
@@ -315,12 +326,14 @@ struct Im2colTile {
       load_vec<VEC>(ok ? p.A + off : g_zero_line, regs[j]);
     }
   }
+  template <bool SWZ = false>
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
     const int r0 = tid / CPR, cq = tid % CPR;
     if (PARTIAL && r0 >= ROWS) return;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      float* dst = lds + (r0 + j * RPP) * ld + cq * VEC;
+      const int r = r0 + j * RPP;
+      float* dst = lds + r * ld + ((cq * VEC) ^ (SWZ ? 32 * ((r >> 2) & 1) : 0));
       store_vec<VEC>(dst, regs[j]);
     }
   }
@@ -345,13 +358,14 @@ struct PlainTile {
       load_vec<VEC>(ok ? src + off : g_zero_line, regs[j]);
     }
   }
+  template <bool SWZ = false>
   __device__ __forceinline__ static void store(const float (&regs)[NL][VEC], float* lds, int ld, int tid) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int idx = tid + j * NT;
       if (TOTAL % NT != 0 && idx >= TOTAL) continue;
       int r = idx / CPR, cq = idx % CPR;
-      float* dst = lds + r * ld + cq * VEC;
+      float* dst = lds + r * ld + ((cq * VEC) ^ (SWZ ? 32 * ((r >> 2) & 1) : 0));
       store_vec<VEC>(dst, regs[j]);
     }
   }
@@ -774,8 +788,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     for (int j = 0; j < BNL; ++j) load_vec_buf<BVEC>(rsB, MODE == MODE_BWD_D ? b_off[j] : b_voff[j], rb[j]);
   };
   auto store_tiles = [&](int buf) {
-    ATile::store(ra, As + buf * Cfg::A_ELEMS, Cfg::A_LD, tid);
-    BTile::store(rb, Bs + buf * Cfg::B_ELEMS, Cfg::B_LD, tid);
+    ATile::template store<Cfg::A_SWZ>(ra, As + buf * Cfg::A_ELEMS, Cfg::A_LD, tid);
+    if constexpr (MODE == MODE_BWD_D) BTile::store(rb, Bs + buf * Cfg::B_ELEMS, Cfg::B_LD, tid);
+    else BTile::template store<Cfg::B_SWZ>(rb, Bs + buf * Cfg::B_ELEMS, Cfg::B_LD, tid);
   };
 
 #ifdef A3D_STAMPS
@@ -820,7 +835,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
     const float* Bc = Bs + cur * Cfg::B_ELEMS;
     if (MODE == MODE_BWD_F && do_bias) {
 #pragma unroll 8
-      for (int k = 0; k < BK; ++k) bsum += Bc[k * Cfg::B_LD + tid];
+      for (int k = 0; k < BK; ++k) bsum += Bc[k * Cfg::B_LD + (tid ^ (Cfg::B_SWZ ? 32 * ((k >> 2) & 1) : 0))];
     }
     // PIPE (8-wave 128-wide backward kernels): fragments double-buffered in registers — chunk u+1 is read from LDS while
     // chunk u's MFMAs issue, in the requested interleave of one MFMA and its share of the next chunk's ds_reads
@@ -833,7 +848,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         const int kk = 8 * u + 4 * lh;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-          const int row = wm * Cfg::WM + a * 32 + li;
+          const int row = (wm * Cfg::WM + a * 32 + li) ^ (Cfg::A_SWZ ? 32 * lh : 0);      // (kk + j) >> 2 is odd exactly for lh = 1
           if (MODE == MODE_BWD_F) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) af[buf][a][j] = Ac[(kk + j) * Cfg::A_LD + row];
@@ -843,7 +858,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          const int col = wn * Cfg::WN + b * 32 + li;
+          const int col = (wn * Cfg::WN + b * 32 + li) ^ (Cfg::B_SWZ ? 32 * lh : 0);
           if (MODE == MODE_BWD_D) {
             bf[buf][b] = *reinterpret_cast<const f32x4*>(Bc + col * Cfg::B_LD + kk);
           } else {
@@ -887,7 +902,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       const int kk = 8 * u + 4 * lh;
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
-        const int row = wm * Cfg::WM + a * 32 + li;
+        const int row = (wm * Cfg::WM + a * 32 + li) ^ (Cfg::A_SWZ ? 32 * lh : 0);
         if (MODE == MODE_BWD_F) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) af[a][j] = Ac[(kk + j) * Cfg::A_LD + row];
@@ -897,7 +912,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
-        const int col = wn * Cfg::WN + b * 32 + li;
+        const int col = (wn * Cfg::WN + b * 32 + li) ^ (Cfg::B_SWZ ? 32 * lh : 0);
         if (MODE == MODE_BWD_D) {
           bf[b] = *reinterpret_cast<const f32x4*>(Bc + col * Cfg::B_LD + kk);
         } else {
