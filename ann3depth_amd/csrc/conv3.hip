@@ -223,8 +223,10 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
     int u = 0;
     for (; u + 2 <= nchunks; u += 2) {                  // two chunks per trip: the register double buffer is static
       fetch(1);
+      __builtin_amdgcn_sched_barrier(0);
       multiply(0);
       fetch(0);                                         // (past the end: zeros, never multiplied)
+      __builtin_amdgcn_sched_barrier(0);
       multiply(1);
     }
     if (u < nchunks) multiply(0);
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(DEPTH > 2 ? 512 : 256, DEPTH > 2 ? 2 : (TM * TN > 4
 #pragma unroll
       for (int i = 0; i < DEPTH; ++i) {
         fetch((i + DEPTH - 1) % DEPTH);
+        __builtin_amdgcn_sched_barrier(0);            // (the loads stay here, DEPTH - 1 chunks ahead of their use)
         multiply(i);
       }
     }
@@ -269,7 +272,10 @@ __global__ __launch_bounds__(256) void conv3b_pack_kernel(const float* __restric
 }
 
 template <int TM, int TN, bool POOL>
-__global__ __launch_bounds__(256, TM * TN > 4 ? 2 : 3) void conv3b_fwd_kernel(const Conv3Params p) {
+// (the six-tile form at most two wavefronts per SIMD: with its addressing in scalar registers it would fit three, and ran 12 % slower
+// that way — three k-steps of loads in flight per wave are what covers the latency here, not more waves on the same L1)
+__global__ __launch_bounds__(256, TM * TN > 4 ? 2 : 3) __attribute__((amdgpu_waves_per_eu(TM * TN > 4 ? 2 : 3, TM * TN > 4 ? 2 : 3)))
+void conv3b_fwd_kernel(const Conv3Params p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
   uint32_t bid = blockIdx.x;
@@ -309,19 +315,34 @@ __global__ __launch_bounds__(256, TM * TN > 4 ? 2 : 3) void conv3b_fwd_kernel(co
   const int nsteps = p.Kp / 16;
   constexpr int DEPTH = 3;                            // k-steps in registers: one being multiplied, two in flight
   bf16x8 af[DEPTH][TM], bf[DEPTH][TN];
-  auto fetch = [&](int u, int buf) {
-    const int k = 16 * u + 8 * lh;                    // this half's eight k: inside one filter row (RLP % 8 == 0)
-    const uint32_t r = fdiv((uint32_t)k, p.div_rlp), q = (uint32_t)k - r * (uint32_t)p.RLP;
-    const uint32_t koff = (u < nsteps && k < p.Kreal) ? (r * (uint32_t)p.rowpitch + q) * 2u : kOOB;
+  // chunk addressing in scalar registers for both k halves, as in conv3_fwd_kernel: k-steps are fetched in order, a lane picks
+  // its half's offset with one select; saturating adds keep "outside" (2^31) outside; the filter's offset is the load's scalar
+  // offset, clamped to the last k-step (past the end A reads zeros)
+  int s_q = 0, s_k = 0;
+  uint32_t s_row = 0;
+  const uint32_t rowstep = (uint32_t)p.rowpitch * 2u;
+  const uint32_t b_lane = (uint32_t)(lh * p.Np) * 16u + b_base;
+  const int bstep = 2 * p.Np * 16, b_last = (nsteps - 1) * bstep;
+  int s_b = 0;
+  auto fetch = [&](int buf) {                         // the next k-step in order
+    int q1 = s_q + 8;                                 // the second half's eight k: the next 8-group of the run, or the next row's first
+    uint32_t row1 = s_row;
+    if (q1 >= p.RLP) { q1 -= p.RLP; row1 += rowstep; }
+    const uint32_t koff0 = s_k < p.Kreal ? s_row + (uint32_t)s_q * 2u : kOOB;
+    const uint32_t koff1 = s_k + 8 < p.Kreal ? row1 + (uint32_t)q1 * 2u : kOOB;
+    const uint32_t koff = lh ? koff1 : koff0;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const uint32_t off = (a_base[a] | koff) & kOOB ? kOOB : a_base[a] + koff;
-      af[buf][a] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
-    }
-    const uint32_t boff = u < nsteps ? (uint32_t)((2 * u + lh) * p.Np) * 16u + b_base : kOOB;
+    for (int a = 0; a < TM; ++a)
+      af[buf][a] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)__builtin_elementwise_add_sat(a_base[a], koff), 0, 0));
+    const int sb = s_b < b_last ? s_b : b_last;
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-      bf[buf][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(boff == kOOB ? kOOB : boff + (uint32_t)b * 512u), 0, 0));
+      bf[buf][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(b_lane + (uint32_t)b * 512u), sb, 0));
+    s_k += 16;
+    s_b += bstep;
+    s_q += 16;                                        // RLP % 8 == 0: two wraps at most (a run of one 8-group)
+    if (s_q >= p.RLP) { s_q -= p.RLP; s_row += rowstep; }
+    if (s_q >= p.RLP) { s_q -= p.RLP; s_row += rowstep; }
   };
   auto multiply = [&](int buf) {
 #pragma unroll
@@ -331,11 +352,14 @@ __global__ __launch_bounds__(256, TM * TN > 4 ? 2 : 3) void conv3b_fwd_kernel(co
   };
   // a ring of DEPTH register sets, DEPTH k-steps per trip (static indices); a k-step past the end fetches zeros
 #pragma unroll
-  for (int i = 0; i < DEPTH - 1; ++i) fetch(i, i);
+  for (int i = 0; i < DEPTH - 1; ++i) fetch(i);
   for (int u = 0; u < nsteps; u += DEPTH) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
-      fetch(u + i + DEPTH - 1, (i + DEPTH - 1) % DEPTH);
+      fetch((i + DEPTH - 1) % DEPTH);
+      // the loads stay HERE, two k-steps ahead of their use: with nothing on the vector unit tying them down the scheduler
+      // moved all three steps' loads behind the trip's first MFMAs and opened the trip with s_waitcnt vmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
       multiply(i);
     }
   }
