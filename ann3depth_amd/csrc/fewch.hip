@@ -48,18 +48,22 @@ constexpr int kPDPooled = 5;         // 4-channel groups of the pooled row (74 w
 #ifdef A3D_STAMPS
 __device__ unsigned long long g_fewch_stamps[1024 * 4 * 8];       // diagnostic build (never shipped): [block][wave][8] phase cycle sums
 #endif
-template <int TN, int SRC, bool VEC>
+// STEP: stride * C of the layer as a compile-time constant (12 / 6 / 3 for conv2d_0 / fine/first / DCNF's first conv), 0 = read
+// it from the descriptor.  With it — and with the tile's row length NP = 32 * TN — every operand read of the MFMA loop is
+// `lane constant + immediate`: beside fp32 MFMAs a v_add per read is paid in full, and there were 16 per 12 MFMAs.
+template <int TN, int SRC, bool VEC, int STEP = 0>
 __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p) {
   constexpr int kPD = SRC == FEW_SRC_DZ ? kPDPlain : kPDPooled;
+  constexpr int NP = 32 * TN;                         // == p.NP
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                                   // [kFewRows][xpitch]
   float* dzs = xs + kFewRows * p.xpitch;              // [wo_pad][NP]
-  float* consts = dzs + p.wo_pad * p.NP;              // 1.0, 0.0
+  float* consts = dzs + p.wo_pad * NP;                // [2][xpitch]: a row of 1.0 (the bias tap's "input row") and a row of 0.0 (taps past M)
   // every LDS write of the staging is unconditional: a piece a thread does not have goes to its own 16 bytes of this scrap area
   // (a pooled source's second piece: NP floats further on, still inside it).  A guarded write is a basic block of its own and
   // its lane mask a pair of scalar registers for the whole loop: the kernel spilled 50-180 of them into vector lanes and read
   // them back one v_readlane at a time.
-  const int scrap = (int)(consts - xs) + 4 + threadIdx.x * 4;
+  const int scrap = (int)(consts - xs) + 2 * p.xpitch + threadIdx.x * 4;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
 #ifdef A3D_STAMPS
   unsigned long long t_entry = 0;
@@ -80,20 +84,21 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   const int nr = rhi - rlo + 1;
   // ---- this lane's A element: row m of the tile, pixel parity lh
   const int m = mg * 128 + wv * 32 + li;
-  int a_off, a_step;
+  // (every lane walks its row with the same step: the bias tap and the taps past M walk rows of constants)
+  const int stC = STEP ? STEP : p.stride * p.c;
+  const int a_step = 2 * stC;
+  int a_off;
   if (m < p.M) {
     const int r = m / SC, j = m - r * SC;
-    a_off = (r - rlo) * p.xpitch + j + lh * p.stride * p.c;
-    a_step = 2 * p.stride * p.c;
+    a_off = (r - rlo) * p.xpitch + j + lh * stC;
   } else {
-    a_off = (int)(consts - xs) + (m == p.M ? 0 : 1);  // the bias row reads 1.0, the rest of the padding 0.0
-    a_step = 0;
+    a_off = (int)(consts - xs) + (m == p.M ? 0 : p.xpitch);  // the bias row reads 1.0, the rest of the padding 0.0
   }
   // zero what the staging never writes: the tails of the input rows (read against dz = 0 when wo is odd) and the columns
   // N..NP / the pad pixel of the dz row
   for (int i = tid; i < kFewRows * p.xpitch; i += 256) xs[i] = 0.f;
-  for (int i = tid; i < p.wo_pad * p.NP; i += 256) dzs[i] = 0.f;
-  if (tid == 0) { consts[0] = 1.f; consts[1] = 0.f; }
+  for (int i = tid; i < p.wo_pad * NP; i += 256) dzs[i] = 0.f;
+  for (int i = tid; i < p.xpitch; i += 256) { consts[i] = 1.f; consts[p.xpitch + i] = 0.f; }
   f32x16 acc[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b)
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   for (int i = 0; i < kPD; ++i) {
     const int e = tid + i * 256, px = e / n4, q = 4 * (e - px * n4);
     const bool ok = e < dtotal;
-    ddst[i] = ok ? (SRC == FEW_SRC_DZ ? px : 2 * px) * p.NP + q : scrap - kFewRows * p.xpitch;      // (float index from dzs)
+    ddst[i] = ok ? (SRC == FEW_SRC_DZ ? px : 2 * px) * NP + q : scrap - kFewRows * p.xpitch;      // (float index from dzs)
     doff[i] = ok ? (uint32_t)((px * p.ldz + q) * ESZ) : kOOB;
     aoff[i] = ok ? (uint32_t)(px * p.ld_arg + q) : kOOB;
   }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
             hi[e] = __uint_as_float(g & (uint32_t)__builtin_amdgcn_sbfe((int)zh, 8 * e + 7, 1));
           }
           *reinterpret_cast<f32x4*>(dzs + ddst[i]) = lo;
-          *reinterpret_cast<f32x4*>(dzs + ddst[i] + p.NP) = hi;
+          *reinterpret_cast<f32x4*>(dzs + ddst[i] + NP) = hi;
         }
     }
   };
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
     //      pixel pairs, the next group's operands read from LDS while this group's MFMAs run; the NEXT row's global loads
     //      are issued behind the first group's MFMAs
     const float* ap = xs + a_off;
-    const float* bp = dzs + lh * p.NP + li;
+    const float* bp = dzs + lh * NP + li;
     const int groups = p.kpairs >> 2;
     const bool more = row + 1 < row_hi;
     float a[2][4], b[2][4][TN];
@@ -254,10 +259,10 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
       for (int u = 0; u < 4; ++u) {
         a[buf][u] = ap[u * a_step];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) b[buf][u][t] = bp[u * 2 * p.NP + t * 32];
+        for (int t = 0; t < TN; ++t) b[buf][u][t] = bp[u * 2 * NP + t * 32];
       }
       ap += 4 * a_step;
-      bp += 8 * p.NP;
+      bp += 8 * NP;
     };
     auto mul = [&](int buf) {
 #pragma unroll
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bp[t * 32], acc[t], 0, 0, 0);
       ap += a_step;
-      bp += 2 * p.NP;
+      bp += 2 * NP;
     }
 #ifdef A3D_STAMPS
     A3D_STAMP(s4);
@@ -308,13 +313,13 @@ __global__ __launch_bounds__(256, 2) void fewch_bwdf_kernel(const FewchParams p)
   A3D_STAMP(t_end2);
 #endif
   // ---- the block's partial tile -> its slab (register 4g+i of a lane: row 8g + 4*lh + i, column li)
-  float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * p.NP;
+  float* slab = p.slabs + ((size_t)split * p.Mp + mg * 128 + wv * 32) * NP;
 #pragma unroll
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) slab[(size_t)(8 * g + 4 * lh + i) * p.NP + t * 32 + li] = acc[t][4 * g + i];
+      for (int i = 0; i < 4; ++i) slab[(size_t)(8 * g + 4 * lh + i) * NP + t * 32 + li] = acc[t][4 * g + i];
 #ifdef A3D_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned long long t_exit = 0;
@@ -370,7 +375,7 @@ static FewchShape fewch_shape(const a3d_conv_desc* d, bool pooled) {
   s.xpitch = (std::max(d->w * d->c, reach) + 3) / 4 * 4;
   // two resident blocks per CU; a block needs a few rows to amortise its slab (Mp x NP floats)
   s.splits = std::max(1, std::min(s.rows_total / 4, tune_int("A3D_FEWCH_BLOCKS", 512) / s.mgroups));
-  s.lds = (size_t)(kFewRows * s.xpitch + s.wo_pad * s.NP + 4 + 256 * 4 + s.NP + 4) * 4;      // rows of x, row of dz, two constants, scrap
+  s.lds = (size_t)((kFewRows + 2) * s.xpitch + s.wo_pad * s.NP + 256 * 4 + s.NP + 4) * 4;      // rows of x, row of dz, two constant rows, scrap
   return s;
 }
 
@@ -394,12 +399,21 @@ size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled) {
   return (size_t)s.splits * s.Mp * s.NP * 4 + 16;
 }
 
+template <int TN, int SRC, bool VEC, int STEP>
+static void fewch_launch4(const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
+  // above 64 KiB of dynamic LDS is possible: the attribute is per device and cheap, set on every call
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, SRC, VEC, STEP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            80 * 1024);
+  hipLaunchKernelGGL((fewch_bwdf_kernel<TN, SRC, VEC, STEP>), dim3(blocks), dim3(256), lds, st, p);
+}
 template <int TN, int SRC, bool VEC>
 static void fewch_launch3(const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
-  // above 64 KiB of dynamic LDS is possible: the attribute is per device and cheap, set on every call
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fewch_bwdf_kernel<TN, SRC, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            80 * 1024);
-  hipLaunchKernelGGL((fewch_bwdf_kernel<TN, SRC, VEC>), dim3(blocks), dim3(256), lds, st, p);
+  // the step of the three layers this kernel was built for (with their tile widths) as compile-time constants; anything else reads it
+  const int step = p.stride * p.c;
+  if (TN == 3 && step == 12) return fewch_launch4<TN, SRC, VEC, TN == 3 ? 12 : 0>(p, blocks, lds, st);      // conv2d_0
+  if (TN == 2 && step == 6) return fewch_launch4<TN, SRC, VEC, TN == 2 ? 6 : 0>(p, blocks, lds, st);        // fine/first
+  if (TN == 2 && step == 3) return fewch_launch4<TN, SRC, VEC, TN == 2 ? 3 : 0>(p, blocks, lds, st);        // DCNF's first conv
+  fewch_launch4<TN, SRC, VEC, 0>(p, blocks, lds, st);
 }
 template <int TN>
 static void fewch_launch(int src, const FewchParams& p, int blocks, size_t lds, hipStream_t st) {
