@@ -703,7 +703,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
           const int4 pt = ptab[a_r0 + j * A_RPP];
           const int y = pt.y + a_dy, x = pt.z + a_dx;
           const bool ok = a_cvalid & (pt.w != 0) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)pW);
-          a_off[j] = ok ? (uint32_t)(pt.x + a_coloff) : kOOB;
+          // (all four fields of the entry used unconditionally: ONE 16-byte LDS read — selecting `pt.x + a_coloff` made the
+          // compiler read x under an exec-mask branch of its own, a second LDS round trip per piece)
+          a_off[j] = (uint32_t)(pt.x + a_coloff) | (ok ? 0u : kOOB);
           if (FETCH) load_vec_buf<AVEC>(rsA, a_off[j], ra[j]);
         }
       }
