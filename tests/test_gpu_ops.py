@@ -58,6 +58,8 @@ CONV_CASES = [
     (3, 23, 29, 1, 40, 5, 1, 'VALID'),       # one channel: runs start 4 bytes apart, run of 5 -> 8 floats
     (2, 20, 27, 4, 70, 3, 2, 'VALID'),       # four channels, 70 filters (three column tiles, 26 of 96 columns idle)
     (65, 15, 15, 2, 33, 7, 4, 'VALID'),      # 65 images of 3 x 3 outputs: row tiles crossing images, M tail
+    (2, 12, 15, 1, 40, 3, 1, 'VALID'),       # a run of ONE 4-group (3 taps -> 4): the chunk's two halves lie in different filter rows
+    (3, 9, 14, 2, 36, 2, 1, 'VALID'),        # ... and a run that fills its 4-group exactly
     # bwd-filter window runs at any 4-byte address (stride 1 x 3 channels) must not be taken where SAME pads on the right /
     # below only (even kernel: pad_t = pad_l = 0): the last column's run would read the next row instead of zeros
     (3, 12, 27, 3, 16, 2, 1, 'SAME'),
