@@ -50,6 +50,8 @@ struct GemmProblem {
   int avec, bvec;    // 1 or 4
   int plain = 0;     // 1: register-staged kernel without split-K only (fused-pool forward)
   int no_glds = 0;   // 1: not the LDS-DMA kernels (bf16 output)
+  int gen2_ok = 0;   // 1: the launch may run on the second-generation LDS-DMA kernel (igemm2.h): float32 tensors, 16-byte
+                     //    operands, forward / bwd-data: gathered channels a multiple of 32 and K = taps x channels
   int ring_ok = 0;   // 1: both operands are bf16 tensors whose 16-byte pieces lie inside one filter tap (channels % 8 == 0):
                      //    forward / stride-1 bwd-data may run on igemm_ring.h
 };

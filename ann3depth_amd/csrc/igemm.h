@@ -510,6 +510,66 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, const f32x16 (&
       }
 }
 
+// What a block does with the accumulators of one share of one tile: a share that covers the tile's whole K range stores it
+// through the mode's epilogue (bias / activation / dropout, the fused 2x2 max pool, the activation gradient), a classic
+// split-K share stores raw sums into its slab, a stream-K share that ends inside the tile leaves the accumulators (and the
+// bias-gradient sums of `do_bias` threads) in the block's slab slot for igemm_fixup_kernel.  Shared by igemm_body and the
+// LDS-DMA kernel of igemm2.h (same accumulator layout: wave (wm, wn), accumulators [TM][TN] of 32x32).
+template <int MODE, int BM, int BN, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], const int split, const uint32_t bid,
+                                               const int seg, const int kt_begin, const int kt_end, const int nk_total,
+                                               const bool do_bias, const float bsum, const int tid, const int wave, const int lane,
+                                               const int m0, const int n0, const int wm, const int wn) {
+  const int li = lane & 31, lh = lane >> 5;
+  float* Cout = p.C;
+  int ldc = p.ldc;
+  const bool partial = !p.streamk && p.splitk > 1;
+  if (partial) {
+    Cout = p.C + (size_t)split * p.slab;
+    ldc = p.N;
+  }
+  if (p.streamk && (kt_begin != 0 || kt_end != nk_total)) {
+    // a share that ends inside the tile: accumulators (and the bias-gradient sums) go to this block's slab as they are
+    const size_t slot = (size_t)2 * bid + (seg > 0 ? 1 : 0);
+    slab_store<TM, TN>(p.sk_ws + slot * (size_t)(BM * BN), acc, wave, lane);
+    if (MODE == MODE_BWD_F && do_bias) p.sk_bias[slot * BN + tid] = bsum;
+  } else if (MODE == MODE_FWD && p.pool) {      // never split (host)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * WN + b * 32 + li;
+        if (col >= p.N) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = m0 + wm * WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
+          if (row >= p.M) continue;
+          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[a][b][4 * g + i] + bias;
+            if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
+            else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
+          }
+          float val = v[0];
+          int arg = 0;
+#pragma unroll
+          for (int i = 1; i < 4; ++i)
+            if (v[i] > val) { val = v[i]; arg = i; }
+          if (p.c16) reinterpret_cast<__bf16*>(Cout)[(size_t)(row >> 2) * ldc + col] = (__bf16)val;
+          else Cout[(size_t)(row >> 2) * ldc + col] = val;
+          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
+        }
+      }
+    }
+  } else {
+    if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
+    store_tile<MODE, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial);
+  }
+}
+
 // The whole GEMM of one block: `nwg` blocks work on problem `p`, this one is number `bid_in`.
 template <int MODE, int BM, int BN, int WAVES_M, int NWAVES, int BKT, int AVEC, int BVEC>
 __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t nwg, const uint32_t bid_in) {
@@ -974,53 +1034,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
 #endif
 
   // ---- epilogue ----
-  float* Cout = p.C;
-  int ldc = p.ldc;
-  const bool partial = !p.streamk && p.splitk > 1;
-  if (partial) {
-    Cout = p.C + (size_t)split * p.slab;
-    ldc = p.N;
-  }
-  if (p.streamk && (kt_begin != 0 || kt_end != nk_total)) {
-    // a share that ends inside the tile: accumulators (and the bias-gradient sums) go to this block's slab as they are
-    const size_t slot = (size_t)2 * bid + (seg > 0 ? 1 : 0);
-    slab_store<TM, TN>(p.sk_ws + slot * (size_t)(BM * BN), acc, wave, lane);
-    if (MODE == MODE_BWD_F && do_bias) p.sk_bias[slot * BN + tid] = bsum;
-  } else if (MODE == MODE_FWD && p.pool) {      // never split (host)
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn * Cfg::WN + b * 32 + li;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = m0 + wm * Cfg::WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
-          if (row >= p.M) continue;
-          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[a][b][4 * g + i] + bias;
-            if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
-            else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
-          }
-          float val = v[0];
-          int arg = 0;
-#pragma unroll
-          for (int i = 1; i < 4; ++i)
-            if (v[i] > val) { val = v[i]; arg = i; }
-          if (p.c16) reinterpret_cast<__bf16*>(Cout)[(size_t)(row >> 2) * ldc + col] = (__bf16)val;
-          else Cout[(size_t)(row >> 2) * ldc + col] = val;
-          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
-        }
-      }
-    }
-  } else {
-    if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
-    store_tile<MODE, TM, TN, Cfg::WM, Cfg::WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial);
-  }
+  igemm_epilogue<MODE, BM, BN, TM, TN, Cfg::WM, Cfg::WN>(p, acc, split, bid, seg, kt_begin, kt_end, nk_total, do_bias, bsum, tid, wave, lane,
+                                                          m0, n0, wm, wn);
   }   // shares of this block
   A3D_STAMP_EXIT();
 }

@@ -41,7 +41,13 @@ static const TileCfg kCfgs[] = {{128, 128, 1.00f, 32}, {128, 96, 1.00f, 32}, {12
                                 // +3-5 % over the register-staged twins; since those stage through buffer loads with
                                 // addresses computed a tile ahead (round 2) they are the faster ones (fine/second
                                 // forward 245 vs 259 us, conv2d_1 325 vs 339 us: profiles/r02_sweep_hot.txt)
-                                {128, 128, 1.10f, 32}, {128, 64, 1.00f, 32}};
+                                {128, 128, 1.10f, 32}, {128, 64, 1.00f, 32},
+                                // second-generation kernel (igemm2.h: LDS-DMA, 4 waves of 64x64, pinned schedule), all three
+                                // modes; takes a launch only when gen2_ok (GemmProblem) — else its register-staged twin, cfg 0.
+                                // Round 6: parity-green and measured on every MSDN layer — 2-5 % behind the 8-wave kernels on
+                                // forward / bwd-data, 15 % behind on bwd-filter (DESIGN.md 3.1i says why): eff 0 = pinned
+                                // plans only (A3D_FORCE_CFG=11 in a tuning process; tools/gen2_check.py, tools/sweep_hot.py)
+                                {128, 128, 0.f, 32}};
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kSlots = 512;               // 256 CUs x 2 resident blocks
 static const size_t kMaxSlabBytes = (size_t)192 << 20;
@@ -111,9 +117,15 @@ static void timing_end(TimingSlot& slot, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_timing_mu);
   g_timing.push_back(slot);
 }
-static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4};
-static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8};
+static const int kCfgWavesM[] = {2, 4, 4, 4, 2, 1, 1, 4, 4, 4, 4, 2};
+static const int kCfgNWaves[] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 4};
 static const int kFirstGldsCfg = 9;
+static const int kGen2Cfg = 11;
+// the forward-only LDS-DMA kernels of round 1 (igemm_glds.h)
+static inline bool is_glds_cfg(int c) { return c >= kFirstGldsCfg && c < kGen2Cfg; }
+// configurations that run stream-K shares (slabs + igemm_fixup_kernel)
+static inline bool streamk_cfg(int c) { return c < kFirstGldsCfg || c == kGen2Cfg; }
+static bool env_flag_no_gen2() { static const bool v = tune_int("A3D_NO_GEN2", 0) != 0; return v; }
 
 // bf16 / bf16x3 kernel: BM = 128.  Staging-bound rather than MFMA-bound: the wider tile wins whenever N allows it
 // (even at one block per CU for the two-plane x3 variant); split-K factors: x3 by round 1's sweep
@@ -219,8 +231,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision);
 GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   if (tuning()) return plan_gemm_search(g, precision);
   static std::mutex mu;
-  static std::map<std::array<int, 10>, GemmPlan> cache;
-  const std::array<int, 10> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision, g.ring_ok};
+  static std::map<std::array<int, 11>, GemmPlan> cache;
+  const std::array<int, 11> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision, g.ring_ok, g.gen2_ok};
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -260,7 +272,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     // a pinned configuration still has to be one this problem can run on: the LDS-DMA kernels are forward-only, take
     // 16-byte operands, and have neither the pooling epilogue nor a bf16 output — their register-staged twins do
     int cfg = force_cfg;
-    if (cfg >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) cfg -= 2;
+    if (is_glds_cfg(cfg) && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) cfg -= 2;
+    if (cfg == kGen2Cfg && !g.gen2_ok) cfg = 0;
     const int force_cfg = cfg;
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
@@ -272,7 +285,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     best.cfg = force_cfg; best.splitk = splitk; best.ktiles_per_split = kps;
     best.tiles_m = (g.M + bm - 1) / bm; best.tiles_n = (g.N + bn - 1) / bn;
     best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
-    if (force_streamk > 0 && force_cfg < kFirstGldsCfg && !g.plain) {
+    if (force_streamk > 0 && streamk_cfg(force_cfg) && !g.plain) {
       best.splitk = 1; best.ktiles_per_split = nk; best.streamk = force_streamk;
       best.ws_bytes = (size_t)2 * force_streamk * ((size_t)bm * bn + bn) * 4;
       best.sk_sliced = tune_int("A3D_FORCE_SK_SLICED", 0) &&
@@ -285,7 +298,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
   // Model picks are within 1.15x (mostly 1.05x) of the best measured configuration for every MSDN layer/direction.
   for (int c = 0; c < kNumCfgs; ++c) {
     if (kCfgs[c].eff <= 0.f) continue;
-    if (c >= kFirstGldsCfg && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) continue;
+    if (is_glds_cfg(c) && (g.mode != MODE_FWD || g.avec != 4 || g.bvec != 4 || g.plain || g.no_glds)) continue;
+    if (c == kGen2Cfg && (!g.gen2_ok || env_flag_no_gen2())) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn;
     const int tm = (g.M + bm - 1) / bm, tn = (g.N + bn - 1) / bn;
     const long tiles = (long)tm * tn;
@@ -306,7 +320,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
       const int splitk = (nk + kps - 1) / kps;
       const long blocks = tiles * splitk;
       double t_b = (double)bm * bn * kps * 32.0 / (96.5e3 * kCfgs[c].eff);                // us
-      if (c >= kFirstGldsCfg && kps < 40) t_b *= 1.08;     // LDS-DMA pays off on long K ranges only (conv2d_2: 158 vs 146 us)
+      if (is_glds_cfg(c) && kps < 40) t_b *= 1.08;     // LDS-DMA pays off on long K ranges only (conv2d_2: 158 vs 146 us)
       double f;      // kernel time in units of t_b: the slowest CU decides (tools/fit_planner.py)
       if (blocks <= 256) f = 0.62;
       else if (blocks <= kSlots) f = 1.0;
@@ -327,7 +341,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     }
     // stream-K: equal shares of the (tile, k-tile) iterations for one or two blocks per CU — no tile quantisation, and
     // at most two partial slabs per block (register-staged kernels only; the pooling forward never splits)
-    if (c < kFirstGldsCfg && !g.plain && !env_flag_no_streamk()) {
+    if (streamk_cfg(c) && !g.plain && !env_flag_no_streamk()) {
       const long iters = tiles * nk;
       for (int G = 256; G <= 512; G += 256) {
         if (force_streamk > 0 && G != 256) continue;
@@ -562,7 +576,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     } else {
       r.bm = kCfgs[plan.cfg].bm; r.bn = kCfgs[plan.cfg].bn; r.waves_m = kCfgWavesM[plan.cfg];
       r.nwaves = kCfgNWaves[plan.cfg]; r.bk = kCfgs[plan.cfg].bk;
-      r.lds_dma = plan.cfg >= kFirstGldsCfg && avec == 4 && bvec == 4;
+      r.lds_dma = plan.cfg == kGen2Cfg ? 5 : (plan.cfg >= kFirstGldsCfg && avec == 4 && bvec == 4);
     }
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;
@@ -723,13 +737,29 @@ struct ConvProblem {
   GemmProblem g;
 };
 
+// May this layer / direction run on the second-generation kernel (igemm2.h)?  By the descriptor alone: the callers clear the
+// flag again when an operand is not 16-byte aligned or the launch takes another form (window runs, dense streams).
+static bool gen2_desc_ok(const a3d_conv_desc* d, int mode) {
+  if (d->precision != A3D_PREC_F32 || d->storage) return false;
+  if (mode == MODE_FWD) return d->c % 32 == 0 && d->ldx % 4 == 0 && d->k % 4 == 0;
+  if (mode == MODE_BWD_D) return d->k % 32 == 0 && d->ldy % 4 == 0;
+  return d->c % 4 == 0 && d->ldx % 4 == 0 && d->k % 4 == 0 && d->ldy % 4 == 0;
+}
+
 static GemmProblem fwd_problem(const a3d_conv_desc* d) {
   GemmProblem g;
   g.mode = MODE_FWD;
   g.M = d->n * d->ho * d->wo; g.N = d->k; g.K = d->r * d->s * d->c;
   g.avec = (d->c % 4 == 0 && d->ldx % 4 == 0) ? 4 : 1;
   g.bvec = (d->k % 4 == 0) ? 4 : 1;
+  g.gen2_ok = gen2_desc_ok(d, MODE_FWD);
   return g;
+}
+// workspace of a problem whichever of the two kernel generations a launch ends up on
+static size_t plan_ws_either(GemmProblem g, int precision) {
+  size_t need = plan_gemm(g, precision).ws_bytes;
+  if (g.gen2_ok) { g.gen2_ok = 0; need = std::max(need, plan_gemm(g, precision).ws_bytes); }
+  return need;
 }
 static GemmProblem bwd_d_problem(const a3d_conv_desc* d) {
   GemmProblem g;
@@ -737,6 +767,7 @@ static GemmProblem bwd_d_problem(const a3d_conv_desc* d) {
   g.M = d->n * d->h * d->w; g.N = d->c; g.K = d->r * d->s * d->k;
   g.avec = (d->k % 4 == 0 && d->ldy % 4 == 0) ? 4 : 1;
   g.bvec = (d->k % 4 == 0) ? 4 : 1;
+  g.gen2_ok = gen2_desc_ok(d, MODE_BWD_D);
   return g;
 }
 static GemmProblem bwd_f_problem(const a3d_conv_desc* d) {
@@ -745,6 +776,7 @@ static GemmProblem bwd_f_problem(const a3d_conv_desc* d) {
   g.M = d->r * d->s * d->c; g.N = d->k; g.K = d->n * d->ho * d->wo;
   g.avec = (d->c % 4 == 0 && d->ldx % 4 == 0) ? 4 : 1;
   g.bvec = (d->k % 4 == 0 && d->ldy % 4 == 0) ? 4 : 1;
+  g.gen2_ok = gen2_desc_ok(d, MODE_BWD_F);
   return g;
 }
 
@@ -849,7 +881,7 @@ size_t a3d_conv2d_fwd_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return 0;
   // (a maximum over the paths a launch may take: which one it is also depends on the operands' alignment)
-  size_t need = plan_gemm(fwd_problem(d), d->precision).ws_bytes;
+  size_t need = plan_ws_either(fwd_problem(d), d->precision);
   {                                              // ... the LDS-DMA kernel's plan among them (its split-K slabs: dense layers)
     const int both = A3D_STORE_X_BF16 | A3D_STORE_W_BF16;
     GemmProblem g = fwd_problem(d);
@@ -1016,6 +1048,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   RunForm rf{};
   const bool prepared = (d->hints & A3D_HINT_W_PREPARED) != 0;
   const bool run = run_form_ok(d, x, &rf) && (prepared || (ws && ws_bytes >= run_filter_bytes(d, rf)));
+  if (run || g.avec != 4 || g.bvec != 4 || (out2 && out2->ptr)) g.gen2_ok = 0;
   A3D_CHECK_ARG(!prepared || (run && aligned16(w)), "conv2d_fwd: A3D_HINT_W_PREPARED on a launch that reads the filter as stored");
   size_t ws_used = 0;
   const float* filter = w;
@@ -1061,7 +1094,7 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   if (ws_used + plan.ws_bytes > ws_bytes)
     return set_error(A3D_EWORKSPACE, "conv2d_fwd: need %zu workspace bytes", ws_used + plan.ws_bytes);
   A3D_CHECK_ARG(!(p.a16 || p.b16) || plan.prec == A3D_PREC_BF16, "conv2d_fwd: bf16 operands need vectorisable tensors");
-  A3D_CHECK_ARG(!p.c16 || plan.prec == A3D_PREC_BF16 || plan.cfg < kFirstGldsCfg, "conv2d_fwd: no bf16 output from the LDS-DMA kernel");
+  A3D_CHECK_ARG(!p.c16 || plan.prec == A3D_PREC_BF16 || plan.cfg < kFirstGldsCfg, "conv2d_fwd: no bf16 output from the LDS-DMA kernels");
   p.A = x; p.B = filter; p.C = y; p.bias = bias; p.act = act;
   p.share = (d->hints & A3D_HINT_SHARE_CU) ? 1 : 0;
   p.npix = g.M; p.nrsc = g.K;
@@ -1170,7 +1203,7 @@ static bool bwd_d_class(const a3d_conv_desc* d, int ph, int pw, BwdDClass* c) {
 size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (d->stride == 1) {
-    size_t need = plan_gemm(bwd_d_problem(d), d->precision).ws_bytes;
+    size_t need = plan_ws_either(bwd_d_problem(d), d->precision);
     const int both = A3D_STORE_Y_BF16 | A3D_STORE_W_BF16;
     GemmProblem g = bwd_d_problem(d);
     g.ring_ok = d->precision == A3D_PREC_BF16 && (d->storage & both) == both && d->c % 8 == 0 && d->k % 8 == 0;
@@ -1182,7 +1215,7 @@ size_t a3d_conv2d_bwd_data_ws_bytes(const a3d_conv_desc* d) {
   for (int ph = 0; ph < d->stride; ++ph)
     for (int pw = 0; pw < d->stride; ++pw) {
       BwdDClass c;
-      if (bwd_d_class(d, ph, pw, &c)) need = std::max(need, plan_gemm(c.g, d->precision).ws_bytes);
+      if (bwd_d_class(d, ph, pw, &c)) need = std::max(need, plan_ws_either(c.g, d->precision));
     }
   return need;
 }
@@ -1214,6 +1247,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
       GemmProblem g = c.g;
       if (!vec_ok_a) g.avec = 1;
       if (!vec_ok_b) g.bvec = 1;
+      if (g.avec != 4 || g.bvec != 4 || g.K == 0) g.gen2_ok = 0;
       IgemmParams p;
       fill_common(p, g);
       rc = apply_storage(p, g, d->precision, d->storage & A3D_STORE_Y_BF16, d->storage & A3D_STORE_W_BF16,
@@ -1285,6 +1319,7 @@ int a3d_conv2d_bwd_data(const a3d_conv_desc* d, const float* dz, const float* w,
         IgemmParams& p = multi.p[i];
         GemmProblem g = bwd_d_problem(d);
         g.M = p.M; g.K = p.K; g.avec = multi_avec; g.bvec = multi_bvec;
+        if (g.avec != 4 || g.bvec != 4 || g.K == 0) g.gen2_ok = 0;
         GemmPlan plan = plan_gemm(g, d->precision);
         if (plan.ws_bytes > ws_bytes)
           return set_error(A3D_EWORKSPACE, "conv2d_bwd_data: need %zu workspace bytes", plan.ws_bytes);
@@ -1425,6 +1460,11 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   GemmProblem g0 = bwd_f_problem(d);
   GemmPlan plan = plan_gemm(g0, d->precision);       // the plan without the LDS-DMA kernel: a launch may fall back to it (a dw
   size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);      // off the 16-byte grid: ADVICE r4)
+  if (g0.gen2_ok) {                                  // ... or to the first-generation kernel (operands off the 16-byte grid)
+    g0.gen2_ok = 0;
+    const GemmPlan p1 = plan_gemm(g0, d->precision);
+    need = std::max(need, p1.ws_bytes + (p1.splitk > 1 ? (size_t)p1.splitk * d->k * 4 : 0));
+  }
   if (bwd_f_ring_ok(d)) {
     g0.ring_ok = 1;
     GemmPlan pr = plan_gemm(g0, d->precision);
@@ -1466,6 +1506,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
     ws_used = run_filter_bytes(d, rf);
     out = static_cast<float*>(ws);
   }
+  if (run || g.avec != 4 || g.bvec != 4) g.gen2_ok = 0;
   IgemmParams p;
   fill_common(p, g);
   rc = apply_storage(p, g, d->precision, d->storage & A3D_STORE_X_BF16, d->storage & A3D_STORE_Y_BF16, false, d->c, d->ldx,
@@ -1519,7 +1560,7 @@ size_t a3d_dense_fwd_ws_bytes(int m, int k, int n) {
   a3d_conv_desc d = dense_desc(m, k, n);
   if (check_desc(&d) != A3D_OK) return 0;
   // the GEMM a3d_dense_fwd plans (never the few-channel convolution paths: a dense layer of <= 4 inputs is still a GEMM)
-  return std::max(plan_gemm(fwd_problem(&d), A3D_PREC_F32).ws_bytes, dense_stream_ws_bytes(m, k, n));
+  return std::max(plan_ws_either(fwd_problem(&d), A3D_PREC_F32), dense_stream_ws_bytes(m, k, n));
 }
 
 int a3d_dense_fwd(int m, int k, int n, const float* x, const float* w, const float* bias, float* y, int act,
@@ -1547,6 +1588,7 @@ int a3d_dense_fwd_ex2(int m, int k, int n, const float* x, const float* w, const
       !tune_int("A3D_NO_DENSE_KERNELS", 0))
     return dense_fwd_stream(m, k, n, x, w, bias, y, act, drop_keep, 2.f, ws, ws_bytes, static_cast<hipStream_t>(stream));
   GemmProblem g = fwd_problem(&d);
+  g.gen2_ok = 0;                                // dense layers: rows of weights, not 128-row pixel tiles
   if (!aligned16(x)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
   IgemmParams p;
@@ -1596,6 +1638,7 @@ int a3d_dense_bwd_data_ex2(int m, int k, int n, const float* dz, const float* w,
   if (rc != A3D_OK) return rc;
   A3D_CHECK_ARG(dz && w && dx, "dense_bwd_data: null tensor");
   GemmProblem g = bwd_d_problem(&d);
+  g.gen2_ok = 0;                                // dense layers: rows of weights, not 128-row pixel tiles
   if (!aligned16(dz)) g.avec = 1;
   if (!aligned16(w)) g.bvec = 1;
   IgemmParams p;

@@ -3,6 +3,7 @@
 #include "a3d_internal.h"
 #include "igemm.h"
 #include "igemm_glds.h"
+#include "igemm2.h"
 
 namespace a3d {
 
@@ -67,6 +68,28 @@ static int launch_glds(IgemmParams& p, unsigned grid, hipStream_t st) {
   return check_launch("igemm_glds");
 }
 
+// second-generation kernel (igemm2.h): config index 11, fix-ups and register-staged twin of config 0 (same wave layout)
+constexpr int kGen2CfgIndex = 11;
+static bool gen2_applicable(const IgemmParams& p, int avec, int bvec) {
+  if (avec != 4 || bvec != 4 || p.a16 || p.b16 || p.c16) return false;
+  if (A3D_MODE == MODE_BWD_F) return p.Cg % 4 == 0 && p.N % 4 == 0;
+  return p.uni && p.Cg % 32 == 0 && p.stride >= 1 && (A3D_MODE == MODE_FWD || p.stride == 1);
+}
+static int launch_gen2(IgemmParams& p, unsigned grid, hipStream_t st) {
+  using Cfg = Gen2Cfg<A3D_MODE>;
+  auto kern = igemm2_kernel<A3D_MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return set_error(A3D_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  clear_stale_error();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_NT), Cfg::LDS_BYTES, st, p);
+  return check_launch("igemm2");
+}
+
 template <int BM, int BN, int WAVES_M, int NWAVES>
 static int launch_fixup_one(IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st) {
   clear_stale_error();
@@ -105,6 +128,7 @@ int launch_igemm_multi_bwd_d(int avec, int bvec, IgemmMulti& ps, unsigned grid_x
 
 // stream-K fixup of a launch made with register-staged config `cfg`
 int A3D_CAT(launch_fixup_mode, A3D_MODE)(int cfg, IgemmParams& p, unsigned tiles, unsigned nblk, hipStream_t st) {
+  if (cfg == kGen2CfgIndex) cfg = 0;
   switch (cfg) {
 #define X(i, bm, bn, wm, nw, bk) \
   case i: return launch_fixup_one<bm, bn, wm, nw>(p, tiles, nblk, st);
@@ -115,6 +139,10 @@ int A3D_CAT(launch_fixup_mode, A3D_MODE)(int cfg, IgemmParams& p, unsigned tiles
 }
 
 int A3D_CAT(launch_igemm_mode, A3D_MODE)(int cfg, int avec, int bvec, IgemmParams& p, unsigned grid, hipStream_t st) {
+  if (cfg == kGen2CfgIndex) {
+    if (gen2_applicable(p, avec, bvec)) return launch_gen2(p, grid, st);
+    cfg = 0;
+  }
   switch (cfg) {
 #define X(i, bm, bn, wm, nw, twin) \
   case i:                          \

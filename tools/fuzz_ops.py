@@ -424,7 +424,7 @@ def force_plan():
     u = rng.random()
     if u < 0.5:
         return 'auto'
-    os.environ['A3D_FORCE_CFG'] = str(int(rng.integers(0, 11)))
+    os.environ['A3D_FORCE_CFG'] = str(int(rng.integers(0, 12)))      # 11: the second-generation kernel (its twin where it does not apply)
     if u < 0.75:
         os.environ['A3D_FORCE_SPLITK'] = str(int(rng.choice([1, 2, 3, 5, 8, 13])))
         return 'cfg%s sk%s' % (os.environ['A3D_FORCE_CFG'], os.environ['A3D_FORCE_SPLITK'])

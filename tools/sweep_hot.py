@@ -37,13 +37,13 @@ for name, h, w, c, k, ks, st, pad in LAYERS:
     for mode, fn in modes.items():
         clear(); t_auto = timeit(fn)
         res = []
-        for ci in (0, 1, 4, 7, 8, 9, 10):
+        for ci in (0, 1, 4, 7, 8, 9, 10, 11):
             for kind, vals in (('sk', (1, 2, 3, 4, 6, 8, 13, 16, 32, 64, 128)), ('st', (256, 512))):
                 for v in vals:
                     clear(); os.environ['A3D_FORCE_CFG'] = str(ci)
                     if kind == 'sk': os.environ['A3D_FORCE_SPLITK'] = str(v)
                     else:
-                        if ci >= 9: continue
+                        if ci in (9, 10): continue
                         os.environ['A3D_FORCE_STREAMK'] = str(v)
                     try: t = timeit(fn, 3)
                     except Exception: continue

@@ -18,7 +18,7 @@ LAYERS = [  # name, h, w, cin, cout, k, stride, pad
     ('fine2', 55, 74, 64, 64, 5, 1, 'SAME'), ('fine3', 55, 74, 64, 1, 5, 1, 'SAME'),
     ('dense_0', 1, 1, 12288, 4096, 1, 1, 'VALID'), ('dense_1', 1, 1, 4096, 4070, 1, 1, 'VALID'),
 ]
-CFGS = ['128x128', '128x96', '128x64', '128x32', '64x64', '32x128', '64x128', '128x128w8', '128x64w8', 'G128x128w8', 'G128x64w8']
+CFGS = ['128x128', '128x96', '128x64', '128x32', '64x64', '32x128', '64x128', '128x128w8', '128x64w8', 'G128x128w8', 'G128x64w8', 'N128x128']       # N: the second-generation kernel (igemm2.h)
 
 
 def timeit(fn, reps=5):
