@@ -49,6 +49,7 @@ struct GemmProblem {
   int M, N, K;
   int avec, bvec;    // 1 or 4
   int plain = 0;     // 1: register-staged kernel without split-K only (fused-pool forward)
+  int need_reduce = 0;   // 1: the output is stored by the split-K reduction only (rows narrower than the GEMM's N): split-K >= 2, no stream-K
   int no_glds = 0;   // 1: not the LDS-DMA kernels (bf16 output)
   int gen2_ok = 0;   // 1: the launch may run on the second-generation LDS-DMA kernel (igemm2.h): float32 tensors, 16-byte
                      //    operands, forward / bwd-data: gathered channels a multiple of 32 and K = taps x channels
@@ -91,6 +92,7 @@ int stencil1_bwd_both(const a3d_conv_desc* d, const float* x, const float* dz, c
 // ---- few-channel filter gradient from LDS-staged input rows, optionally with the max pool's gradient fused (fewch.hip) ----
 bool fewch_bwdf_applicable(const a3d_conv_desc* d, bool pooled);
 size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled);
+bool fewch_extents_ok(const a3d_conv_desc* d, bool pooled, int ldz, int esz, int ld_arg);
 int fewch_bwd_filter(const a3d_conv_desc* d, const float* x, int src, const void* dz, int ldz, const void* pooled_act,
                      const uint8_t* argmax, int ld_arg, float* dw, float* db, void* ws, hipStream_t st);
 

@@ -386,12 +386,23 @@ bool fewch_bwdf_applicable(const a3d_conv_desc* d, bool pooled) {
   if ((d->ho - 1) * d->stride + d->r > d->h || (d->wo - 1) * d->stride + d->s > d->w) return false;   // VALID geometry
   if (pooled && (d->ho < 2 || d->wo < 2)) return false;
   if ((d->w * d->c) % 4 != 0) return false;           // input rows as whole 16-byte pieces
+  // one buffer descriptor per whole tensor, 31-bit byte offsets (kOOB = 2^31 marks a piece as out of range): x here, the
+  // gradient tensors with their real pixel strides in fewch_extents_ok (the callers: igemm_host.hip)
+  if ((double)d->n * d->h * d->w * d->c * 4.0 >= 2147483647.0) return false;
   const FewchShape s = fewch_shape(d, pooled);
   if (s.rows_total < 1 || s.lds > 78 * 1024) return false;
   // the per-thread staging registers: kPX pieces of input rows, kPD pieces of the dz row (or 4-channel groups of the pooled row)
   if (kFewRows * (d->w * d->c / 4) > kPX * 256) return false;
   if ((pooled ? d->wo / 2 : d->wo) * ((d->k + 3) / 4) > (pooled ? kPDPooled : kPDPlain) * 256) return false;
   return true;
+}
+
+// The gradient-side tensors of a launch against the kernels' 31-bit byte offsets: dz (plain source: n x ho x wo pixels of ldz
+// elements of esz bytes) or the pooled gradient and the pooled activations (n x ho/2 x wo/2 pixels of ldz elements) with their
+// argmax bytes (ld_arg per pixel).  Shared by fewch16.hip (bf16 gradient tensors: esz 2).
+bool fewch_extents_ok(const a3d_conv_desc* d, bool pooled, int ldz, int esz, int ld_arg) {
+  const double pixels = pooled ? (double)d->n * (d->ho / 2) * (d->wo / 2) : (double)d->n * d->ho * d->wo;
+  return pixels * ldz * esz < 2147483647.0 && (!pooled || pixels * ld_arg < 2147483647.0);
 }
 
 size_t fewch_bwdf_ws_bytes(const a3d_conv_desc* d, bool pooled) {

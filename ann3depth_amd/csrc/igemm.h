@@ -30,8 +30,18 @@ namespace a3d {
     __builtin_amdgcn_sched_barrier(0);                                                         \
     var = t_;                                                                                  \
   } while (0)
+// the constant 100 MHz counter: loop cycles / loop ticks x 100 MHz = the clock the chip held during the loop
+#define A3D_RTSTAMP(var)                                                                       \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    unsigned long long t_;                                                                     \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    var = t_;                                                                                  \
+  } while (0)
 #else
 #define A3D_STAMP(var) do { } while (0)
+#define A3D_RTSTAMP(var) do { } while (0)
 #endif
 
 #ifndef A3D_PIPE_ALL
@@ -856,7 +866,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   };
 
 #ifdef A3D_STAMPS
-  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0, rtbeg = 0, rtend = 0;
 #endif
   auto k_loop = [&](auto uni_c) {
   // AHEAD: the next tile's addresses are computed one tile early, in the shadow of the MFMAs (forward / bwd-data: a
@@ -872,6 +882,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
 
 #ifdef A3D_STAMPS
   A3D_STAMP(tbeg);
+  A3D_RTSTAMP(rtbeg);
 #endif
   // one K tile; `cur` (which half of the double-buffered LDS tiles it reads) is a compile-time constant: the loop below is
   // unrolled by two, so every fragment read is `lane constant + immediate` instead of an address rebuilt per tile (20 of the
@@ -1018,10 +1029,11 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   }
 #ifdef A3D_STAMPS
   A3D_STAMP(tend);
+  A3D_RTSTAMP(rtend);
   if (p.stamps && lane == 0) {
     unsigned long long* o = p.stamps + ((size_t)bid_in * NWAVES + wave) * 16;
     o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = 0;
-    o[8] = tbeg - t_entry; o[9] = t_entry; o[10] = tend;
+    o[8] = tbeg - t_entry; o[9] = t_entry; o[10] = tend; o[12] = rtend - rtbeg; o[13] = rtbeg; o[14] = rtend;
   }
 #define A3D_STAMP_EXIT()                                                                                   \
   do {                                                                                                     \

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(G2_NT, 2) void igemm2_kernel(const IgemmParams p) {
   const int pW = p.W, pld = p.ld;
 #ifdef A3D_STAMPS          // diagnostic build (never shipped): tools/stamps_layer.py, the slots of igemm_body's stamps
   unsigned long long st_entry = 0, st_beg = 0, st_end = 0, st_wait = 0, st_bar = 0, st_s0 = 0, st_s1 = 0, st_s2 = 0, st_pro = 0, st_loop = 0,
-                     st_nkt = 0;
+                     st_nkt = 0, st_rt0 = 0, st_rt1 = 0, st_rt = 0, st_rtfirst = 0;
   A3D_STAMP(st_entry);
 #endif
 
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(G2_NT, 2) void igemm2_kernel(const IgemmParams p) {
       }
 #ifdef A3D_STAMPS
       A3D_STAMP(st_beg);
-      if (seg == 0) st_pro = st_beg - st_entry;
+      A3D_RTSTAMP(st_rt0);
+      if (seg == 0) { st_pro = st_beg - st_entry; st_rtfirst = st_rt0; }
 #endif
       auto tile_body = [&](const int it, auto cur_c) {
         constexpr int cur = decltype(cur_c)::value;
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(G2_NT, 2) void igemm2_kernel(const IgemmParams p) {
       }
 #ifdef A3D_STAMPS
       A3D_STAMP(st_end);
-      st_loop += st_end - st_beg; st_nkt += (unsigned long long)nkt;
+      A3D_RTSTAMP(st_rt1);
+      st_loop += st_end - st_beg; st_nkt += (unsigned long long)nkt; st_rt += st_rt1 - st_rt0;
 #endif
     };
     if (do_bias) k_loop(std::true_type{});
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(G2_NT, 2) void igemm2_kernel(const IgemmParams p) {
     if (p.stamps && lane == 0) {               // slots as igemm_body writes them (eight waves per block there: four stay empty)
       unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 16;
       o[0] = 0; o[1] = st_loop - st_wait - st_bar; o[2] = st_wait; o[3] = 0; o[4] = st_bar; o[5] = st_loop; o[6] = st_nkt; o[7] = 0;
-      o[8] = st_pro; o[9] = st_entry; o[10] = st_end; o[11] = st_exit;
+      o[8] = st_pro; o[9] = st_entry; o[10] = st_end; o[11] = st_exit; o[12] = st_rt; o[13] = st_rtfirst; o[14] = st_rt1;
     }
   }
 #endif

@@ -145,6 +145,7 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
     const int nk = std::max(1, (g.K + 63) / 64);
     int splitk = (int)std::min<long>(std::max<long>(512 / pl.tiles_n, 1), std::max(1, nk / 4));
     if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), nk);
+    if (g.need_reduce && nk >= 2) splitk = std::max(splitk, 2);      // rows narrower than the GEMM: stored by the reduction
     const int kps = (nk + splitk - 1) / splitk;
     pl.splitk = (nk + kps - 1) / kps;
     pl.ktiles_per_split = kps;
@@ -152,6 +153,7 @@ static bool ring_plan(const GemmProblem& g, GemmPlan& pl) {
     return true;
   }
   if (off && !g.plain) return false;              // (a pooled forward on bf16 inputs has no other kernel: ADVICE r4)
+  if (g.need_reduce) return false;                // the tiles below are never split: igemm_bf16's split-K stores the narrower rows
   if (g.mode == MODE_BWD_F) {
     // filter gradient: few tiles (M = r s Cin rows) over a long pixel axis — 256-row tiles, split-K until every CU has one block
     static const bool off_f = tune_int("A3D_RING_BWDF", 1) == 0;
@@ -215,6 +217,7 @@ static GemmPlan plan_gemm_bf16(const GemmProblem& g, int precision) {
     splitk = (int)std::min<long>(std::max<long>(target / tiles, 1), std::max(1, nk / 4));
   }
   if (tune_int("A3D_FORCE_SPLITK", 0) > 0) splitk = std::min(tune_int("A3D_FORCE_SPLITK", 0), std::max(1, nk));
+  if (g.need_reduce && nk >= 2) splitk = std::max(splitk, 2);
   if (g.plain) splitk = 1;                      // fused pool: whole K ranges only
   while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
   const int kps = (nk + splitk - 1) / splitk;
@@ -232,7 +235,7 @@ GemmPlan plan_gemm(const GemmProblem& g, int precision) {
   if (tuning()) return plan_gemm_search(g, precision);
   static std::mutex mu;
   static std::map<std::array<int, 11>, GemmPlan> cache;
-  const std::array<int, 11> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain, g.no_glds, precision, g.ring_ok, g.gen2_ok};
+  const std::array<int, 11> key = {g.mode, g.M, g.N, g.K, g.avec, g.bvec, g.plain + 2 * g.need_reduce, g.no_glds, precision, g.ring_ok, g.gen2_ok};
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -278,6 +281,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     const int bm = kCfgs[force_cfg].bm, bn = kCfgs[force_cfg].bn;
     const int nk = std::max(1, (g.K + kCfgs[force_cfg].bk - 1) / kCfgs[force_cfg].bk);
     int splitk = std::max(1, std::min(force_split > 0 ? force_split : 1, nk));
+    if (g.need_reduce && nk >= 2) splitk = std::max(splitk, 2);      // a narrower output is stored by the split-K reduction
     if (g.plain) splitk = 1;                     // the fused pool takes whole K ranges
     while (splitk > 1 && (size_t)splitk * g.M * g.N * 4 > kMaxSlabBytes) --splitk;
     int kps = (nk + splitk - 1) / splitk;
@@ -285,7 +289,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     best.cfg = force_cfg; best.splitk = splitk; best.ktiles_per_split = kps;
     best.tiles_m = (g.M + bm - 1) / bm; best.tiles_n = (g.N + bn - 1) / bn;
     best.ws_bytes = splitk > 1 ? (size_t)splitk * g.M * g.N * 4 : 0;
-    if (force_streamk > 0 && streamk_cfg(force_cfg) && !g.plain) {
+    if (force_streamk > 0 && streamk_cfg(force_cfg) && !g.plain && !g.need_reduce) {
       best.splitk = 1; best.ktiles_per_split = nk; best.streamk = force_streamk;
       best.ws_bytes = (size_t)2 * force_streamk * ((size_t)bm * bn + bn) * 4;
       best.sk_sliced = tune_int("A3D_FORCE_SK_SLICED", 0) &&
@@ -314,7 +318,8 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     for (int wi = 0; wi < nw; ++wi) {
       const int want = wants[wi];
       if (want > 1 && g.plain) continue;
-      if (want > 1 && want > nk / 2) continue;
+      if (want == 1 && g.need_reduce && nk >= 2) continue;      // (nk == 1: launch_igemm refuses the call, nothing is enqueued)
+      if (want > 1 && want > nk / 2 && !(g.need_reduce && want == 2)) continue;
       if (want > 1 && (size_t)want * g.M * g.N * 4 > kMaxSlabBytes) continue;
       const int kps = (nk + want - 1) / want;
       const int splitk = (nk + kps - 1) / kps;
@@ -341,7 +346,7 @@ static GemmPlan plan_gemm_search(const GemmProblem& g, int precision) {
     }
     // stream-K: equal shares of the (tile, k-tile) iterations for one or two blocks per CU — no tile quantisation, and
     // at most two partial slabs per block (register-staged kernels only; the pooling forward never splits)
-    if (streamk_cfg(c) && !g.plain && !env_flag_no_streamk()) {
+    if (streamk_cfg(c) && !g.plain && !g.need_reduce && !env_flag_no_streamk()) {
       const long iters = tiles * nk;
       for (int G = 256; G <= 512; G += 256) {
         if (force_streamk > 0 && G != 256) continue;
@@ -581,6 +586,18 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.avec = avec; r.bvec = bvec; r.splitk = plan.splitk; r.m = p.M; r.n = p.N; r.k = p.K; r.ms = 0.f;
     r.flops = 2.0 * p.M * p.N * p.K;
   }
+  // a second output / a narrower output are written by the reduction stage of a classic split-K forward or bwd-data launch
+  // (or, the second output, by a copy launch behind an unsplit one): refuse the other combinations BEFORE anything is
+  // enqueued — a GEMM that has already stored N columns into rows of c_cols floats cannot be taken back
+  const bool reduce_vec4 = plan.splitk > 1 && mode == MODE_BWD_F && p.ldc == p.N && (p.slab % 4) == 0 && aligned16(final_c) && aligned16(ws);
+  if (plan.streamk > 0) {
+    A3D_CHECK_ARG(!p.out2 && !p.c_cols, "second output: not on stream-K launches");
+  } else if (plan.splitk > 1) {
+    if (reduce_vec4 || mode == MODE_BWD_F) A3D_CHECK_ARG(!p.out2 && !p.c_cols, "a second output belongs to a forward or bwd-data launch");
+  } else {
+    A3D_CHECK_ARG(!p.c_cols || p.c_cols == p.N, "this launch has no reduction stage: the output cannot be narrower than the GEMM");
+    A3D_CHECK_ARG(!p.out2 || (p.sub_step == 1 && !p.pool), "second output: plain forward / bwd-data launches only");
+  }
   const bool timed = timing_wanted(slot.rec);
   if (timed && (rc = timing_begin(slot, st)) != A3D_OK) return rc;
   if (plan.ring) rc = launch_igemm_ring(mode, plan.ring - 1, p, grid, st);
@@ -591,7 +608,6 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
   if (timed) timing_end(slot, st);
   if (rc != A3D_OK) return rc;
   if (plan.streamk > 0) {
-    A3D_CHECK_ARG(!p.out2 && !p.c_cols, "second output: not on stream-K launches");
     const unsigned tiles = (unsigned)(plan.tiles_m * plan.tiles_n);
     if (mode == MODE_FWD) return launch_fixup_mode0(plan.cfg, p, tiles, grid, st);
     if (mode == MODE_BWD_D) return launch_fixup_mode1(plan.cfg, p, tiles, grid, st);
@@ -602,7 +618,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.ws = static_cast<const float*>(ws); r.C = final_c; r.bias = p.bias; r.mask = p.mask; r.keep = p.keep;
     r.mask_scale = p.mask_scale; r.M = p.M; r.N = p.N; r.ldc = p.ldc; r.splitk = plan.splitk; r.act = p.act;
     r.mode = mode; r.slab = p.slab; r.mask_act = p.mask_act; r.c16 = p.c16;
-    r.vec4 = mode == MODE_BWD_F && p.ldc == p.N && (p.slab % 4) == 0 && aligned16(final_c) && aligned16(ws);
+    r.vec4 = reduce_vec4;
     r.sub_step = p.sub_step; r.sub_ph = p.sub_ph; r.sub_pw = p.sub_pw; r.outW = p.outW; r.outHW = p.outHW;
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     r.dbias_ws = final_dbias ? p.dbias : nullptr;
@@ -613,13 +629,10 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     }
     r.C2 = p.out2; r.ld2 = p.out2_ld; r.step2 = p.out2_step; r.off2 = p.out2_off; r.c2_16 = p.out2_bf16; r.cols2 = p.out2_cols;
     r.c_cols = p.c_cols;
-    if (r.vec4 || mode == MODE_BWD_F) A3D_CHECK_ARG(!p.out2 && !p.c_cols, "a second output belongs to a forward or bwd-data launch");
     rc = launch_splitk_reduce(r, st);
     return rc;
   }
-  A3D_CHECK_ARG(!p.c_cols || p.c_cols == p.N, "this launch has no reduction stage: the output cannot be narrower than the GEMM");
   if (p.out2) {                                       // no reduction stage wrote it: one copy launch (what the caller saved otherwise)
-    A3D_CHECK_ARG(plan.streamk == 0 && p.sub_step == 1 && !p.pool, "second output: plain forward / bwd-data launches only");
     const size_t total = (size_t)p.M * p.out2_cols;
     clear_stale_error();
     hipLaunchKernelGGL(second_output_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, st,
@@ -1049,7 +1062,9 @@ static int conv_fwd_impl(const a3d_conv_desc* d, const float* x, const float* w,
   const bool prepared = (d->hints & A3D_HINT_W_PREPARED) != 0;
   const bool run = run_form_ok(d, x, &rf) && (prepared || (ws && ws_bytes >= run_filter_bytes(d, rf)));
   if (run || g.avec != 4 || g.bvec != 4 || (out2 && out2->ptr)) g.gen2_ok = 0;
-  A3D_CHECK_ARG(!prepared || (run && aligned16(w)), "conv2d_fwd: A3D_HINT_W_PREPARED on a launch that reads the filter as stored");
+  // (the prepared layout was chosen for a 16-byte aligned x — fwd_filter_form — and this launch reads it with THAT row padding)
+  A3D_CHECK_ARG(!prepared || (run && aligned16(w) && aligned16(x)),
+                "conv2d_fwd: A3D_HINT_W_PREPARED on a launch that reads the filter as stored, or with x off the 16-byte grid");
   size_t ws_used = 0;
   const float* filter = w;
   int run_ldb = d->k;
@@ -1425,6 +1440,7 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
                       (reinterpret_cast<uintptr_t>(dpool) & 7) == 0 && (reinterpret_cast<uintptr_t>(pooled) & 7) == 0 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0,
                   "conv2d_bwd_filter_pooled: bf16 arithmetic takes bf16 pooled tensors in whole aligned 4-channel groups");
+    A3D_CHECK_ARG(fewch_extents_ok(d, true, ld_dpool, 2, ld_argmax), "conv2d_bwd_filter_pooled: pooled tensors of 2 GiB or more");
     if (fewch16_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
     TimingSlot slot{};
     {
@@ -1448,6 +1464,7 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
   A3D_CHECK_ARG(ld_dpool % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(dpool) & (pooled_bf16 ? 7 : 15)) == 0 &&
                     (reinterpret_cast<uintptr_t>(pooled) & (pooled_bf16 ? 7 : 15)) == 0,
                 "conv2d_bwd_filter_pooled: x, dpool and pooled in whole aligned 4-channel groups (ld_dpool % 4 == 0)");
+  A3D_CHECK_ARG(fewch_extents_ok(d, true, ld_dpool, pooled_bf16 ? 2 : 4, ld_argmax), "conv2d_bwd_filter_pooled: pooled tensors of 2 GiB or more");
   if (fewch_bwdf_ws_bytes(d, true) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter_pooled: workspace too small");
   return fewch_timed(d, x, pooled_bf16 ? 2 : 1, dpool, ld_dpool, pooled, argmax, ld_argmax, dw, db, ws,
                      static_cast<hipStream_t>(stream));
@@ -1456,7 +1473,7 @@ int a3d_conv2d_bwd_filter_pooled(const a3d_conv_desc* d, const float* x, const v
 size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
   if (check_desc(d) != A3D_OK) return 0;
   if (stencil1_applicable(d)) return stencil1_bwdf_ws_bytes(d);
-  if (fewch_wanted(d, false)) return fewch_bwdf_ws_bytes(d, false);
+  const size_t few = fewch_wanted(d, false) ? fewch_bwdf_ws_bytes(d, false) : 0;      // (an unaligned x falls back to the plans below)
   GemmProblem g0 = bwd_f_problem(d);
   GemmPlan plan = plan_gemm(g0, d->precision);       // the plan without the LDS-DMA kernel: a launch may fall back to it (a dw
   size_t need = plan.ws_bytes + (plan.splitk > 1 ? (size_t)plan.splitk * d->k * 4 : 0);      // off the 16-byte grid: ADVICE r4)
@@ -1477,7 +1494,7 @@ size_t a3d_conv2d_bwd_filter_ws_bytes(const a3d_conv_desc* d) {
     GemmPlan pr = plan_gemm(g, d->precision);
     need = std::max(need, run_filter_bytes(d, rf) + pr.ws_bytes + (pr.splitk > 1 ? (size_t)pr.splitk * d->k * 4 : 0));
   }
-  return need;
+  return std::max(need, few);
 }
 
 int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* dz, float* dw, float* db, void* ws,
@@ -1490,7 +1507,7 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
     if (stencil1_bwdf_ws_bytes(d) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return stencil1_bwd_filter(d, x, dz, dw, db, ws, static_cast<hipStream_t>(stream));
   }
-  if (fewch_wanted(d, false) && aligned16(x)) {
+  if (fewch_wanted(d, false) && aligned16(x) && fewch_extents_ok(d, false, d->ldy, 4, 0)) {
     if (fewch_bwdf_ws_bytes(d, false) > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: workspace too small");
     return fewch_timed(d, x, 0, dz, d->ldy, nullptr, nullptr, 0, dw, db, ws, static_cast<hipStream_t>(stream));
   }
@@ -1596,6 +1613,7 @@ int a3d_dense_fwd_ex2(int m, int k, int n, const float* x, const float* w, const
   rc = apply_storage(p, g, precision, storage & A3D_STORE_X_BF16, storage & A3D_STORE_W_BF16, false, k, k, n, n, x, w, y, n, n);
   if (rc != A3D_OK) return rc;
   g.ring_ok = p.a16 && p.b16 && precision == A3D_PREC_BF16 && k % 8 == 0 && n % 8 == 0 && aligned16(y) && act != A3D_ACT_SIGMOID;
+  g.need_reduce = ncols_y != n;                  // rows narrower than the GEMM are stored by the split-K reduction: plan one
   GemmPlan plan = plan_gemm(g, precision);
   A3D_CHECK_ARG(!storage || plan.prec == A3D_PREC_BF16, "dense_fwd: bf16 weights need vectorisable operands");
   A3D_CHECK_ARG(!p.a16 || plan.ring, "dense_fwd: a bf16 x is taken by the LDS-DMA kernel only (bf16 weights, k and n multiples of 8)");

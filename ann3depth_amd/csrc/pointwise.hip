@@ -583,7 +583,10 @@ __global__ __launch_bounds__(256) void comm_standin_kernel(const float* __restri
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) acc += v[u];
-    if (wpos < whi) {                                   // one piece written per eight read (the rank keeps 1/8 of the sums)
+    // writes keep pace with the reads: after reading a fraction f of its share a block has written the same fraction of what
+    // it has to write (reduce-scatter: one piece per eight read; all-reduce stand-in, write_f4 == read_f4: eight per eight)
+    const size_t wdue = wlo + (size_t)((double)(min(hi, i + 256 * U) - lo) * (double)(whi - wlo) / (double)(hi - lo));
+    while (wpos < wdue) {
       __builtin_nontemporal_store(acc, d4 + wpos);
       wpos += 256;
     }

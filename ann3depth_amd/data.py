@@ -66,13 +66,32 @@ def _get_pipeline(dataset):
     return pipelines.get(dataset, default)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the smallest of the host's count, the affinity mask and the cgroup's CPU quota
+    (a GPU box of this pipeline shows 256 hardware threads and a quota of 16)."""
+    n = os.cpu_count() or 2
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def default_reader_threads():
-    """The reference uses num_threads=2 (src/data.py:55), enough for a 2017 GPU; an MI355X eats ~10.6 k records/s.
-    Twelve threads decode 16-18 k records/s on the GPU box (tools/bench_input.py, profiles/r03_input_pipeline.json), each
-    taking RECORDS_PER_CALL records per call into liba3d.so so that the interpreter lock stays with the thread that
-    launches the step (one record per call and sixteen threads: 9.1 k images/s through the loop instead of 10.3 k)."""
+    """The reference uses num_threads=2 (src/data.py:55), enough for a 2017 GPU; an MI355X eats ~11.4 k records/s.  Half of
+    the CPUs the process may use, at most eight: a reader that wakes needs the interpreter lock, which the thread that launches
+    the training step takes ~50 times per step, so MORE readers than the decode rate needs make the loop slower (round 6 on
+    a 16-CPU quota: 6 / 8 readers 0.97 of the resident step rate, 12 readers 0.89, 16 readers 0.91; round 5, with every
+    reader woken at every dequeue and release, 12 readers 0.85 — profiles/r06_input_pipeline.json).  Each reader takes
+    RECORDS_PER_CALL records per call into liba3d.so (decode outside the interpreter lock)."""
     env = os.environ.get('A3D_READER_THREADS')
-    return int(env) if env else max(2, min(12, (os.cpu_count() or 2) // 2))
+    return int(env) if env else max(2, min(8, usable_cpus() // 2))
 
 
 def expand_u8(k):
@@ -99,7 +118,13 @@ class ShuffleBatch:
         self.images = self.depths = None
         self.images_u8 = self.depths_u8 = None    # uint8 twins of the pool (allocate(..., alloc_u8)): converter-written records
         self.kind = None                          # per slot: bit 0 image is in images_u8, bit 1 depth is in depths_u8
-        self.cv = threading.Condition()
+        # one lock, two wait sets: producers sleep on `cv` (room in the queue / a free slot), the consumer on `ready` (enough
+        # elements).  A thread that wakes needs the interpreter lock, and so does the thread that launches the training step
+        # ~50 times per step: nobody is woken who cannot make progress (notify_all on one condition woke every reader at
+        # every dequeue and release: 0.85 of the resident step rate with 12 readers, tools/bench_input.py)
+        self.lock = threading.Lock()
+        self.cv = threading.Condition(self.lock)
+        self.ready = threading.Condition(self.lock)
         self.src_lock = threading.Lock()
         self.live = num_threads
         self.error = None
@@ -146,7 +171,7 @@ class ShuffleBatch:
             self.kind[slot] &= ~(1 << which) & 0xff
         return f32[slot]
 
-    RECORDS_PER_CALL = 4      # a reader thread decodes this many records per call into liba3d.so (one lock round trip each)
+    RECORDS_PER_CALL = 8      # a reader thread decodes this many records per call into liba3d.so (one lock round trip each)
 
     def _next_records(self, want):
         """Up to `want` records (at least one, or StopIteration): each record goes to exactly one thread."""
@@ -203,14 +228,16 @@ class ShuffleBatch:
                     recs = recs[room:]
                     with self.cv:
                         self.queue.extend(slots)
-                        self.cv.notify_all()
+                        if len(self.queue) >= self.min_after + self.B:      # (the consumer sleeps below that)
+                            self.ready.notify()
         except BaseException as e:                  # surfaced by dequeue(): never swallow a corrupt record
             with self.cv:
                 self.error = e
+                self.ready.notify_all()
         finally:
             with self.cv:
                 self.live -= 1
-                self.cv.notify_all()
+                self.ready.notify_all()
 
     def start(self):
         if not self.started:
@@ -219,10 +246,15 @@ class ShuffleBatch:
             for t in self.threads:
                 t.start()
 
+    def _wake_producers(self, nslots):
+        # (lock held) as many readers as the slots that became usable give work to, not all of them
+        self.cv.notify(max(1, -(-nslots // self.RECORDS_PER_CALL)))
+
     def close(self):
         with self.cv:
             self.closed = True
             self.cv.notify_all()
+            self.ready.notify_all()
 
     def dequeue(self):
         """-> list of batch_size slot numbers (their contents stay valid until release())."""
@@ -237,7 +269,7 @@ class ShuffleBatch:
                     if len(self.queue) >= self.B:
                         break
                     raise OutOfRangeError('input queue is closed and has insufficient elements')
-                self.cv.wait()
+                self.ready.wait()
             # batch_size uniformly chosen distinct elements (RandomShuffleQueue.dequeue_many), drawn in one call: removing
             # the chosen positions from the back keeps the positions still to be removed valid
             chosen = self.rng.choice(len(self.queue), self.B, replace=False)
@@ -245,13 +277,13 @@ class ShuffleBatch:
             for i in sorted(chosen.tolist(), reverse=True):
                 self.queue[i] = self.queue[-1]
                 self.queue.pop()
-            self.cv.notify_all()
+            self._wake_producers(min(self.B, len(self.free)))
         return picks
 
     def release(self, slots):
         with self.cv:
             self.free.extend(slots)
-            self.cv.notify_all()
+            self._wake_producers(len(slots))
 
     def next_batch(self, out_images=None, out_depths=None):
         """Dequeue into freshly stacked (or caller-provided) host arrays: ([B,H,W,3], [B,H',W',1]) float32."""

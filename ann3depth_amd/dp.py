@@ -196,8 +196,10 @@ class StandinReducer(DetachedReducer):
             torch.cuda.current_stream().wait_event(self.event)
             return True
 
-    def __init__(self, world_size, rank=0, gbytes_per_s=200.0, workgroups=24, urgent_stream=True):
+    def __init__(self, world_size, rank=0, gbytes_per_s=200.0, workgroups=24, urgent_stream=True, inplace=True):
         super().__init__(world_size, rank)
+        self.inplace = bool(inplace)            # False: answer inplace_ok() like a backend that refused the aliasing collectives —
+        #                                         the replica then exchanges the dense bucket as all-reduces (the fallback path)
         self.gbytes_per_s, self.workgroups = float(gbytes_per_s), int(workgroups)
         self.streams = {}
         self.urgent_stream = urgent_stream      # False: every stand-in on ONE stream, as with a single communicator
@@ -224,6 +226,9 @@ class StandinReducer(DetachedReducer):
             ev.record(stream)
         self.launched_bytes += nbytes + wbytes
         return self._Work(ev)
+
+    def inplace_ok(self, device):
+        return self.inplace
 
     def start(self, flat_grad, urgent=False):
         # ring all-reduce: a rank reads and writes its bucket about twice (reduce-scatter + all-gather phases)

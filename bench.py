@@ -216,42 +216,65 @@ def cpu_baseline(B=32, seconds_budget=25.0):
                       f'compiled-in cap) on a {os.cpu_count()}-thread host; CPU restatement, not TF-1.3 Eigen'}
 
 
-def hbm_bytes_bf16_storage(B):
-    """Algorithmic HBM bytes of one coarse-phase step under precision 'bf16s' (BASELINE config 5: 2-byte activations and
-    weight copies), by SURVEY 8d's accounting rule: every tensor is counted once per pass that must read or write it —
-    an activation once when produced and once per consumer pass, weights once per pass that uses them, the frozen
-    ApplyAdam as read g + read m + write m (conv group) or read m + write m (dense kernels, gradient never stored)."""
+def hbm_bytes_bf16_storage(B, phase='coarse'):
+    """Algorithmic HBM bytes of one train step under precision 'bf16s' (BASELINE config 5: 2-byte activations and weight
+    copies), by SURVEY 8d's accounting rule: every tensor is counted once per pass that must read or write it — an activation
+    once when produced and once per consumer pass, weights once per pass that uses them, the frozen ApplyAdam as read g + read
+    m + write m (conv groups) or read m + write m (dense kernels, gradient never stored).  phase 'coarse': both forwards, the
+    backward of coarse/*; 'fine': both forwards, the backward of fine/* (src/models.py:326-344)."""
     f4, b2 = 4, 2
     px = lambda h, w, c, e: h * w * c * e
-    per_image = (
+    forward = (
         px(480, 640, 3, f4) + px(480, 640, 1, f4)                  # stored record, read by the resize
-        + 3 * px(228, 304, 3, f4) + 3 * px(55, 74, 1, f4)          # x: written, read by conv2d_0 fwd, fine/first fwd (+ conv2d_0 bwd-filter: below); t: written, read by both losses
-        + px(228, 304, 3, f4)                                      # x again: conv2d_0 bwd-filter
+        + 3 * px(228, 304, 3, f4) + 3 * px(55, 74, 1, f4)          # x: written, read by conv2d_0 fwd and by the 4-channel bf16 copy; t: written, read by both losses
         + 2 * px(228, 304, 4, b2)                                  # fine/first on the bf16 pipe: x4 written + read (conv + pool fused: f1 never reaches HBM)
-        # forward activations, written once and read once by the next layer (bf16): p0, p1, c2, c3, c4, cat; f2 fp32.  c1 never
-        # reaches HBM since round 4 (conv2d_1's pool is in its kernel's epilogue): one argmax byte per pool window instead
+        # forward activations, written once and read once by the next layer (bf16): p0, p1, c2, c3, c4, cat; f2 fp32.  c0 / c1
+        # never reach HBM (the pools are in the conv kernels' epilogues): one argmax byte per pool window instead
         + 2 * (px(27, 37, 96, b2) + px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2)
-               + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4) + px(13, 18, 256, 1)
-        + px(27, 37, 96, 1)                                        # conv2d_0's pool is in its kernel's epilogue too: argmax bytes, no c0
-        # backward of coarse/*: each stored activation read again (bwd-filter A operand / ReLU mask), each activation
-        # gradient written once and read by bwd-filter and bwd-data of the layer below (2 reads)
-        # (conv2d_1's pool gradient reads the argmax bytes and p1 instead of c1)
-        + (px(27, 37, 96, b2) + px(13, 18, 256, 1) + 2 * px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
-        + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
-        + px(27, 37, 96, 1) + px(27, 37, 96, b2) + 2 * px(55, 74, 96, b2)   # argmax bytes and p0 read by the pool gradient; dc0 (bf16) written + read
-        + 6 * 4096 * f4 + 6 * 4070 * f4                            # dense side tensors (drop, coarse, dz0, dz1, ...)
+               + px(55, 74, 64, b2)) + 2 * px(55, 74, 64, f4) + px(13, 18, 256, 1) + px(27, 37, 96, 1)
+        + 3 * 4096 * f4 + 3 * 4070 * f4                            # dense side tensors of the forward (d0, drop, coarse)
     )
     conv_w = 34944 + 614656 + 885120 + 1327488 + 884992            # coarse/conv parameters
     fine_w = 15372 + 102464 + 1601
     d0, d1 = 12288 * 4096 + 4096, 4096 * 4070 + 4070
-    per_step = (
-        2 * (conv_w - 34944) * b2 + 2 * 34944 * f4                 # conv kernels: bf16 copies in fwd and bwd-data (conv2d_0: fp32)
-        + fine_w * f4                                              # fine network forward
-        + 2 * d0 * b2 + 2 * d1 * b2                                # the dense layers' bf16 copies, fwd and bwd-data (dense_1: round 4)
+    forward_w = (conv_w - 34944) * b2 + 34944 * f4 + fine_w * f4 + (d0 + d1) * b2      # bf16 copies (conv2d_0, fine/*: fp32)
+    if phase == 'fine':
+        backward = (
+            px(228, 304, 3, f4)                                    # x again: fine/first's filter gradient
+            + px(55, 74, 64, 1)                                    # fine/first's pool: argmax bytes written by the forward ...
+            + px(55, 74, 64, 1) + px(55, 74, 64, b2)               # ... and read, with the pooled activations, by its fused pool gradient
+            + px(55, 74, 64, f4)                                   # f2 read again by fine/third's backward
+            + 3 * px(55, 74, 64, b2)                               # df2 written, read by fine/second's bwd-filter and bwd-data
+            + px(55, 74, 64, b2)                                   # cat read again by fine/second's bwd-filter
+            + 2 * px(55, 74, 64, b2)                               # dcat written, read by fine/first's filter gradient
+            + 2 * px(55, 74, 1, f4)                                # the loss gradient
+        )
+        backward_w = 102464 * b2 + fine_w * f4 * (1 + 3)           # fine/second's copy in bwd-data; dW written; ApplyAdam: g, m read, m written
+        return B * (forward + backward) + forward_w + backward_w
+    backward = (
+        px(228, 304, 3, f4)                                        # x again: conv2d_0's filter gradient
+        # each stored activation read again (bwd-filter A operand / ReLU mask), each activation gradient written once and
+        # read by bwd-filter and bwd-data of the layer below (conv2d_1's pool gradient reads the argmax bytes and p1)
+        + (px(27, 37, 96, b2) + px(13, 18, 256, 1) + 2 * px(13, 18, 256, b2) + 2 * px(13, 18, 384, b2) + px(6, 8, 256, b2))
+        + 3 * (px(6, 8, 256, b2) + 2 * px(13, 18, 384, b2) + px(13, 18, 256, b2) + px(27, 37, 256, b2) + px(27, 37, 96, b2))
+        + px(27, 37, 96, 1) + px(27, 37, 96, b2) + 2 * px(55, 74, 96, b2)   # argmax bytes and p0 read by the pool gradient; dc0 (bf16) written + read
+        + 3 * 4096 * f4 + 3 * 4070 * f4                            # dense side tensors of the backward (dz1, dz0, ...)
+    )
+    backward_w = (
+        (conv_w - 34944) * b2 + 34944 * f4                         # conv kernels again in bwd-data
+        + (d0 + d1) * b2                                           # the dense layers' bf16 copies in bwd-data
         + conv_w * f4 * (1 + 3)                                    # conv dW written; ApplyAdam: g, m read, m written
         + (d0 + d1) * f4 * 2                                       # dense dW -> m slot in place: m read, m written
     )
-    return B * per_image + per_step
+    return B * (forward + backward) + forward_w + backward_w
+
+
+def hbm_roofline_bf16_storage(B, phase, seconds_per_step):
+    nbytes = hbm_bytes_bf16_storage(B, phase)
+    return {'bound': 'hbm', 'scope': f'{phase}-phase step, 2-byte activations and weight copies (hbm_bytes_bf16_storage)',
+            'achieved': round(nbytes / seconds_per_step / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+            'frac': round(nbytes / seconds_per_step / 8e12, 4), 'traffic': None,
+            'bytes_per_step': nbytes, 'bytes_per_image': round(nbytes / B)}
 
 
 def bench_dcnf(args, lib, device, rank, world):
@@ -395,12 +418,8 @@ def main():
     roof, _ = roofline_from(recs)                                     # the dominant kernel, event-timed in the timed region
     _, table = roofline_from(warm_recs, with_traffic=False)           # every kernel: event-timed during the warm-up steps
     if args.precision == 'bf16s':
-        # the bf16 matrix cores leave this step HBM-bound: price the whole step against the HBM roofline
-        nbytes = hbm_bytes_bf16_storage(B)
-        roof = {'bound': 'hbm', 'scope': 'coarse-phase step, 2-byte activations and weight copies (hbm_bytes_bf16_storage)',
-                'achieved': round(nbytes / (dt / args.steps) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                'frac': round(nbytes / (dt / args.steps) / 8e12, 4), 'traffic': None,
-                'bytes_per_step': nbytes, 'bytes_per_image': round((nbytes) / B)}
+        # the bf16 matrix cores leave this step HBM-bound: price the whole step of the phase that ran against the HBM roofline
+        roof = hbm_roofline_bf16_storage(B, args.phase, dt / args.steps)
     extra = {}
     if not args.no_fine and args.phase == 'coarse':
         dtf, _ = run_phase(net, img, dep, masks, args.steps, min(args.warmup, 2), models.SAMPLES_COARSE // B, lib,
@@ -408,6 +427,8 @@ def main():
         extra['fine_phase'] = {'value': round(world * B * args.steps / dtf, 1), 'ms_per_step': round(1e3 * dtf / args.steps, 3)}
         if args.precision == 'fp32':
             extra['fine_phase']['roofline'] = step_roofline('fine', B, dtf / args.steps)
+        elif args.precision == 'bf16s':
+            extra['fine_phase']['roofline'] = hbm_roofline_bf16_storage(B, 'fine', dtf / args.steps)
     for prec in [p for p in args.also.split(',') if p and p != args.precision]:
         alt = models.MSDNReplica(B, device=device, seed=3000, reducer=reducer, precision=prec, keep_dense_grads=False)
         dta, _ = run_phase(alt, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
@@ -449,10 +470,29 @@ def main():
                             'mbytes_per_step': round(per_step / 1e6, 1),
                             'ms_of_standin_per_step': round(per_step / args.standin_gbps / 1e6, 3),
                             'what': 'one kernel per bucket on a second stream wherever the rank starts a collective: reads the '
-                                    'bucket, writes 1/world of it (reduce-scatter) or all of it (all-reduce), paced to the rate; '
-                                    'no communication happens'},
+                                    'bucket and, keeping pace with its reads, writes 1/world of it (reduce-scatter) or all of it '
+                                    '(all-reduce), paced to the rate; no communication happens'},
                 'scaling_ceiling_with_standin': round(args.dp_world * dt / dts, 2)})
             del snet
+            # the same with the FALLBACK exchange: what a rank does when the start-up self-check of the in-place collectives
+            # answers False over RCCL (dp.GradReducer.inplace_ok) — the dense bucket as all-reduces (each rank reads and
+            # writes ALL of it, keeps every dense gradient and applies Adam to all of it), not one reduce-scatter
+            fred = _dp.StandinReducer(args.dp_world, 0, args.standin_gbps, args.standin_workgroups,
+                                      urgent_stream=not args.standin_one_stream, inplace=False)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # (the replica announces the fallback on stdout: this line stays the only one there)
+                fnet = models.MSDNReplica(B, device=device, seed=3000, reducer=fred, precision=args.precision)
+            dtf2, _ = run_phase(fnet, img, dep, masks, args.steps, min(args.warmup, 3), 0, lib, world, timed_kernels=False)
+            per_step_f = fred.launched_bytes / (args.steps + min(args.warmup, 3))
+            extra['dp_rank']['fallback_exchange'] = {
+                'dense_exchange': fnet.dense_exchange,
+                'ms_per_step_dp_rank_with_standin': round(1e3 * dtf2 / args.steps, 3),
+                'mbytes_per_step': round(per_step_f / 1e6, 1),
+                'ms_of_standin_per_step': round(per_step_f / args.standin_gbps / 1e6, 3),
+                'scaling_ceiling_with_standin': round(args.dp_world * dt / dtf2, 2),
+                'what': 'inplace_ok() == False: the dense gradients go out as all-reduces (read + write all 268 MB) instead of one '
+                        'in-place reduce-scatter (read all, write 1/world); same pacing, same stand-in kernel'}
+            del fnet
     if rank == 0:
         line = {
             'metric': METRIC, 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,

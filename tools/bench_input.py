@@ -46,6 +46,8 @@ for label, u8 in (('uint8', True), ('float32', False)):
         sb.release(sb.dequeue())
     out[f'decode_only_images_per_s_{label}'] = round(B * steps / (time.perf_counter() - t0), 1)
     out['reader_threads'] = len(sb.threads)
+    out['usable_cpus'] = data.usable_cpus()
+    out['host_threads'] = os.cpu_count()
     sb.close()
 # `make train`'s loop on both transfer paths: converter-written records staged and DMA'd as uint8 pixel values (the default
 # for such records, data.py), and everything as float32 (A3D_NO_U8_RECORDS=1: what round 2 measured)

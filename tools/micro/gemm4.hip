@@ -73,11 +73,11 @@ __device__ __forceinline__ unsigned remap_xcd(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-constexpr int KC = 0, MC = 1;
+constexpr int KC = 0, MC = 1, MX = 2;      // MX: as MC, but unpadded 1-KiB pieces; the column chunks of k rows with (k >> 2) & 1 XOR 8 (= columns XOR 32), reads by ds_read2st64_b32
 constexpr int MC_PIECE = 1088;                                  // bytes between the two-row pieces of an MC tile
-constexpr int tile_bytes(int lay) { return lay == KC ? 128 * 128 : 16 * MC_PIECE; }
+constexpr int tile_bytes(int lay) { return lay == MC ? 16 * MC_PIECE : 128 * 128; }
 
-template <int NS, int AL, int BL, int DM, int ABL, bool STAMPS, int MINB>
+template <int NS, int AL, int BL, int DM, int ABL, bool STAMPS, int MINB, int EPI = 0>
 __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                 int M, int N, int K, unsigned long long* stamps) {
   constexpr int BM = 128, BN = 128, BK = 32;
@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
       const int row = 8 * p + (lane >> 3);
       return (unsigned)((row * K + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
     }
-    return (unsigned)(((2 * p + (lane >> 5)) * R + 4 * (lane & 31)) * 4);
+    const int krow = 2 * p + (lane >> 5);
+    const int chunk = lay == MX ? ((lane & 31) ^ (8 * ((krow >> 2) & 1))) : (lane & 31);
+    return (unsigned)((krow * R + 4 * chunk) * 4);
   };
-  constexpr int A_STEP = AL == KC ? 1024 : MC_PIECE, B_STEP = BL == KC ? 1024 : MC_PIECE;
+  constexpr int A_STEP = AL == MC ? MC_PIECE : 1024, B_STEP = BL == MC ? MC_PIECE : 1024;
   unsigned voffA[4], voffB[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -141,6 +143,9 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
   f32x2 amq[2][4], bmq[2][4];
   const int a_kc_row[2] = {wm * 64 + li, wm * 64 + 32 + li}, b_kc_row[2] = {wn * 64 + li, wn * 64 + 32 + li};
   const int a_mc_base = lh * 2 * MC_PIECE + (wm * 64 + li) * 4, b_mc_base = lh * 2 * MC_PIECE + (wn * 64 + li) * 4;   // bytes
+  f32x2 axq[2][2][2], bxq[2][2][2];          // MX: [set][column group][j pair] = k rows 2h, 2h + 1 of one column
+  const int a_mx_base[2] = {lh * 2048 + ((wm * 64 + li) ^ (32 * lh)) * 4, lh * 2048 + ((wm * 64 + 32 + li) ^ (32 * lh)) * 4};
+  const int b_mx_base[2] = {lh * 2048 + ((wn * 64 + li) ^ (32 * lh)) * 4, lh * 2048 + ((wn * 64 + 32 + li) ^ (32 * lh)) * 4};
   constexpr int NRA = AL == KC ? 2 : 4, NRB = BL == KC ? 2 : 4, NR = NRA + NRB;
   auto read_one = [&](int st, int u, int set, int idx) {            // idx-th fragment read of chunk u (A's first)
     const unsigned char* As = smem + st * STAGE;
@@ -148,6 +153,9 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
     if (idx < NRA) {
       if constexpr (AL == KC) {
         akq[set][idx] = *reinterpret_cast<const f32x4*>(As + a_kc_row[idx] * 128 + 16 * ((2 * u + lh) ^ ((a_kc_row[idx] >> 1) & 7)));
+      } else if constexpr (AL == MX) {
+        const float* p = reinterpret_cast<const float*>(As + a_mx_base[idx >> 1] + u * 4096 + (idx & 1) * 1024);
+        axq[set][idx >> 1][idx & 1] = f32x2{p[0], p[128]};
       } else {
         const float* p = reinterpret_cast<const float*>(As + a_mc_base + (4 * u + (idx >> 1)) * MC_PIECE + (idx & 1) * 512);
         amq[set][idx] = f32x2{p[0], p[32]};
@@ -156,6 +164,9 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
       const int i = idx - NRA;
       if constexpr (BL == KC) {
         bkq[set][i] = *reinterpret_cast<const f32x4*>(Bs + b_kc_row[i] * 128 + 16 * ((2 * u + lh) ^ ((b_kc_row[i] >> 1) & 7)));
+      } else if constexpr (BL == MX) {
+        const float* p = reinterpret_cast<const float*>(Bs + b_mx_base[i >> 1] + u * 4096 + (i & 1) * 1024);
+        bxq[set][i >> 1][i & 1] = f32x2{p[0], p[128]};
       } else {
         const float* p = reinterpret_cast<const float*>(Bs + b_mc_base + (4 * u + (i >> 1)) * MC_PIECE + (i & 1) * 512);
         bmq[set][i] = f32x2{p[0], p[32]};
@@ -167,8 +178,9 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(AL == KC ? akq[set][a][j] : amq[set][j][a],
-                                                         BL == KC ? bkq[set][b][j] : bmq[set][j][b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(AL == KC ? akq[set][a][j] : AL == MX ? axq[set][a][j >> 1][j & 1] : amq[set][j][a],
+                                                         BL == KC ? bkq[set][b][j] : BL == MX ? bxq[set][b][j >> 1][j & 1] : bmq[set][j][b],
+                                                         acc[a][b], 0, 0, 0);
   };
   // the reads of chunk (st, u) spread over the four MFMA quads of the chunk before it: quad q issues reads q * NR / 4 ...
   auto reads_of_quad = [&](int st, int u, int set, int q) {
@@ -266,7 +278,31 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
   unsigned long long t1 = 0, r1 = 0;
   if (STAMPS) { t1 = stamp(); r1 = realtime(); }
 
-  // ---- epilogue ----
+  // ---- epilogue ----   DM 2: through LDS, 16-byte stores (a wave's 32 x 64 half tile at a time, rows 68 floats apart);
+  //                        DM 3: no stores at all (ablation)
+  if constexpr (EPI == 2) {
+    __syncthreads();                                   // every wave is done with the operand tiles
+    float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) stage[(8 * (v >> 2) + 4 * lh + (v & 3)) * 68 + b * 32 + li] = acc[a][b][v];
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own writes have landed
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = (lane >> 4) + 4 * i, c4 = lane & 15;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + r * 68 + 4 * c4);
+        *reinterpret_cast<f32x4*>(C + (size_t)(m0 + wm * 64 + a * 32 + r) * N + n0 + wn * 64 + 4 * c4) = v4;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if constexpr (EPI == 3) {       // one store per lane: the accumulators stay live, nothing else is written
+    C[(size_t)(m0 + wm * 64 + li) * N + n0 + wn * 64 + lh] = acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15];
+  } else {
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -277,6 +313,7 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
         const int col = n0 + wn * 64 + b * 32 + li;
         C[(size_t)row * N + col] = acc[a][b][v];
       }
+  }
   if (STAMPS) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long r2 = realtime();
@@ -290,10 +327,10 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
 struct Problem { int M, N, K; const char* what; };
 struct Bufs { const float *A, *At, *B, *Bt; float* C; unsigned long long* st; const std::vector<float>*hA, *hB; };
 
-template <int NS, int AL, int BL, int DM, int ABL, bool STAMPS, int MINB>
+template <int NS, int AL, int BL, int DM, int ABL, bool STAMPS, int MINB, int EPI = 0>
 static void run(const char* name, const Problem& pr, const Bufs& bf) {
   const size_t lds = (size_t)NS * (tile_bytes(AL) + tile_bytes(BL));
-  auto kern = g4<NS, AL, BL, DM, ABL, STAMPS, MINB>;
+  auto kern = g4<NS, AL, BL, DM, ABL, STAMPS, MINB, EPI>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (pr.M / 128) * (pr.N / 128);
   const float* Ap = AL == KC ? bf.A : bf.At;
@@ -304,7 +341,9 @@ static void run(const char* name, const Problem& pr, const Bufs& bf) {
   CK(hipDeviceSynchronize());
   const int reps = 20;
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, Ap, Bp, bf.C, pr.M, pr.N, pr.K, bf.st);
+  // (stamped launches write their stamps to slices of their own: the gaps between consecutive launches can be read off)
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, Ap, Bp, bf.C, pr.M, pr.N, pr.K, bf.st + (STAMPS ? (size_t)i * grid * 32 : 0));
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -345,6 +384,20 @@ static void run(const char* name, const Problem& pr, const Bufs& bf) {
     auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     auto mx = [](std::vector<double> v) { return *std::max_element(v.begin(), v.end()); };
     const double nk = pr.K / 32.0;
+    {
+      std::vector<unsigned long long> all((size_t)reps * grid * 32);
+      CK(hipMemcpy(all.data(), bf.st, all.size() * 8, hipMemcpyDeviceToHost));
+      double gap = 0, span = 0;
+      unsigned long long prev_end = 0;
+      for (int i = 0; i < reps; ++i) {
+        unsigned long long f = ~0ull, l = 0;
+        for (int w = 0; w < grid * 4; ++w) { const unsigned long long* o = &all[((size_t)i * grid * 4 + w) * 8]; f = std::min(f, o[4]); l = std::max(l, o[7]); }
+        span += (l - f) * 0.01;
+        if (i) gap += (double)(long long)(f - prev_end) * 0.01;
+        prev_end = l;
+      }
+      printf("\n      20 launches: first wave in -> last wave out %.1f us on average, last wave out -> next launch's first wave in %.1f us", span / reps, gap / (reps - 1));
+    }
     printf("\n      per k-tile %.0f cyc (dma wait %.0f, barrier %.0f), clock %.2f GHz | us: kernel span %.1f, wave start med %.1f max %.1f, prologue med %.1f, loop med %.1f max %.1f, epilogue med %.1f max %.1f",
            tl / (grid * 4) / nk, tw / (grid * 4) / nk, tb / (grid * 4) / nk, tl / tr * 0.1, (last - first) * 0.01, med(start), mx(start),
            med(pro), med(loop), mx(loop), med(epi), mx(epi));
@@ -367,22 +420,28 @@ int main() {
     float *dA, *dAt, *dB, *dBt, *dC;
     unsigned long long* dst;
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dAt, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dBt, hB.size() * 4));
-    CK(hipMalloc(&dC, (size_t)pr.M * pr.N * 4)); CK(hipMalloc(&dst, (size_t)4096 * 32 * 8));
+    CK(hipMalloc(&dC, (size_t)pr.M * pr.N * 4)); CK(hipMalloc(&dst, (size_t)20 * 512 * 32 * 8));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dAt, hAt.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dBt, hBt.data(), hBt.size() * 4, hipMemcpyHostToDevice));
     const Bufs bf{dA, dAt, dB, dBt, dC, dst, &hA, &hB};
     //  NS  AL  BL  DM ABL STAMPS MINB
+    if (getenv("G4_CLOCK")) {
+      // the clock question: the same loop without DMA, fragment reads as ds_read_b128 (KC) or ds_read2_b32 (MC), in alternating order
+      for (int rep = 0; rep < 2; ++rep) {
+        run<2, KC, KC, 0, 0, false, 2>("2st KC/KC, dword stores", pr, bf);
+        run<2, KC, KC, 0, 0, true, 2>("2st KC/KC, dword stores, stamps", pr, bf);
+        run<2, KC, KC, 0, 0, true, 2, 2>("2st KC/KC, 16-byte stores, stamps", pr, bf);
+        run<2, KC, KC, 0, 4, true, 2, 3>("2st KC/KC, one store per lane, stamps", pr, bf);
+      }
+    } else {
     run<2, KC, KC, 0, 0, false, 2>("2st KC/KC (bwd-data form)", pr, bf);
     run<2, KC, MC, 0, 0, false, 2>("2st KC/MC (forward form)", pr, bf);
     run<2, MC, MC, 0, 0, false, 2>("2st MC/MC (bwd-filter form)", pr, bf);
     run<3, KC, KC, 0, 0, false, 1>("3st KC/KC 1 block/CU", pr, bf);
     run<3, KC, MC, 0, 0, false, 1>("3st KC/MC 1 block/CU", pr, bf);
     run<3, MC, MC, 0, 0, false, 1>("3st MC/MC 1 block/CU", pr, bf);
-    run<2, KC, KC, 1, 0, false, 2>("2st KC/KC, one M0 per four pieces", pr, bf);
-    run<2, MC, MC, 1, 0, false, 2>("2st MC/MC, one M0 per four pieces", pr, bf);
-    run<3, KC, MC, 1, 0, false, 1>("3st KC/MC, one M0 per four pieces", pr, bf);
     run<2, KC, KC, 0, 0, true, 2>("2st KC/KC stamps", pr, bf);
     run<2, MC, MC, 0, 0, true, 2>("2st MC/MC stamps", pr, bf);
     run<3, KC, KC, 0, 0, true, 1>("3st KC/KC stamps", pr, bf);
@@ -391,6 +450,7 @@ int main() {
     run<3, KC, KC, 0, 2, true, 1>("3st KC/KC stamps, no frag reads", pr, bf);
     run<3, KC, KC, 0, 3, true, 1>("3st KC/KC stamps, MFMAs + barrier only", pr, bf);
     run<3, MC, MC, 0, 1, true, 1>("3st MC/MC stamps, no DMA", pr, bf);
+    }
     CK(hipFree(dA)); CK(hipFree(dAt)); CK(hipFree(dB)); CK(hipFree(dBt)); CK(hipFree(dC)); CK(hipFree(dst));
   }
   return 0;

@@ -17,7 +17,8 @@ name, mode = sys.argv[1], sys.argv[2]
 if len(sys.argv) > 3 and int(sys.argv[3]) >= 0:
     os.environ['A3D_FORCE_CFG'] = sys.argv[3]
     os.environ['A3D_FORCE_SPLITK'] = sys.argv[4] if len(sys.argv) > 4 else '1'
-_, h, w, c, k, ks, st, pad = next(l for l in LAYERS if l[0] == name)
+EXTRA = [('gemm', 25, 40, 2400, 256, 1, 1, 'VALID'), ('gemmT', 25, 40, 256, 2400, 1, 1, 'VALID')]      # plain GEMMs as 1x1 convs (tools/gen2_ab.py)
+_, h, w, c, k, ks, st, pad = next(l for l in LAYERS + EXTRA if l[0] == name)
 d = ops.conv_desc(B, h, w, c, k, ks, ks, st, pad)
 x = torch.randn((B, h, w, c), device='cuda')
 wt = torch.randn((ks, ks, c, k), device='cuda') * 0.01
@@ -55,4 +56,9 @@ print(f'  prologue {a[:, 8].mean():.0f} cyc (min {a[:, 8].min():.0f} max {a[:, 8
       f'epilogue {(t_exit - t_end).mean():.0f} (min {(t_exit - t_end).min()} max {(t_exit - t_end).max()})')
 print(f'  kernel span (first entry -> last exit) {t_exit.max() - t0} cyc; entries spread over {t_entry.max() - t0} cyc; '
       f'exit times: 10% {np.percentile(t_exit - t0, 10):.0f} 50% {np.percentile(t_exit - t0, 50):.0f} 90% {np.percentile(t_exit - t0, 90):.0f}')
+rt = a[:, 12]
+ok = rt > 0
+if ok.any():
+    print(f'  clock held during the loops: {np.mean(a[ok, 5] / rt[ok]) * 0.1:.3f} GHz (loop cycles / 100 MHz ticks; min {np.min(a[ok, 5] / rt[ok]) * 0.1:.3f} max {np.max(a[ok, 5] / rt[ok]) * 0.1:.3f}); '
+          f'first loop start -> last loop end {(raw[ok, 14].astype(np.int64).max() - raw[ok, 13].astype(np.int64).min()) * 0.01:.1f} us')
 print(f'  of P: issue of the A tile loads {np.mean(a[:, 7] / nkt):.0f} cyc/tile (incl. the prologue tile)')
