@@ -238,7 +238,7 @@ class Session:
         arr = (_lib.TimingRecord * cap)()
         n = lib.a3d_timing_collect(arr, cap)
         recs = [{'mode': ('fwd', 'bwd_data', 'bwd_filter')[r.mode], 'tile': f'{r.bm}x{r.bn}', 'waves': r.nwaves,
-                 'precision': ('fp32', 'bf16x3', 'bf16')[r.prec], 'kernel': ('igemm', 'igemm_glds', 'conv3_fwd', 'igemm_ring', 'fewch_bwdf')[r.lds_dma], 'splitk': r.splitk, 'm': r.m, 'n': r.n, 'k': r.k,
+                 'precision': ('fp32', 'bf16x3', 'bf16')[r.prec], 'kernel': ('igemm', 'igemm_glds', 'conv3_fwd', 'igemm_ring', 'fewch_bwdf', 'igemm2')[r.lds_dma], 'splitk': r.splitk, 'm': r.m, 'n': r.n, 'k': r.k,
                  'ms': round(r.ms, 4), 'tflops': round(r.flops / max(r.ms, 1e-6) / 1e9, 1)} for r in arr[:n]]
         with open(os.path.join(self.dir, f'trace-{step}.json'), 'w') as f:
             json.dump({'global_step': step, 'launches': recs}, f)

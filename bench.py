@@ -67,6 +67,8 @@ def collect_timing(lib):
 
 
 def kernel_name(r):
+    if r.lds_dma == 5:
+        return f'igemm2_kernel<{r.mode}>'
     if r.lds_dma == 4:
         return f'fewch16_bwdf_kernel<{r.bn // 32}>' if r.prec else f'fewch_bwdf_kernel<{r.bn // 32}>'
     if r.lds_dma == 3:

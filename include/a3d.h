@@ -386,7 +386,8 @@ typedef struct a3d_timing_record {
   int32_t lds_dma;     /* 1: igemm_glds_kernel<mode,bm,bn,waves_m,nwaves> (tiles staged by global_load_lds);
                         * 2: conv3_fwd_kernel<bm/32,bn/32,pool> (few-channel layers, one wave per bm x bn tile, no LDS);
                         * 3: igemm_ring_kernel<mode,bm,bn> (bf16-stored operands, LDS-DMA);
-                        * 4: fewch_bwdf_kernel<bn/32> (few-channel filter gradient from LDS-staged rows; ms includes its slab reduction) */
+                        * 4: fewch_bwdf_kernel<bn/32> (few-channel filter gradient from LDS-staged rows; ms includes its slab reduction);
+                        * 5: igemm2_kernel<mode> (second-generation fp32 kernel, LDS-DMA staging, 128 x 128 tiles: pinned plans only) */
   int32_t splitk;
   int32_t m, n, k;     /* GEMM extents of the launch */
   float ms;            /* duration of the igemm kernel alone (split-K reduction excluded) */

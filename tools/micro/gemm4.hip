@@ -324,6 +324,265 @@ __global__ __launch_bounds__(256, MINB) void g4(const float* __restrict__ A, con
   }
 }
 
+// ---- the same KC / KC loop on v_mfma_f32_16x16x4_f32 (sixteen 16 x 16 accumulators per wave, k-steps of 4): the same FLOPs
+//      per cycle and the same LDS bytes, half the accumulator-register traffic per FLOP — does the chip hold a higher clock? ----
+template <bool STAMPS>
+__global__ __launch_bounds__(256, 2) void g5(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                             int M, int N, int K, unsigned long long* stamps) {
+  constexpr int BM = 128, BN = 128, BK = 32, STAGE = 2 * 128 * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, g = lane >> 4;
+  const int tiles_n = N / BN;
+  const unsigned bid = remap_xcd(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = K / BK;
+  unsigned long long rt_entry = 0;
+  if (STAMPS) rt_entry = realtime();
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32x4 rsA = rsrc_of(A + (size_t)m0 * K, (unsigned long long)128 * K * 4), rsB = rsrc_of(B + (size_t)n0 * K, (unsigned long long)128 * K * 4);
+  unsigned voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * (4 * j + wave) + (lane >> 3);
+    voff[j] = (unsigned)((row * K + 4 * ((lane & 7) ^ ((row >> 1) & 7))) * 4);
+  }
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  auto dma_a = [&](int kt, int st, int j) { dma16(rsA, voff[j], (unsigned)(kt * BK * 4), lds0 + (unsigned)(st * STAGE + (4 * j + wave) * 1024)); };
+  auto dma_b = [&](int kt, int st, int j) { dma16(rsB, voff[j], (unsigned)(kt * BK * 4), lds0 + (unsigned)(st * STAGE + 16384 + (4 * j + wave) * 1024)); };
+  // fragments: f32x4 = k 16 u + 4 g + (0..3) of row rg * 16 + l16 (u = 0, 1: the two halves of a k-tile)
+  f32x4 af[2][4], bf[2][4];
+  int a_row[4], b_row[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a_row[r] = wm * 64 + r * 16 + l16; b_row[r] = wn * 64 + r * 16 + l16; }
+  auto read_one = [&](int st, int u, int set, int idx) {
+    const unsigned char* As = smem + st * STAGE;
+    if (idx < 4) af[set][idx] = *reinterpret_cast<const f32x4*>(As + a_row[idx] * 128 + 16 * ((4 * u + g) ^ ((a_row[idx] >> 1) & 7)));
+    else bf[set][idx - 4] = *reinterpret_cast<const f32x4*>(As + 16384 + b_row[idx - 4] * 128 + 16 * ((4 * u + g) ^ ((b_row[idx - 4] >> 1) & 7)));
+  };
+  auto mfma_ja = [&](int set, int j, int a) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[set][a][j], bf[set][b][j], acc[a][b], 0, 0, 0);
+  };
+  unsigned long long t_wait = 0, t_bar = 0, t_loop0 = 0, r0 = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dma_a(0, 0, j); dma_b(0, 0, j); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int idx = 0; idx < 8; ++idx) read_one(0, 0, 0, idx);
+  if (STAMPS) { t_loop0 = stamp(); r0 = realtime(); }
+  auto tile_body = [&](int it, auto st_c) {
+    constexpr int ST = decltype(st_c)::value;
+    FENCE();
+    // half 0 (k 0..15): sixteen groups of four MFMAs; the eight reads of half 1 and the eight requests of the next tile between them
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        mfma_ja(0, j, a);
+        FENCE();
+        const int s = j * 4 + a;
+        if (s < 8) read_one(ST, 1, 1, s);
+        else if (s < 12) dma_a(it + 1, ST ^ 1, s - 8);
+        else dma_b(it + 1, ST ^ 1, s - 12);
+        FENCE();
+      }
+    // half 1: eight groups, the barrier, the first reads of the next tile, eight groups
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) mfma_ja(1, j, a);
+    FENCE();
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (STAMPS) s0 = stamp();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAMPS) s1 = stamp();
+    __builtin_amdgcn_s_barrier();
+    if (STAMPS) { s2 = stamp(); t_wait += s1 - s0; t_bar += s2 - s1; }
+    FENCE();
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) read_one(ST ^ 1, 0, 0, idx);
+    FENCE();
+#pragma unroll
+    for (int j = 2; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) mfma_ja(1, j, a);
+    FENCE();
+  };
+  int it = 0;
+  for (; it + 1 < nkt; it += 2) {
+    tile_body(it, std::integral_constant<int, 0>{});
+    tile_body(it + 1, std::integral_constant<int, 1>{});
+  }
+  if (it < nkt) tile_body(it, std::integral_constant<int, 0>{});
+  unsigned long long t1 = 0, r1 = 0;
+  if (STAMPS) { t1 = stamp(); r1 = realtime(); }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        C[(size_t)(m0 + wm * 64 + a * 16 + 4 * g + v) * N + n0 + wn * 64 + b * 16 + l16] = acc[a][b][v];
+  if (STAMPS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long r2 = realtime();
+    if (lane == 0) {
+      unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+      o[0] = t1 - t_loop0; o[1] = t_wait; o[2] = t_bar; o[3] = r1 - r0; o[4] = rt_entry; o[5] = r0; o[6] = r1; o[7] = r2;
+    }
+  }
+}
+
+// ---- KC / KC fragments for operands that are NOT k-contiguous in memory (the bwd-filter case: x and dz are [pixel][channel]):
+//      register staging with a free 4 x 4 transpose.  A thread loads four k rows x four columns (four 16-byte loads of the
+//      [K][rows] operand), and writes four ds_write_b128: row (4 mq + j) gets its four consecutive k.  Same LDS image and the same
+//      fragment reads as the LDS-DMA KC tiles. ----
+template <bool STAMPS>
+__global__ __launch_bounds__(256, 2) void g6(const float* __restrict__ At, const float* __restrict__ Bt, float* __restrict__ C,
+                                             int M, int N, int K, unsigned long long* stamps) {
+  constexpr int BM = 128, BN = 128, BK = 32, STAGE = 2 * 128 * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int tiles_n = N / BN;
+  const unsigned bid = remap_xcd(blockIdx.x, gridDim.x);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = K / BK;
+  unsigned long long rt_entry = 0;
+  if (STAMPS) rt_entry = realtime();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+  // staging: thread -> (k quad kq = tid / 32, column quad mq = tid % 32)
+  const int kq = tid >> 5, mq = tid & 31;
+  const __amdgpu_buffer_rsrc_t brA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(At + m0), 0, (int)(((long long)K * M - m0) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t brB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bt + n0), 0, (int)(((long long)K * N - n0) * 4), 0x00020000);
+  unsigned voffA[4], voffB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    voffA[i] = (unsigned)(((4 * kq + i) * M + 4 * mq) * 4);
+    voffB[i] = (unsigned)(((4 * kq + i) * N + 4 * mq) * 4);
+  }
+  unsigned wr[4];                    // LDS byte offset of row 4 mq + j, chunk kq (swizzled), inside an operand tile
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int row = 4 * mq + j; wr[j] = (unsigned)(row * 128 + 16 * (kq ^ ((row >> 1) & 7))); }
+  f32x4 ra[4], rb[4];
+  auto load_regs = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brA, (int)voffA[i], kt * BK * M * 4, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brB, (int)voffB[i], kt * BK * N * 4, 0));
+  };
+  auto store_one = [&](int st, int j, bool isb) {
+    const f32x4 (&r)[4] = isb ? rb : ra;
+    const f32x4 w = {r[0][j], r[1][j], r[2][j], r[3][j]};
+    *reinterpret_cast<f32x4*>(smem + st * STAGE + (isb ? 16384 : 0) + wr[j]) = w;
+  };
+  f32x4 af[2][2], bf[2][2];
+  const int a_row[2] = {wm * 64 + li, wm * 64 + 32 + li}, b_row[2] = {wn * 64 + li, wn * 64 + 32 + li};
+  auto read_one = [&](int st, int u, int set, int idx) {
+    const unsigned char* As = smem + st * STAGE;
+    if (idx < 2) af[set][idx] = *reinterpret_cast<const f32x4*>(As + a_row[idx] * 128 + 16 * ((2 * u + lh) ^ ((a_row[idx] >> 1) & 7)));
+    else bf[set][idx - 2] = *reinterpret_cast<const f32x4*>(As + 16384 + b_row[idx - 2] * 128 + 16 * ((2 * u + lh) ^ ((b_row[idx - 2] >> 1) & 7)));
+  };
+  auto mfma_j = [&](int set, int j) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][a][j], bf[set][b][j], acc[a][b], 0, 0, 0);
+  };
+  unsigned long long t_wait = 0, t_bar = 0, t_loop0 = 0, r0 = 0;
+  load_regs(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { store_one(0, j, false); store_one(0, j, true); }
+  __syncthreads();
+#pragma unroll
+  for (int idx = 0; idx < 4; ++idx) read_one(0, 0, 0, idx);
+  if (STAMPS) { t_loop0 = stamp(); r0 = realtime(); }
+  auto tile_body = [&](int it, auto st_c) {
+    constexpr int ST = decltype(st_c)::value;
+    FENCE();
+    load_regs(it + 1 < nkt ? it + 1 : it);        // (the last iteration re-reads its own tile: never used)
+    FENCE();
+    // chunks 0, 1: MFMAs and the next chunk's fragment reads
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mfma_j(u & 1, q);
+        FENCE();
+        read_one(ST, u + 1, (u + 1) & 1, q);
+        FENCE();
+      }
+    // chunk 2: MFMAs, chunk 3's reads and the first half of the transposed LDS writes of tile it + 1 (loads issued 32 MFMAs ago)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mfma_j(0, q);
+      FENCE();
+      read_one(ST, 3, 1, q);
+      store_one(ST ^ 1, q, false);
+      FENCE();
+    }
+    // chunk 3: the other half of the writes, the barrier, the next tile's first fragments
+    mfma_j(1, 0);
+    FENCE();
+    store_one(ST ^ 1, 0, true); store_one(ST ^ 1, 1, true);
+    FENCE();
+    mfma_j(1, 1);
+    FENCE();
+    store_one(ST ^ 1, 2, true); store_one(ST ^ 1, 3, true);
+    FENCE();
+    unsigned long long s0 = 0, s2 = 0;
+    if (STAMPS) s0 = stamp();
+    __syncthreads();
+    if (STAMPS) { s2 = stamp(); t_bar += s2 - s0; }
+    FENCE();
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) read_one(ST ^ 1, 0, 0, idx);
+    FENCE();
+    mfma_j(1, 2);
+    mfma_j(1, 3);
+    FENCE();
+  };
+  int it = 0;
+  for (; it + 1 < nkt; it += 2) {
+    tile_body(it, std::integral_constant<int, 0>{});
+    tile_body(it + 1, std::integral_constant<int, 1>{});
+  }
+  if (it < nkt) tile_body(it, std::integral_constant<int, 0>{});
+  unsigned long long t1 = 0, r1 = 0;
+  if (STAMPS) { t1 = stamp(); r1 = realtime(); }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        C[(size_t)(m0 + wm * 64 + a * 32 + 8 * (v >> 2) + 4 * lh + (v & 3)) * N + n0 + wn * 64 + b * 32 + li] = acc[a][b][v];
+  if (STAMPS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long r2 = realtime();
+    if (lane == 0) {
+      unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+      o[0] = t1 - t_loop0; o[1] = t_wait; o[2] = t_bar; o[3] = r1 - r0; o[4] = rt_entry; o[5] = r0; o[6] = r1; o[7] = r2;
+    }
+  }
+}
+
 struct Problem { int M, N, K; const char* what; };
 struct Bufs { const float *A, *At, *B, *Bt; float* C; unsigned long long* st; const std::vector<float>*hA, *hB; };
 
@@ -406,6 +665,50 @@ static void run(const char* name, const Problem& pr, const Bufs& bf) {
   fflush(stdout);
 }
 
+template <bool STAMPS, int WHICH = 5>
+static void run5(const char* name, const Problem& pr, const Bufs& bf_in) {
+  Bufs bf = bf_in;
+  if (WHICH == 6) { bf.A = bf_in.At; bf.B = bf_in.Bt; }          // g6 takes the [K][rows] operands
+  const size_t lds = 2 * 2 * 128 * 128;
+  auto kern = WHICH == 6 ? g6<STAMPS> : g5<STAMPS>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (pr.M / 128) * (pr.N / 128);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, bf.A, bf.B, bf.C, pr.M, pr.N, pr.K, bf.st);
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, bf.A, bf.B, bf.C, pr.M, pr.N, pr.K, bf.st);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, tf = 2.0 * pr.M * pr.N * pr.K / (us * 1e-6) / 1e12;
+  std::vector<float> hC((size_t)pr.M * pr.N);
+  CK(hipMemcpy(hC.data(), bf.C, hC.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  unsigned s = 12345;
+  for (int t = 0; t < 3000; ++t) {
+    s = s * 1664525u + 1013904223u; const int m = (s >> 8) % pr.M;
+    s = s * 1664525u + 1013904223u; const int n = (s >> 8) % pr.N;
+    double ref = 0;
+    for (int k = 0; k < pr.K; ++k) ref += (double)(*bf.hA)[(size_t)m * pr.K + k] * (*bf.hB)[(size_t)n * pr.K + k];
+    maxerr = std::max(maxerr, fabs(ref - hC[(size_t)m * pr.N + n]) / (fabs(ref) + 1.0));
+  }
+  printf("%-46s %-14s %8.1f us %6.1f TF (%.3f) err %.1e %s", name, pr.what, us, tf, tf / 157.3, maxerr, maxerr < 1e-4 ? "ok" : "WRONG");
+  if (STAMPS) {
+    std::vector<unsigned long long> h((size_t)grid * 32);
+    CK(hipMemcpy(h.data(), bf.st, h.size() * 8, hipMemcpyDeviceToHost));
+    double tl = 0, tw = 0, tb = 0, tr = 0;
+    for (int i = 0; i < grid * 4; ++i) { const unsigned long long* o = &h[(size_t)i * 8]; tl += o[0]; tw += o[1]; tb += o[2]; tr += o[3]; }
+    printf("\n      per k-tile %.0f cyc (dma wait %.0f, barrier %.0f), clock %.2f GHz", tl / (grid * 4) / (pr.K / 32.0), tw / (grid * 4) / (pr.K / 32.0),
+           tb / (grid * 4) / (pr.K / 32.0), tl / tr * 0.1);
+  }
+  printf("\n");
+  fflush(stdout);
+}
+
 int main() {
   const Problem probs[] = {{32000, 256, 2400, "conv2d_1-like"}, {7424, 384, 3456, "conv2d_3-like"}};
   for (const Problem& pr : probs) {
@@ -429,11 +732,11 @@ int main() {
     //  NS  AL  BL  DM ABL STAMPS MINB
     if (getenv("G4_CLOCK")) {
       // the clock question: the same loop without DMA, fragment reads as ds_read_b128 (KC) or ds_read2_b32 (MC), in alternating order
-      for (int rep = 0; rep < 2; ++rep) {
-        run<2, KC, KC, 0, 0, false, 2>("2st KC/KC, dword stores", pr, bf);
-        run<2, KC, KC, 0, 0, true, 2>("2st KC/KC, dword stores, stamps", pr, bf);
-        run<2, KC, KC, 0, 0, true, 2, 2>("2st KC/KC, 16-byte stores, stamps", pr, bf);
-        run<2, KC, KC, 0, 4, true, 2, 3>("2st KC/KC, one store per lane, stamps", pr, bf);
+      for (int rep = 0; rep < 3; ++rep) {
+        run<2, KC, KC, 0, 0, false, 2>("2st KC/KC, LDS-DMA", pr, bf);
+        run<2, MX, MX, 0, 0, false, 2>("2st MX/MX, LDS-DMA (operands as stored)", pr, bf);
+        run5<false, 6>("2st KC/KC, registers + transposed writes", pr, bf);
+        run5<true, 6>("2st KC/KC, registers + transposed writes, stamps", pr, bf);
       }
     } else {
     run<2, KC, KC, 0, 0, false, 2>("2st KC/KC (bwd-data form)", pr, bf);
