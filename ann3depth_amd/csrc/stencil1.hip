@@ -392,6 +392,114 @@ __global__ __launch_bounds__(256, 2) void stencil1_bwd_kernel(const Stencil1BwdP
   }
 }
 
+
+// ---- forward on the matrix cores through a taps-as-columns product (round 6) ----
+// y[p] = b + sum_{r,s} ( sum_c x[p + (r,s)][c] w[r][s][c] ): the inner sum over the 64 channels of ONE input pixel for all 25
+// taps is a [pixels][64] x [64][25] product — the input as it lies in memory times a 6.4-KB matrix that lives in registers —
+// and the outer sum then adds 25 numbers per output pixel out of LDS.  A block owns a band of RB output rows of one image: it
+// reads the RB + 4 input rows ONCE with 16-byte loads straight into MFMA A fragments (lane = pixel of a 32-pixel piece of a
+// row, its 64 channels in eight float4: no LDS staging of x, no cross-lane reduction: the lane-per-channel kernel above spends a
+// quarter of its wave cycles in ds_bpermute and reads every pixel three times through the L1), leaves Z[pixel][tap] in LDS
+// (25 floats per pixel) and sums, skipping the tap columns that fall outside a row (SAME padding).  Input rows outside the
+// image are loaded as zeros (out-of-range buffer offsets).  Bands of one image are neighbours on one XCD (block remap), so the
+// four halo rows two bands share come from that L2.
+constexpr int kS1mRB = 8;                           // output rows per block
+constexpr int kS1mZP = 25;                          // floats per pixel of Z (odd: consecutive pixels fall into different banks)
+struct Stencil1MfmaParams {
+  const float* x; const float* w; const float* bias; float* y;
+  int n, h, w_in, ho, wo, pad_t, pad_l, ldy, act, bands, tpr;      // tpr: 32-pixel pieces per input row
+};
+__global__ __launch_bounds__(256, 1) void stencil1_fwd_mfma_kernel(const Stencil1MfmaParams p) {
+  extern __shared__ __attribute__((aligned(16))) float Zs[];        // [(RB + 4) * w_in pixels][25], the band's pixels in memory order
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int img = (int)bid / p.bands, band = (int)bid - img * p.bands;
+  const int oy0 = band * kS1mRB;
+  const int rows_out = min(kS1mRB, p.ho - oy0);
+  const int iy0 = oy0 - p.pad_t, nrows = rows_out + 4;
+  // B fragments: lane (tap li, half lh) holds w[tap][8 u + 4 lh .. + 3] for the eight channel chunks u
+  f32x4 wf[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    wf[u] = li < 25 ? *reinterpret_cast<const f32x4*>(p.w + li * 64 + 8 * u + 4 * lh) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // The band's input rows are ONE contiguous run of nrows * w_in pixels of 256 bytes (rows above / below the image: a run that
+  // starts before / ends after the image's pixels — those pixels are out of range for the descriptor of THIS image and load as
+  // zeros).  Pieces of 32 pixels of that run, no padding at row ends: 28 pieces for 12 rows of 74 instead of 36.
+  const long long img_px = (long long)img * p.h * p.w_in;
+  const int px_lo = max(0, -iy0) * p.w_in;                                     // first band pixel that exists
+  const int px_hi = (min(p.h, iy0 + nrows) - iy0) * p.w_in;                    // one past the last
+  const int npx = nrows * p.w_in, ntiles = (npx + 31) / 32;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (img_px + (long long)iy0 * p.w_in) * 64, 0x7fffffffull);      // base may lie before the image: offsets below px_lo are never used
+  auto tile_off = [&](int t) -> uint32_t {
+    const int px = t * 32 + li;
+    return (t < ntiles && px >= px_lo && px < px_hi) ? (uint32_t)((px * 64 + 4 * lh) * 4) : kOOB;
+  };
+  f32x4 af[2][8];
+  auto fetch = [&](int t, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    const uint32_t off = tile_off(t);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 32 * u, 0);
+      af[set][u] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto tile = [&](int t, auto set_c, auto next_c) {
+    constexpr int set = decltype(set_c)::value;
+    fetch(t + 4, next_c);                            // the wave's next piece is in flight while this one is multiplied
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][u][j], wf[u][j], acc, 0, 0, 0);
+    if (li < 25) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int px = t * 32 + 8 * (v >> 2) + 4 * lh + (v & 3);
+        if (px < npx) Zs[px * kS1mZP + li] = acc[v];
+      }
+    }
+  };
+  fetch(wave, std::integral_constant<int, 0>{});
+  for (int t = wave; t < ntiles; t += 8) {
+    tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    if (t + 4 < ntiles) tile(t + 4, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  }
+  __syncthreads();
+  const float b = p.bias ? p.bias[0] : 0.f;
+  for (int o = tid; o < rows_out * p.wo; o += 256) {
+    const int oyl = o / p.wo, ox = o - oyl * p.wo;
+    float sum = b;
+#pragma unroll
+    for (int s2 = 0; s2 < 5; ++s2) {
+      const int ix = ox + s2 - p.pad_l;                                        // input column of tap column s2: outside the row = padding
+      if ((unsigned)ix >= (unsigned)p.w_in) continue;
+      const float* z = Zs + (oyl * p.w_in + ix) * kS1mZP + s2;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) sum += z[(r * p.w_in) * kS1mZP + r * 5];
+    }
+    if (p.act == EPI_RELU) sum = fmaxf(sum, 0.f);
+    else if (p.act == EPI_SIGMOID) sum = 1.f / (1.f + expf(-sum));
+    p.y[(((size_t)img * p.ho + oy0 + oyl) * p.wo + ox) * p.ldy] = sum;
+  }
+}
+
+static size_t s1m_lds_bytes(const a3d_conv_desc* d) { return (size_t)(kS1mRB + 4) * d->w * kS1mZP * 4 + 16; }
+// 64 densely packed channels, whole 16-byte pieces, one descriptor over x (31-bit byte offsets), Z of a band in LDS
+static bool stencil1_mfma_applicable(const a3d_conv_desc* d, const float* x, const float* w) {
+  if (!stencil1_applicable(d) || d->c != 64 || d->ldx != 64 || d->precision != A3D_PREC_F32 || d->storage) return false;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return false;
+  if ((double)d->n * d->h * d->w * 64.0 * 4.0 >= 2147483647.0) return false;
+  if (s1m_lds_bytes(d) > 150 * 1024) return false;
+  return tune_int("A3D_STENCIL_MFMA", 1) != 0;
+}
+
 static const int kStencilBlocks = 1024;
 static const int kStencilGroup = 32;
 
@@ -415,6 +523,18 @@ static Stencil1Params make_params(const a3d_conv_desc* d) {
 
 int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int act,
                  hipStream_t st) {
+  if (stencil1_mfma_applicable(d, x, w)) {
+    Stencil1MfmaParams q{};
+    q.x = x; q.w = w; q.bias = bias; q.y = y; q.act = act;
+    q.n = d->n; q.h = d->h; q.w_in = d->w; q.ho = d->ho; q.wo = d->wo; q.pad_t = d->pad_t; q.pad_l = d->pad_l; q.ldy = d->ldy;
+    q.bands = (d->ho + kS1mRB - 1) / kS1mRB;
+    q.tpr = (d->w + 31) / 32;
+    const size_t lds = s1m_lds_bytes(d);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil1_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    clear_stale_error();
+    hipLaunchKernelGGL(stencil1_fwd_mfma_kernel, dim3(d->n * q.bands), dim3(256), lds, st, q);
+    return check_launch("stencil1_fwd_mfma");
+  }
   Stencil1Params p = make_params(d);
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.act = act;
   const int tiles = p.n * ((p.ho + 3) / 4) * p.strips_per_row;      // 4 output rows x 8 columns per wave iteration

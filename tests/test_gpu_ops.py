@@ -43,6 +43,8 @@ CONV_CASES = [
     (2, 21, 30, 64, 1, 5, 1, 'SAME'),        # fine/third: Cout=1 (direct stencil kernels)
     (3, 55, 74, 64, 1, 5, 1, 'SAME'),        # fine/third at full spatial size (74 = 9 strips of 8 + 2)
     (2, 9, 13, 40, 1, 5, 1, 'VALID'),        # stencil path with Cin < 64 and VALID padding
+    (2, 12, 17, 64, 1, 5, 1, 'VALID'),       # 64 channels, VALID: the forward's taps-as-columns product on the matrix cores, a band of 8 + 4 rows cut short
+    (1, 19, 70, 64, 1, 5, 1, 'SAME'),        # ... three bands (8 + 8 + 3 rows), rows of three 32-pixel pieces with 26 idle lanes
     (1, 10, 11, 8, 12, 4, 2, 'SAME'),        # asymmetric SAME padding, stride 2
     (1, 9, 9, 5, 7, 3, 1, 'SAME'),           # Cin, Cout not multiples of 4
     (5, 24, 24, 64, 256, 5, 1, 'VALID'),     # dcnf conv2d_1 kind
