@@ -407,7 +407,7 @@ constexpr int kS1mRB = 8;                           // output rows per block
 constexpr int kS1mZP = 25;                          // floats per pixel of Z (odd: consecutive pixels fall into different banks)
 struct Stencil1MfmaParams {
   const float* x; const float* w; const float* bias; float* y;
-  int n, h, w_in, ho, wo, pad_t, pad_l, ldy, act, bands, tpr;      // tpr: 32-pixel pieces per input row
+  int n, h, w_in, ho, wo, pad_t, pad_l, ldy, act, bands;
 };
 __global__ __launch_bounds__(256, 1) void stencil1_fwd_mfma_kernel(const Stencil1MfmaParams p) {
   extern __shared__ __attribute__((aligned(16))) float Zs[];        // [(RB + 4) * w_in pixels][25], the band's pixels in memory order
@@ -528,7 +528,6 @@ int stencil1_fwd(const a3d_conv_desc* d, const float* x, const float* w, const f
     q.x = x; q.w = w; q.bias = bias; q.y = y; q.act = act;
     q.n = d->n; q.h = d->h; q.w_in = d->w; q.ho = d->ho; q.wo = d->wo; q.pad_t = d->pad_t; q.pad_l = d->pad_l; q.ldy = d->ldy;
     q.bands = (d->ho + kS1mRB - 1) / kS1mRB;
-    q.tpr = (d->w + 31) / 32;
     const size_t lds = s1m_lds_bytes(d);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil1_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     clear_stale_error();
