@@ -201,10 +201,77 @@ struct Stencil1BwdParams {
   int bands, runs_per_row, dwid, group, ngroups, mask, xvec4;
 };
 
+// The end of a backward block: the four waves' filter-gradient sums (red[4][TW], (tap, channel) order) and bias sums become the
+// block's slab, the last-arriving block of a group adds the group's slabs, the last group the groups' — in index order at every
+// level (the same bits on every run); tickets in p.state, which every call leaves zero.
+template <int KS>
+__device__ __forceinline__ void stencil1_bwd_reduce_tail(const Stencil1BwdParams& p, const float* red, const float* dbred, unsigned& last) {
+  constexpr int TW = KS * KS * 64;
+  constexpr int SLAB4 = TW / 4 + 1;
+  // slabs cross CUs (and XCDs) as 16-byte write-through stores, drained before the block's ticket, and are read back with
+  // sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: the last-arriver form)
+  const int nblocks = gridDim.x;
+  const size_t slab_bytes = (size_t)SLAB4 * 16;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slabs, (unsigned long long)nblocks * slab_bytes);
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gslabs, (unsigned long long)p.ngroups * slab_bytes);
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    f32x4 s;
+    if (i4 < TW / 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(red + 4 * i4), b = *reinterpret_cast<const f32x4*>(red + TW + 4 * i4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(red + 2 * TW + 4 * i4), d = *reinterpret_cast<const f32x4*>(red + 3 * TW + 4 * i4);
+      s = (a + b) + (c + d);
+    } else {
+      s = f32x4{(dbred[0] + dbred[1]) + (dbred[2] + dbred[3]), 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rs, (int)(blockIdx.x * slab_bytes + i4 * 16), 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int grp = blockIdx.x / p.group;
+  const int gfirst = grp * p.group, gcount = min(p.group, nblocks - gfirst);
+  if (threadIdx.x == 0) last = atomicInc(&p.state[1 + grp], (unsigned)gcount - 1u) == (unsigned)gcount - 1u;
+  __syncthreads();
+  if (!last) return;
+  auto sum_slabs = [&](const __amdgpu_buffer_rsrc_t r, int firstslab, int count, int i4) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int b0 = 0; b0 < count; b0 += U) {            // eight loads in flight, added in slab order
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, b0 + u < count ? (int)((firstslab + b0 + u) * slab_bytes + i4 * 16) : (int)kOOB, 0, 16);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (b0 + u < count) s += __builtin_bit_cast(f32x4, v[u]);
+    }
+    return s;
+  };
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    const f32x4 s = sum_slabs(rs, gfirst, gcount, i4);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rg, (int)(grp * slab_bytes + i4 * 16), 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicInc(&p.state[0], (unsigned)p.ngroups - 1u) == (unsigned)p.ngroups - 1u;
+  __syncthreads();
+  if (!last) return;
+  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
+    const f32x4 s = sum_slabs(rg, 0, p.ngroups, i4);
+    if (i4 == TW / 4) {
+      if (p.db) p.db[0] = s[0];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * i4 + e, t = i / 64, ch = i % 64;
+        if (ch < p.c) p.dw[t * p.c + ch] = s[e];
+      }
+    }
+  }
+}
+
+
 template <int KS, int RB, bool DX16>
 __global__ __launch_bounds__(256, 2) void stencil1_bwd_kernel(const Stencil1BwdParams p) {
-  constexpr int TW = KS * KS * 64;                   // a slab: TW filter-gradient sums, then db, padded to whole 16-byte pieces
-  constexpr int SLAB4 = TW / 4 + 1;
   constexpr int DROWS = RB + KS - 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* D = smem;                                   // [DROWS][dwid]
@@ -331,65 +398,7 @@ __global__ __launch_bounds__(256, 2) void stencil1_bwd_kernel(const Stencil1BwdP
     if (half == 0) *reinterpret_cast<pk2*>(red + (wv * KS * KS + t) * 64 + 2 * cl) = pk2{a0, a1};
   }
   __syncthreads();
-  // slabs cross CUs (and XCDs) as 16-byte write-through stores, drained before the block's ticket, and are read back with
-  // sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: the last-arriver form)
-  const int nblocks = gridDim.x;
-  const size_t slab_bytes = (size_t)SLAB4 * 16;
-  const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slabs, (unsigned long long)nblocks * slab_bytes);
-  const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gslabs, (unsigned long long)p.ngroups * slab_bytes);
-  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
-    f32x4 s;
-    if (i4 < TW / 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(red + 4 * i4), b = *reinterpret_cast<const f32x4*>(red + TW + 4 * i4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(red + 2 * TW + 4 * i4), d = *reinterpret_cast<const f32x4*>(red + 3 * TW + 4 * i4);
-      s = (a + b) + (c + d);
-    } else {
-      s = f32x4{(dbred[0] + dbred[1]) + (dbred[2] + dbred[3]), 0.f, 0.f, 0.f};
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rs, (int)(blockIdx.x * slab_bytes + i4 * 16), 0, 16);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int grp = blockIdx.x / p.group;
-  const int gfirst = grp * p.group, gcount = min(p.group, nblocks - gfirst);
-  if (threadIdx.x == 0) last = atomicInc(&p.state[1 + grp], (unsigned)gcount - 1u) == (unsigned)gcount - 1u;
-  __syncthreads();
-  if (!last) return;
-  auto sum_slabs = [&](const __amdgpu_buffer_rsrc_t r, int firstslab, int count, int i4) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
-    for (int b0 = 0; b0 < count; b0 += U) {            // eight loads in flight, added in slab order
-      u32x4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, b0 + u < count ? (int)((firstslab + b0 + u) * slab_bytes + i4 * 16) : (int)kOOB, 0, 16);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (b0 + u < count) s += __builtin_bit_cast(f32x4, v[u]);
-    }
-    return s;
-  };
-  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
-    const f32x4 s = sum_slabs(rs, gfirst, gcount, i4);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rg, (int)(grp * slab_bytes + i4 * 16), 0, 16);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicInc(&p.state[0], (unsigned)p.ngroups - 1u) == (unsigned)p.ngroups - 1u;
-  __syncthreads();
-  if (!last) return;
-  for (int i4 = threadIdx.x; i4 < SLAB4; i4 += 256) {
-    const f32x4 s = sum_slabs(rg, 0, p.ngroups, i4);
-    if (i4 == TW / 4) {
-      if (p.db) p.db[0] = s[0];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * i4 + e, t = i / 64, ch = i % 64;
-        if (ch < p.c) p.dw[t * p.c + ch] = s[e];
-      }
-    }
-  }
+  stencil1_bwd_reduce_tail<KS>(p, red, dbred, last);
 }
 
 

@@ -304,6 +304,9 @@ BOTH_CASES = [
     (2, 9, 13, 40, 'VALID', 40, 40),         # fewer channels than lanes, no padding: output smaller than the input
     (5, 7, 6, 64, 'SAME', 64, 72),           # fewer rows than two bands' reach; dx with a wider pixel stride
     (70, 5, 9, 24, 'SAME', 32, 24),          # more than 63 groups' worth of blocks at the default group size; strided x
+    (2, 12, 17, 64, 'VALID', 64, 64),        # 64 channels, no padding: the matrix-core form (round 6) with an output smaller than the input
+    (1, 19, 70, 64, 'SAME', 64, 64),         # ... three bands of 7 / 7 / 5 rows, pieces of 32 pixels that straddle rows
+    (300, 6, 5, 64, 'SAME', 64, 64),         # ... 300 one-band blocks: ten groups, a last piece of 30 pixels
 ]
 
 
