@@ -12,10 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ann3depth_amd import ops  # noqa: E402
 from tools.sweep_igemm import LAYERS, timeit  # noqa: E402
 
-B = 32
 SPECS = {l[0]: l[1:] for l in LAYERS}
 SPECS['gemm'] = (25, 40, 2400, 256, 1, 1, 'VALID')
 SPECS['gemmT'] = (25, 40, 256, 2400, 1, 1, 'VALID')      # its bwd-data is the same GEMM with both operands k-contiguous
+# DCNF's unary stack at batch 16 = 768 patches (src/models.py:61-83): its 5x5 conv and the first of its 3x3 convs
+SPECS['dcnf5'] = (45, 45, 64, 256, 5, 1, 'VALID')
+SPECS['dcnf3'] = (20, 20, 256, 256, 3, 1, 'VALID')
+BATCH = {'dcnf5': 768, 'dcnf3': 768}
 only = sys.argv[1:] or ['gemm', 'conv2d_1', 'conv2d_2', 'conv2d_3', 'fine2']
 PLANS = [('gen1 128x128w8', '7'), ('gen2 128x128w4', '11'), ('gen1 128x128w4', '0')]
 
@@ -31,6 +34,7 @@ for _ in range(100):
 torch.cuda.synchronize()
 for name in only:
     h, w, c, k, ks, st, pad = SPECS[name]
+    B = BATCH.get(name, 32)
     d = ops.conv_desc(B, h, w, c, k, ks, ks, st, pad)
     x = torch.randn((B, h, w, c), device='cuda'); wt = torch.randn((ks, ks, c, k), device='cuda') * 0.01
     bias = torch.zeros(k, device='cuda'); y = torch.empty((B, d.ho, d.wo, k), device='cuda'); dz = torch.randn_like(y)
@@ -42,7 +46,7 @@ for name in only:
     for mode, fn in modes.items():
         if name == 'gemmT' and mode != 'bwd_d':
             continue
-        kinds = [('sk', '1')] if ((mode == 'fwd' and tiles >= 400) or name == 'gemmT') else [('st', '512'), ('st', '256')]
+        kinds = [('sk', '1')] if ((mode == 'fwd' and tiles >= 400) or name == 'gemmT' or (tiles >= 2000 and mode != 'bwd_f')) else [('st', '512'), ('st', '256')]
         for kind, v in kinds:
             best = {}
             for rnd in range(4):
