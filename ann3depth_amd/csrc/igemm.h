@@ -520,13 +520,215 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, const f32x16 (&
       }
 }
 
+// ---- the same epilogues by raw buffer stores ----
+// store_quad branches per value (activation, dropout, output type, row in range), and the compiler closes each value's
+// control flow with s_waitcnt vmcnt(0) — the loads of the dropout / mask paths join there — so every store waited for the
+// round trip of the one before: 41 k cycles for the 64 stores of a lane against 3.4 k for a stream-K slab of the same
+// bytes, 8 - 20 us of every unsplit launch (in-kernel stamps).  Here every uniform choice branches once
+// per tile, the accumulators are finished in place (bias, activation, activation gradient: the mask's loads issued
+// together), and the stores follow each other with one v_add between them: the descriptor starts at the tile's first
+// row, so a lane's offset is `lane constant + uniform row offset`, and rows >= M / columns >= N fall outside
+// num_records (kOOB) instead of being branched around.
+// (base and extent are block-uniform, but the tile coordinates they come from live in vector registers — an integer
+// division — and a descriptor in vector registers makes the compiler wrap every access in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, size_t byte_off, uint32_t bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base) + byte_off;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// Which tiles may take it: row remaps (the parity classes of a strided bwd-data) and dropout (dense layers only) keep the
+// per-value form, and so does a pitch whose 128 rows would not fit a 31-bit offset.
+template <int MODE>
+__device__ __forceinline__ bool epi_buf_ok(const IgemmParams& p, int ldc, bool partial) {
+  if (ldc >= (1 << 21)) return false;
+  if (partial) return true;
+  if (MODE == MODE_BWD_D && p.sub_step > 1) return false;
+  if (MODE == MODE_FWD && p.keep) return false;
+  return true;
+}
+template <int MODE, int BM, int TM, int TN, int WM, int WN, bool MASK16, bool FASTEXP = true>
+__device__ __forceinline__ void store_tile_buf(const IgemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                               int li, int lh, float* Cout, int ldc, bool partial, bool c16) {
+  int rows_left = p.M - m0;
+  rows_left = rows_left < 0 ? 0 : (rows_left > BM ? BM : rows_left);
+  const uint32_t row_el = (uint32_t)((wm * WM + 4 * lh) * ldc);      // this lane's first row of the tile, in elements
+  uint32_t elb[TN];
+  bool okb[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = n0 + wn * WN + b * 32 + li;
+    okb[b] = col < p.N;
+    elb[b] = row_el + (uint32_t)col;
+  }
+  auto row_off = [&](int a, int e) -> uint32_t { return (uint32_t)((a * 32 + 8 * (e >> 2) + (e & 3)) * ldc); };   // uniform
+  if (!partial) {
+    if (MODE == MODE_FWD) {
+      float bias[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bias[b] = (p.bias && okb[b]) ? p.bias[n0 + wn * WN + b * 32 + li] : 0.f;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] += bias[b];
+      if (p.act == EPI_RELU) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = fmaxf(acc[a][b][e], 0.f);
+      } else if (p.act == EPI_SIGMOID) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 1.f / (1.f + (FASTEXP ? __expf(-acc[a][b][e]) : expf(-acc[a][b][e])));
+      }
+    } else if (MODE == MODE_BWD_D) {
+      if (p.mask) {
+        constexpr uint32_t MSZ = MASK16 ? 2u : 4u;
+        const __amdgpu_buffer_rsrc_t rsM = epi_rsrc(p.mask, (size_t)m0 * ldc * MSZ, (uint32_t)(rows_left * ldc) * MSZ);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            const uint32_t vb = okb[b] ? elb[b] * MSZ : kOOB;
+            float y[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              if constexpr (MASK16)
+                y[e] = (float)__builtin_bit_cast(
+                    __bf16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsM, (int)(vb + row_off(a, e) * MSZ), 0, 0));
+              else
+                y[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsM, (int)(vb + row_off(a, e) * MSZ), 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = apply_act_grad(acc[a][b][e], y[e], p.mask_act, p.mask_scale);
+          }
+      }
+    }
+  }
+  if (c16) {
+    const __amdgpu_buffer_rsrc_t rsC = epi_rsrc(Cout, (size_t)m0 * ldc * 2u, (uint32_t)(rows_left * ldc) * 2u);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const uint32_t vb = okb[b] ? elb[b] * 2u : kOOB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)acc[a][b][e]), rsC,
+                                                (int)(vb + row_off(a, e) * 2u), 0, 0);
+      }
+  } else {
+    const __amdgpu_buffer_rsrc_t rsC = epi_rsrc(Cout, (size_t)m0 * ldc * 4u, (uint32_t)(rows_left * ldc) * 4u);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const uint32_t vb = okb[b] ? elb[b] * 4u : kOOB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[a][b][e]), rsC, (int)(vb + row_off(a, e) * 4u), 0, 0);
+      }
+  }
+}
+// The fused 2x2 max pool: window g of an accumulator is its registers 4 g .. 4 g + 3 (conv rows row, .., row + 3), written
+// to pooled row `row / 4`.  Descriptors start at the tile's first pooled row.
+template <int BM, int TM, int TN, int WM, int WN, bool ROUND16 = false, bool FASTEXP = true>
+__device__ __forceinline__ void store_tile_pool_buf(const IgemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                    int li, int lh, float* Cout, int ldc, bool c16) {
+  static_assert(BM % 4 == 0 && WM % 4 == 0, "pool windows");
+  int rows_left = (p.M - m0) >> 2;      // pooled rows of this tile (host: M % 4 == 0)
+  rows_left = rows_left < 0 ? 0 : (rows_left > BM / 4 ? BM / 4 : rows_left);
+  const int prow = wm * (WM / 4) + lh;      // this lane's first pooled row of the tile
+  float val[TM][TN][4];
+  uint32_t arg[TM][TN];                     // four 2-bit positions
+  float bias[TN];
+  bool okb[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = n0 + wn * WN + b * 32 + li;
+    okb[b] = col < p.N;
+    bias[b] = (p.bias && okb[b]) ? p.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      arg[a][b] = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * g + i] + bias[b];
+        if (p.act == EPI_RELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        } else if (p.act == EPI_SIGMOID) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = 1.f / (1.f + (FASTEXP ? __expf(-v[i]) : expf(-v[i])));
+        }
+        if (ROUND16) {      // the bf16-storage kernels compare what a separate conv would have stored: rounded values
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (float)(__bf16)v[i];
+        }
+        float m = v[0];
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+          if (v[i] > m) { m = v[i]; w = (uint32_t)i; }
+        val[a][b][g] = m;
+        arg[a][b] |= w << (2 * g);
+      }
+    }
+  auto row_off = [&](int a, int g, int ld) -> uint32_t { return (uint32_t)((a * 8 + 2 * g) * ld); };      // uniform
+  const uint32_t esz = c16 ? 2u : 4u;
+  const __amdgpu_buffer_rsrc_t rsC = epi_rsrc(Cout, (size_t)(m0 >> 2) * ldc * esz, (uint32_t)(rows_left * ldc) * esz);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const uint32_t el = (uint32_t)(prow * ldc + n0 + wn * WN + b * 32 + li);
+      if (c16) {
+        const uint32_t vb = okb[b] ? el * 2u : kOOB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)val[a][b][g]), rsC,
+                                                (int)(vb + row_off(a, g, ldc) * 2u), 0, 0);
+      } else {
+        const uint32_t vb = okb[b] ? el * 4u : kOOB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[a][b][g]), rsC, (int)(vb + row_off(a, g, ldc) * 4u), 0, 0);
+      }
+    }
+  if (p.argmax) {
+    const __amdgpu_buffer_rsrc_t rsA = epi_rsrc(p.argmax, (size_t)(m0 >> 2) * p.N, (uint32_t)(rows_left * p.N));
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const uint32_t vb = okb[b] ? (uint32_t)(prow * p.N + n0 + wn * WN + b * 32 + li) : kOOB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((arg[a][b] >> (2 * g)) & 3u), rsA, (int)(vb + row_off(a, g, p.N)), 0, 0);
+      }
+  }
+}
+
 // What a block does with the accumulators of one share of one tile: a share that covers the tile's whole K range stores it
 // through the mode's epilogue (bias / activation / dropout, the fused 2x2 max pool, the activation gradient), a classic
 // split-K share stores raw sums into its slab, a stream-K share that ends inside the tile leaves the accumulators (and the
 // bias-gradient sums of `do_bias` threads) in the block's slab slot for igemm_fixup_kernel.  Shared by igemm_body and the
 // LDS-DMA kernel of igemm2.h (same accumulator layout: wave (wm, wn), accumulators [TM][TN] of 32x32).
 template <int MODE, int BM, int BN, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x16 (&acc)[TM][TN], const int split, const uint32_t bid,
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[TM][TN], const int split, const uint32_t bid,
                                                const int seg, const int kt_begin, const int kt_end, const int nk_total,
                                                const bool do_bias, const float bsum, const int tid, const int wave, const int lane,
                                                const int m0, const int n0, const int wm, const int wn) {
@@ -544,39 +746,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const f32x1
     slab_store<TM, TN>(p.sk_ws + slot * (size_t)(BM * BN), acc, wave, lane);
     if (MODE == MODE_BWD_F && do_bias) p.sk_bias[slot * BN + tid] = bsum;
   } else if (MODE == MODE_FWD && p.pool) {      // never split (host)
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn * WN + b * 32 + li;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = m0 + wm * WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
-          if (row >= p.M) continue;
-          // the values a separate conv would have stored, compared the way MaxPool / MaxPoolGrad scan them
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[a][b][4 * g + i] + bias;
-            if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
-            else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + __expf(-v[i]));
-          }
-          float val = v[0];
-          int arg = 0;
-#pragma unroll
-          for (int i = 1; i < 4; ++i)
-            if (v[i] > val) { val = v[i]; arg = i; }
-          if (p.c16) reinterpret_cast<__bf16*>(Cout)[(size_t)(row >> 2) * ldc + col] = (__bf16)val;
-          else Cout[(size_t)(row >> 2) * ldc + col] = val;
-          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
-        }
-      }
-    }
+    store_tile_pool_buf<BM, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, p.c16 != 0);
   } else {
     if (MODE == MODE_BWD_F && do_bias && n0 + tid < p.N) p.dbias[(partial ? (size_t)split * p.N : 0) + n0 + tid] = bsum;
-    store_tile<MODE, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial);
+    if (epi_buf_ok<MODE>(p, ldc, partial))
+      store_tile_buf<MODE, BM, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial, p.c16 && !partial);
+    else
+      store_tile<MODE, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial);
   }
 }
 

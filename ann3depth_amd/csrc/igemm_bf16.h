@@ -517,37 +517,13 @@ __device__ __forceinline__ void igemm_bf16_body(const IgemmParams& p, const uint
     }
   }
   if (MODE == MODE_FWD && p.pool) {      // never split (host): rows 4w .. 4w+3 are the conv outputs of pool window w (make_pix)
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn * Cfg::WN + b * 32 + li;
-        if (col >= p.N) continue;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = m0 + wm * Cfg::WM + a * 32 + 8 * g + 4 * lh;      // first conv output of the window
-          if (row >= p.M) continue;
-          // the values a separate conv would have stored (rounded to bf16 if its output tensor is), compared the way
-          // MaxPool / MaxPoolGrad scan them: first maximum wins
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[a][b][4 * g + i] + bias;
-            if (p.act == EPI_RELU) v[i] = fmaxf(v[i], 0.f);
-            else if (p.act == EPI_SIGMOID) v[i] = 1.f / (1.f + expf(-v[i]));
-            if (C16) v[i] = (float)(__bf16)v[i];
-          }
-          float val = v[0];
-          int arg = 0;
-#pragma unroll
-          for (int i = 1; i < 4; ++i)
-            if (v[i] > val) { val = v[i]; arg = i; }
-          if (C16) reinterpret_cast<__bf16*>(Cout)[(size_t)(row >> 2) * ldc + col] = (__bf16)val;
-          else Cout[(size_t)(row >> 2) * ldc + col] = val;
-          if (p.argmax) p.argmax[(size_t)(row >> 2) * p.N + col] = (uint8_t)arg;
-        }
-      }
+    // the values a separate conv would have stored (rounded to bf16 if its output tensor is), compared the way MaxPool /
+    // MaxPoolGrad scan them: first maximum wins (igemm.h: the epilogues by raw buffer stores)
+    store_tile_pool_buf<BM, TM, TN, Cfg::WM, Cfg::WN, C16, false>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, C16);
+    return;
+  }
+  if (epi_buf_ok<MODE>(p, ldc, partial)) {
+    store_tile_buf<MODE, BM, TM, TN, Cfg::WM, Cfg::WN, C16, false>(p, acc, m0, n0, wm, wn, li, lh, Cout, ldc, partial, C16 && !partial);
     return;
   }
 #pragma unroll

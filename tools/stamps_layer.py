@@ -27,7 +27,11 @@ y = torch.empty((B, d.ho, d.wo, k), device='cuda')
 dz = torch.randn_like(y)
 dx = torch.empty_like(x)
 dw = torch.empty_like(wt)
+yp = torch.empty((B, d.ho // 2, d.wo // 2, k), device='cuda')
+am = torch.empty((B, d.ho // 2, d.wo // 2, k), dtype=torch.uint8, device='cuda')
 fn = {'fwd': lambda: ops.conv2d_fwd(d, x, wt, bias, y, 'relu'),
+      'fwdpool': lambda: ops.conv2d_pool_fwd(d, x, wt, bias, yp, 'relu', am),
+      'fwdplain': lambda: ops.conv2d_fwd(d, x, wt, None, y, None),
       'bwd_f': lambda: ops.conv2d_bwd_filter(d, x, dz, dw, None),
       'bwd_d': lambda: ops.conv2d_bwd_data(d, dz, wt, dx)}[mode]
 for _ in range(3):
