@@ -685,28 +685,60 @@ __global__ __launch_bounds__(256) void dense_fwd_stream_kernel(const DenseStream
         *reinterpret_cast<f32x4*>(mine + ((vv & 3) + 8 * (vv >> 2) + 4 * lh) * 132 + 4 * li) = q;
       }
       __syncthreads();
+      // the eight sums of this thread first, then its stores back to back: with the split / bias / dropout branches around
+      // each store the compiler put s_waitcnt vmcnt(0) between them, and every block of the one-round grid ended with
+      // sixteen store round trips in a row
+      float sv[4][2];
+      bool okv[4][2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int lr = wave * 4 + r, m = 32 * b + 16 * hh + lr;
-        if (m >= p.M) continue;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int c = lane + 64 * h, col = n0 + c;
-          if (col >= p.N) continue;
+          const int c = lane + 64 * h;
+          okv[r][h] = m < p.M && n0 + c < p.N;
           float s = red[lr * 132 + c];
           s += red[(16 + lr) * 132 + c];
           s += red[(32 + lr) * 132 + c];
           s += red[(48 + lr) * 132 + c];
-          if (p.splits > 1) {
-            p.out[((size_t)split * p.M + m) * p.N + col] = s;
-          } else {
-            if (p.bias) s += p.bias[col];
+          sv[r][h] = s;
+        }
+      }
+      if (p.splits > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (okv[r][h]) p.out[((size_t)split * p.M + 32 * b + 16 * hh + wave * 4 + r) * p.N + n0 + lane + 64 * h] = sv[r][h];
+      } else {
+        float bias[2] = {0.f, 0.f};
+        uint8_t kp[4][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (p.bias && n0 + lane + 64 * h < p.N) bias[h] = p.bias[n0 + lane + 64 * h];
+        if (p.keep) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              kp[r][h] = okv[r][h] ? p.keep[(size_t)(32 * b + 16 * hh + wave * 4 + r) * p.N + n0 + lane + 64 * h] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float s = sv[r][h];
+            if (p.bias) s += bias[h];
             if (p.act == EPI_RELU) s = fmaxf(s, 0.f);
             else if (p.act == EPI_SIGMOID) s = 1.f / (1.f + expf(-s));
-            if (p.keep) s = p.keep[(size_t)m * p.N + col] ? s * p.scale : 0.f;
-            p.out[(size_t)m * p.N + col] = s;
+            if (p.keep) s = kp[r][h] ? s * p.scale : 0.f;
+            sv[r][h] = s;
           }
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (okv[r][h]) p.out[(size_t)(32 * b + 16 * hh + wave * 4 + r) * p.N + n0 + lane + 64 * h] = sv[r][h];
       }
     }
   }

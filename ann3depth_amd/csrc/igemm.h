@@ -481,29 +481,58 @@ template <int MODE>
 __device__ __forceinline__ void store_quad(const IgemmParams& p, const f32x4 q, int row0, int col, float* Cout, int ldc,
                                            bool partial) {
   if (col >= p.N) return;
-  float bias = 0.f;
-  if (!partial && MODE == MODE_FWD && p.bias) bias = p.bias[col];
+  // values first (every uniform choice branches once per quad, the loads of a mask are issued together), then the four
+  // stores back to back: with the branches inside the per-value loop each store was followed by s_waitcnt vmcnt(0) — the
+  // mask path's load joins there — and waited for the round trip of the one before (see store_tile_buf)
+  float v[4];
+  size_t o[4];
+  bool ok[4];
+  const bool remap = !partial && MODE == MODE_BWD_D;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = row0 + i;
-    if (row >= p.M) continue;
-    float val = q[i];
-    const size_t o = (partial || MODE != MODE_BWD_D
-                          ? (size_t)row
-                          : remap_row(row, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw)) *
-                         ldc + col;
-    if (!partial) {
-      if (MODE == MODE_FWD) {
-        val += bias;
-        if (p.act == EPI_RELU) val = fmaxf(val, 0.f);
-        else if (p.act == EPI_SIGMOID) val = 1.f / (1.f + __expf(-val));
-        if (p.keep) val = p.keep[(size_t)row * p.N + col] ? val * p.mask_scale : 0.f;
-      } else if (MODE == MODE_BWD_D) {
-        if (p.mask) val = apply_act_grad(val, p.mask[o], p.mask_act, p.mask_scale);
+    v[i] = q[i];
+    ok[i] = row < p.M;
+    o[i] = (remap ? remap_row(ok[i] ? row : 0, p.sub_step, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw, p.div_pw) : (size_t)row) *
+               ldc + col;
+  }
+  if (!partial) {
+    if (MODE == MODE_FWD) {
+      const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += bias;
+      if (p.act == EPI_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+      } else if (p.act == EPI_SIGMOID) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = 1.f / (1.f + __expf(-v[i]));
+      }
+      if (p.keep) {
+        uint8_t k[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k[i] = ok[i] ? p.keep[(size_t)(row0 + i) * p.N + col] : (uint8_t)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = k[i] ? v[i] * p.mask_scale : 0.f;
+      }
+    } else if (MODE == MODE_BWD_D) {
+      if (p.mask) {
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = ok[i] ? p.mask[o[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act_grad(v[i], y[i], p.mask_act, p.mask_scale);
       }
     }
-    if (p.c16 && !partial) reinterpret_cast<__bf16*>(Cout)[o] = (__bf16)val;      // bf16-stored output tensor
-    else Cout[o] = val;
+  }
+  if (p.c16 && !partial) {      // bf16-stored output tensor
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (ok[i]) reinterpret_cast<__bf16*>(Cout)[o[i]] = (__bf16)v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (ok[i]) Cout[o[i]] = v[i];
   }
 }
 template <int MODE, int TM, int TN, int WM, int WN>
@@ -1042,16 +1071,18 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   };
 
 #ifdef A3D_STAMPS
-  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0, rtbeg = 0, rtend = 0;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, d01 = 0, d12 = 0, d23 = 0, d34 = 0, d45 = 0, tbeg = 0, tend = 0, rtbeg = 0, rtend = 0, tp1 = 0, tp2 = 0;
 #endif
   auto k_loop = [&](auto uni_c) {
   // AHEAD: the next tile's addresses are computed one tile early, in the shadow of the MFMAs (forward / bwd-data: a
   // handful of scalar operations).  The bwd-filter gather reads its row table from LDS and keeps more lane state; there
   // the addresses are computed where they are used (measured: +4-7 % the other way round).
   constexpr bool AHEAD = MODE != MODE_BWD_F;
+  A3D_STAMP(tp1);
   if (nkt > 0) {
     prepare(uni_c, std::true_type{}, kt_begin, 0, true);
     if (AHEAD) prepare(uni_c, std::false_type{}, kt_begin + 1, 1, nkt > 1);
+    A3D_STAMP(tp2);
     store_tiles(0);
   }
   __syncthreads();
@@ -1208,7 +1239,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const uint32_t 
   A3D_RTSTAMP(rtend);
   if (p.stamps && lane == 0) {
     unsigned long long* o = p.stamps + ((size_t)bid_in * NWAVES + wave) * 16;
-    o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = 0;
+    o[0] = d01; o[1] = d12; o[2] = d23; o[3] = d34; o[4] = d45; o[5] = tend - tbeg; o[6] = (unsigned long long)nkt; o[7] = tp1 - t_entry; o[15] = tp2 - tp1;
     o[8] = tbeg - t_entry; o[9] = t_entry; o[10] = tend; o[12] = rtend - rtbeg; o[13] = rtbeg; o[14] = rtend;
   }
 #define A3D_STAMP_EXIT()                                                                                   \

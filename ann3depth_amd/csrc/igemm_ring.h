@@ -771,6 +771,40 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
         continue;
       }
     }
+    if (MODE == MODE_BWD_D && !partial && p.mask && (unsigned)ldc < (1u << 20)) {
+      // ReluGrad of the layer below: dx = 0 where its activation is not positive.  The mask pieces of the whole 32-row group
+      // are requested first and the stores follow them: with the load inside the store loop every store waited for its
+      // mask's round trip AND for the store before it (vmcnt counts both; seen in the ISA as one s_waitcnt vmcnt(0) per
+      // store).  Descriptors based at the tile's first row: rows >= M and invalid columns lie past their ends (igemm.h).
+      int rows_left = p.M - m0;
+      rows_left = rows_left < 0 ? 0 : (rows_left > BM ? BM : rows_left);
+      const __amdgpu_buffer_rsrc_t rsM = epi_rsrc(p.mask, (size_t)m0 * ldc * ESZ, (uint32_t)(rows_left * ldc) * ESZ);
+      const __amdgpu_buffer_rsrc_t rsC = epi_rsrc(Cout, (size_t)m0 * ldc * ESZ, (uint32_t)(rows_left * ldc) * ESZ);
+      const int col0 = n0 + wn * Cfg::WN + ec * (16 / ESZ);
+      const bool lane_ok = (LPR == LPRP || ec < LPR) && col0 < p.N;
+      const uint32_t v0 = lane_ok ? (uint32_t)((wm * Cfg::WM + a * 32 + er) * ldc + col0) * ESZ : kOOB;
+      u32x4 mk[32 / RPI];
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i)
+        mk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (int)(v0 + (uint32_t)(i * RPI * ldc) * ESZ), 0, 0);
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int r = i * RPI + er;
+        u32x4 q = *reinterpret_cast<const u32x4*>(eb + r * EP + (LPR != LPRP && ec >= LPR ? 0 : ec) * 16);
+        if constexpr (C16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool lo = __uint_as_float(mk[i][e] << 16) > 0.f, hi = __uint_as_float(mk[i][e] & 0xffff0000u) > 0.f;
+            q[e] &= (lo ? 0x0000ffffu : 0u) | (hi ? 0xffff0000u : 0u);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] = __uint_as_float(mk[i][e]) > 0.f ? q[e] : 0u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(q, rsC, (int)(v0 + (uint32_t)(i * RPI * ldc) * ESZ), 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 32 / RPI; ++i) {
       const int r = i * RPI + er;

@@ -65,4 +65,12 @@ ok = rt > 0
 if ok.any():
     print(f'  clock held during the loops: {np.mean(a[ok, 5] / rt[ok]) * 0.1:.3f} GHz (loop cycles / 100 MHz ticks; min {np.min(a[ok, 5] / rt[ok]) * 0.1:.3f} max {np.max(a[ok, 5] / rt[ok]) * 0.1:.3f}); '
           f'first loop start -> last loop end {(raw[ok, 14].astype(np.int64).max() - raw[ok, 13].astype(np.int64).min()) * 0.01:.1f} us')
-print(f'  of P: issue of the A tile loads {np.mean(a[:, 7] / nkt):.0f} cyc/tile (incl. the prologue tile)')
+if ok.any():
+    rb = (raw[ok, 13].astype(np.int64) - raw[ok, 13].astype(np.int64).min()) * 0.01
+    first = rb < 30.0
+    print(f'  prologue parts (cycles): setup {a[:, 7].mean():.0f}, address + issue of tiles 0/1 {a[:, 15].mean():.0f}, wait + LDS store + barrier '
+          f'{(a[:, 8] - a[:, 7] - a[:, 15]).mean():.0f}; loop starts of the first round ({first.sum()} waves): '
+          f'10% {np.percentile(rb[first], 10):.1f} 50% {np.percentile(rb[first], 50):.1f} 90% {np.percentile(rb[first], 90):.1f} max {rb[first].max():.1f} us after the first')
+    lb = (t_entry + raw[:, 8].astype(np.int64) - t0)[ok][first]
+    print(f'  first-round loop starts, cycles after the first wave entered the kernel: 10% {np.percentile(lb, 10):.0f} 50% {np.percentile(lb, 50):.0f} 90% {np.percentile(lb, 90):.0f}; '
+          f'entries of those waves: 50% {np.percentile((t_entry - t0)[ok][first], 50):.0f} 90% {np.percentile((t_entry - t0)[ok][first], 90):.0f}')
