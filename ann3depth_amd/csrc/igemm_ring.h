@@ -658,27 +658,49 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   // neighbouring column of the same rows.
   auto erow = [&](int e) { return M16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * lh; };
   auto ecol = [&](int e) { return M16 ? 16 * ((e >> 2) & 1) + (lane & 15) : li; };
+  // this lane's bias values, all requested before the first sub-tile: loaded where they are used, each was a dependent
+  // global load (an L2 round trip) at the head of its sub-tile — eight in a row for a 64 x 128 wave tile
+  float bias_all[TN][2];
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int col = n0 + wn * Cfg::WN + b * 32 + ecol(4 * h2);
+      bias_all[b][h2] = (MODE == MODE_FWD && !partial && p.bias && (M16 || h2 == 0) && col < p.N) ? p.bias[col] : 0.f;
+    }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      float bias[2] = {0.f, 0.f};
-#pragma unroll
-      for (int h2 = 0; h2 < (M16 ? 2 : 1); ++h2) {
-        const int col = n0 + wn * Cfg::WN + b * 32 + ecol(4 * h2);
-        if (MODE == MODE_FWD && !partial && p.bias && col < p.N) bias[h2] = p.bias[col];
-      }
+      const float bias[2] = {bias_all[b][0], bias_all[b][1]};
+      // every uniform choice (activation, dropout) branches once per 32 x 32 sub-tile, not once per value: with the branches
+      // inside the value loop the sub-tile's code was ~1 200 instructions of which the ReLU path executes 100, jumping
+      // over the sigmoid's and the dropout's sixteen times — the epilogue of the whole kernel 50 KB of code walked in
+      // hops, each hop an instruction-cache miss on every CU at once (in-kernel stamps: 25.7 k cycles for conv2d_1's
+      // forward at batch 64, a fifth of its loop)
       float val[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         if constexpr (M16) val[v] = acc16[2 * a + (v >> 3)][2 * b + ((v >> 2) & 1)][v & 3];
         else val[v] = acc[a][b][v];
-        if (MODE == MODE_BWD_D && !partial && p.mask) val[v] *= p.mask_scale;       // (dropout's gradient factor; the mask itself: 16-byte phase)
-        if (MODE == MODE_FWD && !partial) {
-          val[v] += bias[M16 ? (v >> 2) & 1 : 0];
-          if (p.act == EPI_RELU) val[v] = fmaxf(val[v], 0.f);
-          else if (p.act == EPI_SIGMOID) val[v] = 1.f / (1.f + expf(-val[v]));
-          if (p.keep) {                            // tf.layers.dropout fused (dense layers: a handful of rows)
+      }
+      if (MODE == MODE_BWD_D && !partial && p.mask) {       // (dropout's gradient factor; the mask itself: 16-byte phase)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) val[v] *= p.mask_scale;
+      }
+      if (MODE == MODE_FWD && !partial) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) val[v] += bias[M16 ? (v >> 2) & 1 : 0];
+        if (p.act == EPI_RELU) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) val[v] = fmaxf(val[v], 0.f);
+        } else if (__builtin_expect(p.act == EPI_SIGMOID, 0)) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) val[v] = 1.f / (1.f + expf(-val[v]));
+        }
+        if (__builtin_expect(p.keep != nullptr, 0)) {      // tf.layers.dropout fused (dense layers: a handful of rows; out of line)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
             const int row = m0 + wm * Cfg::WM + a * 32 + erow(v), col = n0 + wn * Cfg::WN + b * 32 + ecol(v);
             if (row < p.M && col < p.N) val[v] = p.keep[(size_t)row * p.N + col] ? val[v] * p.mask_scale : 0.f;
           }
