@@ -75,7 +75,7 @@ int dense_dw_launch(int m, int k, int n, const float* x, const float* dz, float*
 // ---- BiasAddGrad of a bf16 gradient tensor beside the LDS-DMA bwd-filter (igemm_ring.hip) ----
 size_t colsum_bf16_ws_bytes(int n);
 bool colsum_bf16_ok(int n);
-int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, hipStream_t st);
+int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, int* nparts, hipStream_t st);
 
 // ---- single-output-channel 5x5 stencil (stencil1.hip) ----
 bool stencil1_applicable(const a3d_conv_desc* d);

@@ -203,6 +203,9 @@ struct IgemmParams {
   // only the first c_cols columns of the GEMM's N are stored to C (rows of a tensor narrower than the padded GEMM)
   void* out2;
   int out2_ld, out2_step, out2_off, out2_bf16, out2_cols, c_cols;
+  // host only (launch_igemm): BiasAddGrad partial sums [dbias_parts_n][N] computed beside the launch (the LDS-DMA bwd-filter never
+  // holds dz in registers); the split-K reduction adds them into dbias_parts_out on the side instead of a launch of its own
+  const float* dbias_parts; float* dbias_parts_out; int dbias_parts_n;
   FastDiv div_nk;               // k-tiles per tile
   int share;                    // host only: A3D_HINT_SHARE_CU — launch with enough dynamic LDS that <= 8 waves fit a CU
   int dbg;                      // diagnostic builds only: bit 0 / 1 = A / B tile loads fetch nothing
@@ -1363,6 +1366,8 @@ struct ReduceParams {
   int vec4;              // plain 16-byte sum (bwd-filter slabs)
   int c16;               // output (and BWD_D mask) tensors are bf16
   const float* dbias_ws; float* dbias_out;     // bwd-filter: the [splitk][N] BiasAddGrad slabs ride along, or null
+  int dbias_splits;      // > 0: dbias_ws holds that many rows instead of splitk (the column-sum partials of colsum_bf16), added by
+  unsigned dbias_block0; //      the blocks dbias_block0 .. of the grid, sixteen threads per column (reduce_wide)
   void* C2; int ld2, step2, off2, c2_16, cols2;      // second output: element (row, col < cols2) at (row * ld2 + col) * step2 + off2
   int c_cols;            // > 0: columns >= c_cols are not stored to C
   int row_rl, row_rlp;   // vec4 sums of a window-run filter gradient: row rr*row_rlp + q of the slabs is row rr*row_rl + q of

@@ -416,9 +416,21 @@ __device__ __forceinline__ size_t unpadded_pos(size_t i, int nv, int rl, int rlp
   const size_t rr = row / (size_t)rlp, q = row - rr * (size_t)rlp;
   return q < (size_t)rl ? (rr * (size_t)rl + q) * (size_t)nv + c : SIZE_MAX;
 }
+template <typename V>
+__device__ __forceinline__ void reduce_wide(const V* src, V* dst, size_t slab, size_t count, int splitk, size_t first, V* lds, int nv,
+                                            int rl, int rlp);
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p) {
   const size_t total = (size_t)p.M * p.N;
-  if (p.dbias_out) {       // N sums of `splitk` values: the grid's first threads do them on the side
+  unsigned nblk = gridDim.x;
+  if (p.dbias_splits > 0) {      // up to 256 rows of column-sum partials: blocks of their own, sixteen threads per column
+    __shared__ float lds[256];
+    if (blockIdx.x >= p.dbias_block0) {
+      reduce_wide<float>(p.dbias_ws, p.dbias_out, (size_t)p.N, (size_t)p.N, p.dbias_splits, (size_t)(blockIdx.x - p.dbias_block0) * 16, lds,
+                         0, 0, 0);
+      return;
+    }
+    nblk = p.dbias_block0;
+  } else if (p.dbias_out) {       // N sums of `splitk` values: the grid's first threads do them on the side
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)p.N; i += (size_t)gridDim.x * 256)
       p.dbias_out[i] = slab_sum<float>(p.dbias_ws, (size_t)p.N, p.splitk, i);
   }
@@ -427,13 +439,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceParams p
     const size_t nv = total / 4;
     const f4* ws4 = reinterpret_cast<const f4*>(p.ws);
     const size_t slab4 = p.slab / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)nblk * 256) {
       const size_t o = unpadded_pos(i, p.N / 4, p.row_rl, p.row_rlp);
       if (o != SIZE_MAX) reinterpret_cast<f4*>(p.C)[o] = slab_sum<f4>(ws4, slab4, p.splitk, i);
     }
     return;
   }
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
     float s = slab_sum<float>(p.ws, p.slab, p.splitk, i);
     const int row = (int)(i / p.N), col = (int)(i - (size_t)row * p.N);
     const size_t o = remap_row(row, p.mode == MODE_BWD_D ? p.sub_step : 1, p.sub_ph, p.sub_pw, p.outW, p.outHW, p.div_phw,
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(256) void second_output_kernel(const void* C, int c
 // one-thread sum above: a launch uses one or the other by shape alone, never by timing).
 template <typename V>
 __device__ __forceinline__ void reduce_wide(const V* src, V* dst, size_t slab, size_t count, int splitk, size_t first,
-                                            V* lds, int nv = 0, int rl = 0, int rlp = 0) {
+                                            V* lds, int nv, int rl, int rlp) {
   const int tid = threadIdx.x, out = tid & 15, part = tid >> 4;
   const size_t i = first + out;
   const int per = (splitk + 15) / 16, z0 = part * per, z1 = min(splitk, z0 + per);
@@ -513,8 +525,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const ReducePar
     reduce_wide<f4>(reinterpret_cast<const f4*>(p.ws), reinterpret_cast<f4*>(p.C), p.slab / 4, (size_t)p.M * p.N / 4,
                     p.splitk, (size_t)blockIdx.x * 16, lds, p.N / 4, p.row_rl, p.row_rlp);
   else
-    reduce_wide<float>(p.dbias_ws, p.dbias_out, (size_t)p.N, (size_t)p.N, p.splitk, (size_t)(blockIdx.x - blocks_c) * 16,
-                       reinterpret_cast<float*>(lds));
+    reduce_wide<float>(p.dbias_ws, p.dbias_out, (size_t)p.N, (size_t)p.N, p.dbias_splits > 0 ? p.dbias_splits : p.splitk, (size_t)(blockIdx.x - blocks_c) * 16,
+                       reinterpret_cast<float*>(lds), 0, 0, 0);
 }
 
 int launch_splitk_reduce(const ReduceParams& r, hipStream_t st) {
@@ -527,7 +539,10 @@ int launch_splitk_reduce(const ReduceParams& r, hipStream_t st) {
     return check_launch("splitk_reduce_wide");
   }
   const unsigned g = (unsigned)std::min<size_t>(((r.vec4 ? total / 4 : total) + 255) / 256, 2048);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, st, r);
+  ReduceParams rr = r;
+  rr.dbias_block0 = g;
+  const unsigned gb = (r.dbias_out && r.dbias_splits > 0) ? (unsigned)((r.N + 15) / 16) : 0u;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g + gb), dim3(256), 0, st, rr);
   return check_launch("splitk_reduce");
 }
 
@@ -623,6 +638,7 @@ int launch_igemm(int mode, const GemmPlan& plan, int avec, int bvec, IgemmParams
     r.div_phw = p.div_phw; r.div_pw = p.div_pw;
     r.dbias_ws = final_dbias ? p.dbias : nullptr;
     r.dbias_out = final_dbias;
+    if (p.dbias_parts) { r.dbias_ws = p.dbias_parts; r.dbias_out = p.dbias_parts_out; r.dbias_splits = p.dbias_parts_n; }
     if (r.vec4 && p.unpad_dst && p.unpad_rlp > 0 && p.N % 4 == 0 && aligned16(p.unpad_dst)) {
       r.C = p.unpad_dst; r.row_rl = p.unpad_rl; r.row_rlp = p.unpad_rlp;
       p.unpad_done = 1;
@@ -1537,8 +1553,12 @@ int a3d_conv2d_bwd_filter(const a3d_conv_desc* d, const float* x, const float* d
   if (need > ws_bytes) return set_error(A3D_EWORKSPACE, "conv2d_bwd_filter: need %zu workspace bytes", need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (plan.ring && db) {                           // the LDS-DMA kernel never holds dz in registers: BiasAddGrad on the side
-    rc = colsum_bf16(dz, g.K, d->k, d->ldy, db, static_cast<char*>(ws) + plan.ws_bytes, st);
+    // a split launch ends in a reduction kernel anyway: that one adds the partial sums (one launch fewer per layer)
+    float* parts = reinterpret_cast<float*>(static_cast<char*>(ws) + plan.ws_bytes);
+    int nparts = 0;
+    rc = colsum_bf16(dz, g.K, d->k, d->ldy, plan.splitk > 1 ? nullptr : db, parts, &nparts, st);
     if (rc != A3D_OK) return rc;
+    if (plan.splitk > 1) { p.dbias_parts = parts; p.dbias_parts_out = db; p.dbias_parts_n = nparts; }
     db = nullptr;
   }
   p.A = x; p.B = dz; p.C = out; p.dbias = db;     // BiasAddGrad = column sums of dz, fused into the same kernel

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   constexpr int CPR = BN / 8;                     // its 16-byte chunks per row
 
 #ifdef A3D_STAMPS           // diagnostic build (never shipped): cycle stamps of the loop's phases, per wave (tools/stamps_ring.py)
-  unsigned long long st_entry = 0, st_beg = 0, st_end = 0, st_s0 = 0, st_s1 = 0, st_s2 = 0, st_d1 = 0, st_dw = 0, st_d2 = 0, st_rt0 = 0, st_rt1 = 0;
+  unsigned long long st_entry = 0, st_beg = 0, st_end = 0, st_s0 = 0, st_s1 = 0, st_s2 = 0, st_d1 = 0, st_dw = 0, st_d2 = 0, st_rt0 = 0, st_rt1 = 0, st_tab = 0, st_fire = 0;
   A3D_STAMP(st_entry);
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -194,6 +194,9 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     taptab[t] = e;
   }
   __syncthreads();
+#ifdef A3D_STAMPS
+  A3D_STAMP(st_tab);
+#endif
 
   // ---- per-lane constants of the LDS-DMA pieces.  Piece (j, wave) of a [rows][64 k] image covers rows 8 (8 j + wave) ..
   //      + 7, lane l its row (l >> 3) and chunk position l & 7; successive j are 64 rows apart: the same swizzle ----
@@ -312,6 +315,20 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     for (int d = 0; d < NDMA; ++d) fire_one(stg, d);
   };
 
+  // The first tile's requests leave NOW: everything between here and the loop (fragment addresses, 128 accumulator
+  // registers to clear) happens while they are in flight instead of ahead of them — one block per CU, nothing else covers
+  // the prologue.
+  if (nkt > 0) {
+    prep_head(kt_begin);
+    prep_all(aoff, boff);
+    fire(0);
+    prep_head(kt_begin + 1);
+    prep_all(aoff, boff);
+  }
+#ifdef A3D_STAMPS
+  A3D_STAMP(st_fire);
+#endif
+
   // ---- fragment addresses: LDS byte offsets per STAGE, loop-invariant registers (made opaque so that the compiler keeps them
   //      instead of re-deriving one from another with a VALU add ahead of every read: a read without address arithmetic
   //      can be issued in any MFMA shadow).  k-contiguous images: one register per (stage, k-step) — the k-step is an XOR
@@ -425,11 +442,6 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
       }
     };
     if (nkt > 0) {
-      prep_head(kt_begin);
-      prep_all(aoff, boff);
-      fire(0);
-      prep_head(kt_begin + 1);
-      prep_all(aoff, boff);
       ring_landed();
       __syncthreads();
       if (nkt > 1) fire(1);
@@ -524,11 +536,6 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
   constexpr bool math = true, dbar = true, dland = true, dreads = true;
 #endif
   if (nkt > 0) {
-    prep_head(kt_begin);
-    prep_all(aoff, boff);
-    fire(0);
-    prep_head(kt_begin + 1);
-    prep_all(aoff, boff);
     ring_landed();
     __syncthreads();
     if (nkt > 1) {
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(512, (RingCfg<MODE, BM, BN, WAVES_M>::MIN_WAVES)) v
     if (p.stamps && lane == 0) {
       unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 16;
       o[0] = st_d1; o[1] = st_dw; o[2] = st_d2; o[3] = st_end - st_beg; o[4] = st_rt1 - st_rt0; o[5] = (unsigned long long)nkt;
-      o[6] = st_beg - st_entry; o[7] = st_exit - st_end; o[8] = st_entry; o[9] = st_exit;
+      o[6] = st_beg - st_entry; o[7] = st_exit - st_end; o[8] = st_entry; o[9] = st_exit; o[10] = st_tab - st_entry; o[11] = st_fire - st_tab;
     }
   }
 #endif

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 }
 size_t colsum_bf16_ws_bytes(int n) { return (size_t)256 * n * 4; }
 bool colsum_bf16_ok(int n) { return n % 8 == 0 && n >= 8 && n / 8 <= 256; }
-int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, hipStream_t st) {
+// out == nullptr: pass 1 only — the caller adds the *nparts rows of `ws` itself (the split-K reduction of the launch beside it)
+int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, int* nparts, hipStream_t st) {
   const int blocks = std::min(256, std::max(1, rows / 64));
   const int rpb = (rows + blocks - 1) / blocks;
   const int used = (rows + rpb - 1) / rpb;
@@ -148,7 +149,8 @@ int colsum_bf16(const void* dz, int rows, int n, int ld, float* out, void* ws, h
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(used), dim3(256), 0, st, static_cast<const __bf16*>(dz), static_cast<float*>(ws), rows, n,
                      ld, rpb);
   int rc = check_launch("colsum_bf16");
-  if (rc != A3D_OK) return rc;
+  if (nparts) *nparts = used;
+  if (rc != A3D_OK || !out) return rc;
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 63) / 64), dim3(256), 0, st, static_cast<const float*>(ws), out, n, used);
   return check_launch("colsum_finish");
 }

@@ -60,4 +60,6 @@ for i, n in enumerate(['k-steps 0..2 (24 MFMA slots of this wave)', 'wait for th
 t_entry, t_exit = raw[:, 8].astype(np.int64), raw[:, 9].astype(np.int64)
 print(f'  prologue {a[:, 6].mean():.0f} cycles (min {a[:, 6].min():.0f} max {a[:, 6].max():.0f}), loop {a[:, 3].mean():.0f}, '
       f'epilogue {a[:, 7].mean():.0f} (min {a[:, 7].min():.0f} max {a[:, 7].max():.0f})')
+print(f'  prologue parts: tables + first barrier {a[:, 10].mean():.0f}, lane constants + offsets + requests of tile 0 {a[:, 11].mean():.0f}, '
+      f'fragment addresses + wait for tile 0 + barrier + first reads {(a[:, 6] - a[:, 10] - a[:, 11]).mean():.0f}')
 print(f'  kernel span (first entry -> last exit) {t_exit.max() - t_entry.min()} cycles; entries spread over {t_entry.max() - t_entry.min()}')
