@@ -396,6 +396,63 @@ def test_conv2d_strided_pixels(ops):
     assert (got[..., k:] == 7.0).all()
 
 
+GUARD_CASES = [
+    # n, h, w, c, k, ksize, ld (output pixel stride)      rows of the last tile past M, columns past N, pitch wider than N
+    (2, 21, 30, 64, 64, 5, 64),       # fine/second kind: one column tile exactly, 1260 rows = 9 tiles of 128 + 108
+    (1, 27, 37, 96, 72, 5, 80),       # 72 of 128 (96) columns, pitch 80, 999 rows
+    (3, 13, 18, 32, 200, 3, 208),     # two column tiles, the second with 72 columns
+    (1, 9, 11, 16, 4, 3, 12),         # one tile, 99 rows x 4 columns of it
+]
+
+
+@pytest.mark.parametrize('n,h,w,c,k,ks,ld', GUARD_CASES)
+def test_tile_epilogues_leave_guard_rows_and_columns_alone(ops, n, h, w, c, k, ks, ld):
+    """The tile epilogues store through a buffer descriptor that ends with the tile's last valid row; columns past N are
+    offsets past its end (igemm.h: store_tile_buf / store_tile_pool_buf).  Every output tensor here is a window of a
+    larger allocation filled with a sentinel: pad columns, and the rows that follow the tensor, must keep it — forward
+    (plain, bias + ReLU, fused pool with its argmax bytes) and bwd-data with the ReluGrad mask."""
+    rng = np.random.default_rng(n * 1000 + k)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((ks, ks, c, k)) / np.sqrt(ks * ks * c)).astype(np.float32)
+    bias = rng.standard_normal(k).astype(np.float32)
+    d = ops.conv_desc(n, h, w, c, k, ks, ks, 1, 'SAME', ldy=ld)
+    rows = n * h * w
+    big = torch.full((rows + 300, ld), 7.0, device='cuda')
+    y = big[:rows].view(n, h, w, ld)
+    y_ref = T.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, 'SAME')
+    for act in (None, 'relu'):
+        big.fill_(7.0)
+        ops.conv2d_fwd(d, dev(x), dev(wt), dev(bias), y, act)
+        got = big.cpu().numpy()
+        ref = np.maximum(y_ref, 0) if act else y_ref
+        assert rel_l2(got[:rows, :k], ref.reshape(rows, k)) < RTOL_F32
+        assert (got[:rows, k:] == 7.0).all() and (got[rows:] == 7.0).all()
+    # fused 2x2 max pool: the pooled tensor and its argmax bytes, each followed by guard rows
+    ph, pw = h // 2, w // 2
+    prow = n * ph * pw
+    pbig = torch.full((prow + 100, ld), 7.0, device='cuda')
+    abig = torch.full((prow + 100, k), 9, device='cuda', dtype=torch.uint8)
+    ops.conv2d_pool_fwd(d, dev(x), dev(wt), dev(bias), pbig[:prow].view(n, ph, pw, ld), 'relu', abig[:prow].view(n, ph, pw, k))
+    relu = np.maximum(y_ref, 0)[:, :2 * ph, :2 * pw].reshape(n, ph, 2, pw, 2, k).transpose(0, 1, 3, 5, 2, 4).reshape(prow, k, 4)
+    got = pbig.cpu().numpy()
+    assert rel_l2(got[:prow, :k], relu.max(-1)) < RTOL_F32
+    assert (got[:prow, k:] == 7.0).all() and (got[prow:] == 7.0).all()
+    a = abig.cpu().numpy()
+    assert (a[:prow] < 4).all() and (a[prow:] == 9).all()
+    # bwd-data into a window of a wider buffer (pixel stride ld2 > c), ReluGrad mask read with the same pitch
+    ld2 = c + 8
+    dd = ops.conv_desc(n, h, w, c, k, ks, ks, 1, 'SAME', ldx=ld2)
+    dz = rng.standard_normal((n, h, w, k)).astype(np.float32)
+    xb = torch.full((rows + 200, ld2), 0.0, device='cuda')
+    xb[:rows, :c] = dev(x).view(rows, c)
+    dxb = torch.full((rows + 200, ld2), 7.0, device='cuda')
+    ops.conv2d_bwd_data(dd, dev(dz), dev(wt), dxb[:rows].view(n, h, w, ld2), relu_mask=xb[:rows].view(n, h, w, ld2))
+    dx_ref = T.conv2d_bwd_data(dz.astype(np.float64), wt.astype(np.float64), (n, h, w, c), 1, 'SAME') * (x > 0)
+    got = dxb.cpu().numpy()
+    assert rel_l2(got[:rows, :c], dx_ref.reshape(rows, c)) < RTOL_F32
+    assert (got[:rows, c:] == 7.0).all() and (got[rows:] == 7.0).all()
+
+
 @pytest.mark.parametrize('n,h,w,k,ks,st,y16', [(2, 23, 32, 63, 9, 2, True), (3, 17, 20, 16, 5, 2, False), (1, 40, 36, 8, 11, 4, True)])
 def test_conv_fwd_bf16_image_form(ops, n, h, w, k, ks, st, y16):
     """A 3-channel image stored as bf16 pixels of 4 channels (a3d_pad_channels_bf16) through the bf16 kernel's window-run
